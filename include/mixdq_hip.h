@@ -1,0 +1,164 @@
+/*
+ * mixdq_hip.h -- C-ABI of libmixdq_hip.so, the MI355X (gfx950) implementation of the
+ * MixDQ W8A8 operator stack (quantize -> INT8 GEMM / implicit-GEMM conv -> dequant epilogue).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch types, no libtorch link.
+ * Every entry point cites the reference interface it replaces (paths relative to the
+ * reference checkout, kernels/mixdq_extension/...).  The Python shim that turns these back into
+ * the reference's `mixdq_extension._C` functions is mixdq_amd/_C.py; the binding a reference
+ * maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions (same as the reference's pybind layer):
+ *   - all pointers are DEVICE pointers unless stated otherwise; inputs are borrowed;
+ *   - outputs are caller-allocated (the Python shim uses torch.empty so the caching allocator
+ *     and graph capture keep working);
+ *   - every call is an asynchronous launch on `stream` (a hipStream_t passed as void*);
+ *     no host synchronisation, no allocation, scalars (scale_inv, zero_point) are read on the
+ *     device  =>  safe under hipGraph capture;
+ *   - return value: MIXDQ_OK (0) or an error code; the shim raises RuntimeError with
+ *     mixdq_status_string(code) (reference: TORCH_CHECK -> RuntimeError).
+ *   - no global mutable state.
+ */
+#ifndef MIXDQ_HIP_H_
+#define MIXDQ_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MIXDQ_ABI_VERSION 1
+
+typedef void* mixdq_stream_t; /* hipStream_t */
+
+enum mixdq_status {
+  MIXDQ_OK = 0,
+  MIXDQ_ERR_INVALID_ARG = 1,     /* null pointer, negative size, ndim out of range ...            */
+  MIXDQ_ERR_ALIGNMENT = 2,       /* "Int8 kernel with input or output alignment not to 4 is not
+                                    supported." (qlinear.cc:131-134, qconv2d.cc:200-203)          */
+  MIXDQ_ERR_UNSUPPORTED = 3,     /* dilation != 1 (op/qconv2d.py:120 "dilation has bugs")         */
+  MIXDQ_ERR_LAUNCH = 4           /* hipGetLastError() != hipSuccess ("CUTLASS kernel failed")    */
+};
+
+/* Bit flags accepted by the compute entry points. */
+enum mixdq_flags {
+  /* Epilogue / quantize rounding variant.  Default (0) = variant A: the
+     multiply-add is one fused FMA (what nvcc -fmad=true makes of the reference's mul+add).
+     MIXDQ_FLAG_UNFUSED = variant B: round after the multiply, then add.                          */
+  MIXDQ_FLAG_UNFUSED = 1
+};
+
+const char* mixdq_status_string(int status);
+int mixdq_abi_version(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * a1. FP16 -> INT8 per-tensor affine quantize.
+ * Replaces: quantize_per_tensor_to_int8 / quantize_per_tensor_to_int8_vectorized
+ *           (csrc/quant_dequant/quantize.cc:9-53, quantize_kernel.cu:10-48,
+ *            quantize_kernel_vectorized.cu:29-95).  One kernel serves both names.
+ *   q = (int8) clamp(rint(fma(f32(x), *scale_inv, *zero_point)), -128, 127)
+ * `sizes`/`x_strides`/`out_strides` are HOST arrays of length ndim (1..8), strides in elements.
+ * The reference reads x linearly and ignores strides (quantize_kernel.cu:20-25), which is only
+ * right for dense inputs; this entry point implements the intended strided semantics.
+ */
+int mixdq_quantize_f16_i8(const void* x_f16, int8_t* out,
+                          const int64_t* sizes, const int64_t* x_strides,
+                          const int64_t* out_strides, int ndim,
+                          const float* scale_inv, const float* zero_point,
+                          int flags, mixdq_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a2. INT8 x INT8 -> INT32 GEMM with FP32 epilogue -> FP16.
+ * Replaces: qlinear_w8_a8_ohalf (csrc/qlinear/qlinear.cc:13-137) and the four CUTLASS kernels
+ *           cutlassGemm_{withBias,noBias}_{optimal,small}Alignment.cu.
+ *   D[m,n] = f16( fma( (f32(sum_k A[m,k]*W[n,k]) - bias0[n]), scale[n], f32(bias[n]) ) )
+ *            (no bias: f16((acc - bias0[n]) * scale[n]))
+ * A: [M,K] row-major (lda = K), W: [N,K] row-major, D: [M,N] row-major (ldd = N).
+ * Alignment: K % 4 == 0 and N % 4 == 0, else MIXDQ_ERR_ALIGNMENT (qlinear.cc:96-134).
+ * The reference's unused arguments (weight_scale, input_scale, input_zero_point,
+ * weight_sum_by_input_channels) stay in the Python signature and are not passed down.
+ */
+int mixdq_qlinear_w8a8(const int8_t* A, const int8_t* W,
+                       const float* bias0, const float* scale,
+                       const void* bias_f16_or_null, void* D_f16,
+                       int64_t M, int N, int K,
+                       int flags, mixdq_stream_t stream);
+
+/* Same GEMM with an output row map, used by QuantizedLinear's BOS path (nn/Linear.py:178-194)
+ * to write rows straight into the [B, T, N] result instead of torch.cat:
+ *   D_row(m) = (m / group_rows) * group_stride + group_offset + (m % group_rows)
+ * (group_rows = T-1 = 76, group_stride = T = 77, group_offset = 1).  group_rows <= 0 = identity.
+ */
+int mixdq_qlinear_w8a8_rows(const int8_t* A, const int8_t* W,
+                            const float* bias0, const float* scale,
+                            const void* bias_f16_or_null, void* D_f16,
+                            int64_t M, int N, int K,
+                            int group_rows, int group_stride, int group_offset,
+                            int flags, mixdq_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a3 + a4. INT8 NHWC implicit-GEMM conv2d (cross-correlation) with the same epilogue, and the
+ * activation zero-point propagation for padded convs.
+ * Replaces: qconv2d_w8_a8_ohalf (csrc/qconv2d/qconv2d.cc:27-206), the eight CUTLASS conv
+ *           kernels cutlassConv2d_*.cu, and activation_zero_point_propagate
+ *           (csrc/qconv2d/conv_act_zero_point_propagate.cu:11-83).
+ * X: [N,H,W,C] int8 (channels-last), Wt: [K,R,S,C] int8 (channels-last weight),
+ * D: [N,P,Q,K] f16 (channels-last), P = (H + 2*pad - R)/stride + 1 (same for Q).
+ *   pad == 0: bias0[K] required (per-channel);  wsum ignored.
+ *   pad  > 0: wsum[K,R,S] f32 and *zero_point required; per output pixel
+ *             bias0[n,p,q,k] = f32(sum over in-bounds taps of wsum[k,r,s]) * zp.
+ *             The reference materialises that as an [N,P,Q,K] f32 tensor on every call; here a
+ *             small table of tap-subset sums (mixdq_conv_border_table) is built into `workspace`
+ *             on the same stream and the conv epilogue looks its border class up per pixel.
+ * `workspace`: device buffer of at least mixdq_qconv2d_workspace_bytes(K,R,S,pad) bytes
+ *             (may be null when that is 0).
+ * dilation must be 1 (MIXDQ_ERR_UNSUPPORTED otherwise); C % 4 == 0 and K % 4 == 0.
+ */
+size_t mixdq_qconv2d_workspace_bytes(int K, int R, int S, int pad);
+
+int mixdq_qconv2d_w8a8(const int8_t* X_nhwc, const int8_t* Wt_krsc,
+                       const float* scale,
+                       const float* wsum_krs_or_null, const float* zero_point,
+                       const float* bias0_or_null,
+                       const void* bias_f16_or_null, void* D_nhwc_f16,
+                       void* workspace,
+                       int N, int H, int W, int C, int K, int R, int S,
+                       int stride, int pad, int dilation,
+                       int flags, mixdq_stream_t stream);
+
+/* The two halves of the call above, for callers that cache the table per layer
+ * (mixdq_amd.nn.QuantizedConv2d does: the table depends only on the weights). */
+int mixdq_conv_border_table(const float* wsum_krs, float* table,
+                            int K, int R, int S, mixdq_stream_t stream);
+
+int mixdq_qconv2d_w8a8_table(const int8_t* X_nhwc, const int8_t* Wt_krsc,
+                             const float* scale,
+                             const float* table_or_null, const float* zero_point,
+                             const float* bias0_or_null,
+                             const void* bias_f16_or_null, void* D_nhwc_f16,
+                             int N, int H, int W, int C, int K, int R, int S,
+                             int stride, int pad,
+                             int flags, mixdq_stream_t stream);
+
+/* Stand-alone restatement of the reference's materialised zero-point propagation
+ * (conv_act_zero_point_propagate.cu:11-83): out[n,p,q,k] f32, NHWC.  Not on the fast path;
+ * kept so the a4 row of the scope table has a directly comparable artefact. */
+int mixdq_conv_zero_point_propagate(const float* wsum_krs, const float* zero_point,
+                                    float* out_npqk,
+                                    int N, int H, int W, int K, int R, int S,
+                                    int stride, int pad, mixdq_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * FP16 debug GEMM.  Replaces: qlinear_fp_reference (csrc/qlinear/qlinear.cc:140-204,
+ * cutlassGemm_reference.cu:117-283).  D[M,N] = A[M,K] * B[K,N], B row-major [K,N]
+ * (qlinear.cc:161), FP32 accumulate, FP16 out.  Not on the hot path.
+ */
+int mixdq_gemm_f16(const void* A_f16, const void* B_f16_kn, void* D_f16,
+                   int64_t M, int N, int K, mixdq_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIXDQ_HIP_H_ */

@@ -1,0 +1,245 @@
+/*
+ * mixdq_oracle.c -- CPU restatement of the MixDQ W8A8 operator arithmetic.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under mixdq_amd/ may import, link or call this file; only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it, as the checker.
+ *
+ * Each function follows one reference file (paths relative to the reference checkout,
+ * kernels/mixdq_extension/...).  The reference's native path cannot be built here (CUDA +
+ * an un-vendored, unpinned NVIDIA/cutlass submodule: .gitmodules:1-3, kernels/setup.py:19-23), so
+ * this file restates the specified arithmetic and is pinned by
+ *   - torch.quantize_per_tensor on CPU, the reference's own exact check (op/quant.py:24-27);
+ *   - the reference's in-file integer/FP reference formulas (op/qlinear.py:66-83,
+ *     op/qconv2d.py:65-95) at the reference's tolerances;
+ *   - the reference's imported Python (nn/Linear.py, nn/Conv2d.py, qdiff QuantLayer) run over
+ *     this oracle, committed as tests/golden/ fixtures (tests/golden/gen_golden.py).
+ * Bit-level agreement with the CUDA binary itself is UNPINNED in this container: whether nvcc
+ * contracted the epilogue's mul+add into an FMA cannot be observed without a CUDA toolchain.
+ * `variant` selects: 0 = A, fused (fmaf), the likelier one under nvcc -fmad=true; 1 = B, unfused.
+ *
+ * Plain C99, no dependencies.  Build: see oracle/Makefile.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- IEEE half <-> float, exact / round-to-nearest-even ---------------------------------- */
+static float h2f(uint16_t h) {
+  uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+  uint32_t exp = (h >> 10) & 0x1fu;
+  uint32_t man = h & 0x3ffu;
+  uint32_t bits;
+  if (exp == 0) {
+    if (man == 0) {
+      bits = sign;
+    } else { /* subnormal: normalise */
+      int e = -1;
+      do { man <<= 1; e++; } while (!(man & 0x400u));
+      man &= 0x3ffu;
+      bits = sign | ((uint32_t)(127 - 15 - e) << 23) | (man << 13);
+    }
+  } else if (exp == 31) {
+    bits = sign | 0x7f800000u | (man << 13);
+  } else {
+    bits = sign | ((exp + 127 - 15) << 23) | (man << 13);
+  }
+  float f;
+  memcpy(&f, &bits, 4);
+  return f;
+}
+
+static uint16_t f2h(float f) { /* round-to-nearest-even; overflow -> inf (no saturation) */
+  uint32_t x;
+  memcpy(&x, &f, 4);
+  uint16_t sign = (uint16_t)((x >> 16) & 0x8000u);
+  uint32_t ax = x & 0x7fffffffu;
+  if (ax >= 0x7f800000u) { /* inf / nan */
+    return (uint16_t)(sign | 0x7c00u | ((ax > 0x7f800000u) ? 0x200u | ((ax >> 13) & 0x3ffu) : 0));
+  }
+  if (ax >= 0x477ff000u) { /* >= 65520 rounds to inf */
+    return (uint16_t)(sign | 0x7c00u);
+  }
+  if (ax < 0x33000001u) { /* < 2^-25 (or == 2^-25: ties to even -> 0) */
+    return sign;
+  }
+  int e = (int)(ax >> 23) - 127;
+  uint32_t man = (ax & 0x7fffffu) | 0x800000u; /* 24-bit significand */
+  int shift;
+  uint32_t hexp;
+  if (e < -14) { /* subnormal half */
+    shift = 13 + (-14 - e);
+    hexp = 0;
+  } else {
+    shift = 13;
+    hexp = (uint32_t)(e + 15);
+  }
+  uint32_t q = man >> shift;
+  uint32_t rem = man & ((1u << shift) - 1u);
+  uint32_t half = 1u << (shift - 1);
+  if (rem > half || (rem == half && (q & 1u))) q++;
+  uint32_t out;
+  if (hexp == 0) {
+    out = q; /* may carry into exponent 1: correct */
+  } else {
+    out = ((hexp - 1) << 10) + q; /* q has the implicit bit at 0x400; carry propagates */
+  }
+  return (uint16_t)(sign | out);
+}
+
+/* Exposed for the Python-side tests of the converters themselves. */
+float mixdq_oracle_h2f(uint16_t h) { return h2f(h); }
+uint16_t mixdq_oracle_f2h(float f) { return f2h(f); }
+
+static int8_t quant1(float xf, float s_inv, float zp, int variant) {
+  /* quantize_kernel.cu:21-25: lrintf(x * scale_inv + zp), clamp, cast.  lrintf = RNE. */
+  float t;
+  if (variant == 0) {
+    t = fmaf(xf, s_inv, zp);
+  } else {
+    volatile float p = xf * s_inv; /* volatile: forbid contraction */
+    t = p + zp;
+  }
+  /* lrintf on NaN/huge is UB in C; the GPU's v_cvt_i32_f32 saturates and maps NaN to 0. */
+  long r;
+  if (t != t) r = 0;
+  else if (t >= 2147483520.0f) r = 2147483647L;
+  else if (t <= -2147483648.0f) r = -2147483647L - 1;
+  else r = lrintf(t);
+  if (r < -128) r = -128;
+  if (r > 127) r = 127;
+  return (int8_t)r;
+}
+
+/* a1: quantize_kernel.cu:10-27 / quantize_kernel_vectorized.cu:29-72, with the intended strided
+ * read: logical index -> x offset via x_strides, out offset via
+ * out_strides.  ndim <= 8.  Row-major logical order. */
+void mixdq_oracle_quantize(const uint16_t* x, int8_t* out, const int64_t* sizes,
+                           const int64_t* x_strides, const int64_t* out_strides, int ndim,
+                           float s_inv, float zp, int variant) {
+  int64_t idx[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int64_t numel = 1;
+  for (int d = 0; d < ndim; d++) numel *= sizes[d];
+  for (int64_t i = 0; i < numel; i++) {
+    int64_t xo = 0, oo = 0;
+    for (int d = 0; d < ndim; d++) {
+      xo += idx[d] * x_strides[d];
+      oo += idx[d] * out_strides[d];
+    }
+    out[oo] = quant1(h2f(x[xo]), s_inv, zp, variant);
+    for (int d = ndim - 1; d >= 0; d--) {
+      if (++idx[d] < sizes[d]) break;
+      idx[d] = 0;
+    }
+  }
+}
+
+/* Epilogue: cutlassGemm_withBias_optimalAlignment.cu:29-95 (Accum -> minus Bias0 ->
+ * multiplies Scale -> plus Bias1 -> store half, all FloatRoundStyle::round_to_nearest). */
+static uint16_t epilogue(int32_t acc, float bias0, float scale, int has_bias, uint16_t bias_h,
+                         int variant) {
+  float v = (float)acc; /* cvt.rn.f32.s32 */
+  volatile float d = v - bias0;
+  float r;
+  if (!has_bias) {
+    volatile float m = d * scale;
+    r = m;
+  } else if (variant == 0) {
+    r = fmaf(d, scale, h2f(bias_h));
+  } else {
+    volatile float m = d * scale;
+    r = m + h2f(bias_h);
+  }
+  return f2h(r);
+}
+
+/* a2: qlinear.cc:13-137.  A [M,K], W [N,K], D [M,N] f16 bits.  acc_out (optional) receives the
+ * exact int32 accumulators. */
+void mixdq_oracle_qlinear(const int8_t* A, const int8_t* W, const float* bias0,
+                          const float* scale, const uint16_t* bias_or_null, uint16_t* D,
+                          int32_t* acc_out_or_null, int64_t M, int N, int K, int variant) {
+  for (int64_t m = 0; m < M; m++) {
+    const int8_t* a = A + m * (int64_t)K;
+    for (int n = 0; n < N; n++) {
+      const int8_t* w = W + (int64_t)n * K;
+      int32_t acc = 0;
+      for (int k = 0; k < K; k++) acc += (int32_t)a[k] * (int32_t)w[k];
+      if (acc_out_or_null) acc_out_or_null[m * N + n] = acc;
+      D[m * N + n] = epilogue(acc, bias0[n], scale[n], bias_or_null != NULL,
+                              bias_or_null ? bias_or_null[n] : 0, variant);
+    }
+  }
+}
+
+/* a4: conv_act_zero_point_propagate.cu:23-51.  out [N,P,Q,K] f32.  `acc` is a float sum in
+ * (r, s) order, exactly as the reference's template<float> instantiation. */
+void mixdq_oracle_zp_propagate(const float* wsum_krs, float zp, float* out, int N, int H, int W,
+                               int K, int R, int S, int P, int Q, int stride, int pad) {
+  for (int n = 0; n < N; n++)
+    for (int p = 0; p < P; p++)
+      for (int q = 0; q < Q; q++)
+        for (int k = 0; k < K; k++) {
+          int h0 = -pad + p * stride, w0 = -pad + q * stride;
+          float acc = 0.f;
+          for (int r = 0; r < R; r++)
+            for (int s = 0; s < S; s++) {
+              int h = h0 + r, w = w0 + s;
+              if (h >= 0 && h < H && w >= 0 && w < W) acc += wsum_krs[((int64_t)k * R + r) * S + s];
+            }
+          out[(((int64_t)n * P + p) * Q + q) * K + k] = acc * zp;
+        }
+}
+
+/* a3: qconv2d.cc:27-206.  X [N,H,W,C], Wt [K,R,S,C], D [N,P,Q,K] f16 bits.
+ * pad == 0: bias0 [K] (qconv2d.cc:117-120,144-146);  pad > 0: wsum [K,R,S] + zp -> per-pixel
+ * bias0 (qconv2d.cc:131-136).  Zero padding is 0 in the INT8 domain. */
+void mixdq_oracle_qconv2d(const int8_t* X, const int8_t* Wt, const float* scale,
+                          const float* wsum_or_null, float zp, const float* bias0_or_null,
+                          const uint16_t* bias_or_null, uint16_t* D, int32_t* acc_out_or_null,
+                          int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
+                          int variant) {
+  int P = (H + 2 * pad - (R - 1) - 1) / stride + 1;
+  int Q = (W + 2 * pad - (S - 1) - 1) / stride + 1;
+  for (int n = 0; n < N; n++)
+    for (int p = 0; p < P; p++)
+      for (int q = 0; q < Q; q++) {
+        int h0 = -pad + p * stride, w0 = -pad + q * stride;
+        for (int k = 0; k < K; k++) {
+          int32_t acc = 0;
+          float wacc = 0.f;
+          for (int r = 0; r < R; r++)
+            for (int s = 0; s < S; s++) {
+              int h = h0 + r, w = w0 + s;
+              if (h < 0 || h >= H || w < 0 || w >= W) continue;
+              const int8_t* xp = X + (((int64_t)n * H + h) * W + w) * C;
+              const int8_t* wp = Wt + (((int64_t)k * R + r) * S + s) * C;
+              for (int c = 0; c < C; c++) acc += (int32_t)xp[c] * (int32_t)wp[c];
+              if (pad > 0) wacc += wsum_or_null[((int64_t)k * R + r) * S + s];
+            }
+          float b0 = (pad > 0) ? wacc * zp : bias0_or_null[k];
+          int64_t o = (((int64_t)n * P + p) * Q + q) * K + k;
+          if (acc_out_or_null) acc_out_or_null[o] = acc;
+          D[o] = epilogue(acc, b0, scale[k], bias_or_null != NULL,
+                          bias_or_null ? bias_or_null[k] : 0, variant);
+        }
+      }
+}
+
+/* f16 + f16 -> f16 elementwise (torch's half add: f32 add, one rounding), used by the split
+ * conv_shortcut: nn/Conv2d.py:345 `output = output + output_0`. */
+void mixdq_oracle_add_f16(const uint16_t* a, const uint16_t* b, uint16_t* out, int64_t n) {
+  for (int64_t i = 0; i < n; i++) out[i] = f2h(h2f(a[i]) + h2f(b[i]));
+}
+
+/* FP16 debug GEMM: qlinear.cc:140-204 (B is [K,N] row-major, qlinear.cc:161).  FP32 accumulate
+ * here; the reference accumulates in half (cutlassGemm_reference.cu:133) and is only checked to
+ * rtol 1e-4 / atol 1e-2 (op/qlinear.py:95). */
+void mixdq_oracle_gemm_f16(const uint16_t* A, const uint16_t* B, uint16_t* D, int64_t M, int N,
+                           int K) {
+  for (int64_t m = 0; m < M; m++)
+    for (int n = 0; n < N; n++) {
+      float acc = 0.f;
+      for (int k = 0; k < K; k++) acc = fmaf(h2f(A[m * K + k]), h2f(B[(int64_t)k * N + n]), acc);
+      D[m * N + n] = f2h(acc);
+    }
+}

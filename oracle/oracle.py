@@ -1,0 +1,207 @@
+"""ctypes front-end of oracle/mixdq_oracle.c (+ a NumPy mirror used to cross-check the C).
+
+TEST INFRASTRUCTURE ONLY -- see oracle/__init__.py.  The arithmetic specification and the
+reference file:line each function follows are in mixdq_oracle.c; "parity pinning" is described
+in that file's header and in DESIGN.md.
+
+All functions take/return NumPy arrays.  FP16 tensors are np.float16; the C side sees their
+bit patterns as uint16.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libmixdq_oracle.so")
+_lib = None
+
+VARIANT_FUSED = 0    # variant A: fmaf (default; nvcc -fmad=true contraction)
+VARIANT_UNFUSED = 1  # variant B: separate mul and add
+
+
+def build(force: bool = False) -> str:
+    """Compile the C oracle with the committed Makefile (gcc only)."""
+    if force or not os.path.exists(_LIB_PATH) or (
+            os.path.getmtime(_LIB_PATH) < os.path.getmtime(os.path.join(_HERE, "mixdq_oracle.c"))):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B" if force else "all"])
+    return _LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        L = ctypes.CDLL(_LIB_PATH)
+        vp, i64, i32, f32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_float
+        L.mixdq_oracle_quantize.argtypes = [vp, vp, vp, vp, vp, i32, f32, f32, i32]
+        L.mixdq_oracle_quantize.restype = None
+        L.mixdq_oracle_qlinear.argtypes = [vp, vp, vp, vp, vp, vp, vp, i64, i32, i32, i32]
+        L.mixdq_oracle_qlinear.restype = None
+        L.mixdq_oracle_zp_propagate.argtypes = [vp, f32, vp] + [i32] * 10
+        L.mixdq_oracle_zp_propagate.restype = None
+        L.mixdq_oracle_qconv2d.argtypes = [vp, vp, vp, vp, f32, vp, vp, vp, vp] + [i32] * 10
+        L.mixdq_oracle_qconv2d.restype = None
+        L.mixdq_oracle_add_f16.argtypes = [vp, vp, vp, i64]
+        L.mixdq_oracle_add_f16.restype = None
+        L.mixdq_oracle_gemm_f16.argtypes = [vp, vp, vp, i64, i32, i32]
+        L.mixdq_oracle_gemm_f16.restype = None
+        L.mixdq_oracle_h2f.argtypes = [ctypes.c_uint16]
+        L.mixdq_oracle_h2f.restype = f32
+        L.mixdq_oracle_f2h.argtypes = [f32]
+        L.mixdq_oracle_f2h.restype = ctypes.c_uint16
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _c(a, dtype):
+    return None if a is None else np.ascontiguousarray(a, dtype=dtype)
+
+
+def _elem_strides(a: np.ndarray):
+    return np.asarray([s // a.itemsize for s in a.strides], dtype=np.int64)
+
+
+def quantize(x: np.ndarray, scale_inv: float, zero_point: float,
+             variant: int = VARIANT_FUSED) -> np.ndarray:
+    """a1.  x: float16 array of any strides.  Returns int8 of the same shape (C-contiguous)."""
+    assert x.dtype == np.float16
+    out = np.empty(x.shape, dtype=np.int8)
+    if x.size == 0:
+        return out
+    sizes = np.asarray(x.shape if x.ndim else (1,), dtype=np.int64)
+    xs = _elem_strides(x) if x.ndim else np.asarray([1], dtype=np.int64)
+    os_ = _elem_strides(out) if x.ndim else np.asarray([1], dtype=np.int64)
+    assert (xs >= 0).all(), "negative strides not supported"
+    lib().mixdq_oracle_quantize(_p(x), _p(out), _p(sizes), _p(xs), _p(os_), int(sizes.size),
+                                float(np.float32(scale_inv)), float(np.float32(zero_point)),
+                                variant)
+    return out
+
+
+def qlinear(a_i8, w_i8, bias0, scale, bias=None, variant=VARIANT_FUSED, return_acc=False):
+    """a2.  a_i8 [..., K] int8, w_i8 [N, K] int8, bias0/scale [N] f32, bias [N] f16 or None.
+    Returns float16 [..., N] (and the exact int32 accumulators if return_acc)."""
+    a = _c(a_i8, np.int8)
+    w = _c(w_i8, np.int8)
+    N, K = w.shape
+    assert a.shape[-1] == K
+    M = a.size // K if K else 0
+    b0 = _c(np.asarray(bias0).reshape(-1), np.float32)
+    sc = _c(np.asarray(scale).reshape(-1), np.float32)
+    bs = None if bias is None else _c(np.asarray(bias).reshape(-1), np.float16)
+    assert b0.size == N and sc.size == N and (bs is None or bs.size == N)
+    D = np.empty(a.shape[:-1] + (N,), dtype=np.float16)
+    acc = np.empty(a.shape[:-1] + (N,), dtype=np.int32) if return_acc else None
+    if M:
+        lib().mixdq_oracle_qlinear(_p(a), _p(w), _p(b0), _p(sc), _p(bs), _p(D), _p(acc),
+                                   M, N, K, variant)
+    return (D, acc) if return_acc else D
+
+
+def conv_out_hw(H, W, R, S, stride, pad):
+    return (H + 2 * pad - (R - 1) - 1) // stride + 1, (W + 2 * pad - (S - 1) - 1) // stride + 1
+
+
+def zp_propagate(wsum_krs, zp, N, H, W, stride, pad):
+    """a4.  wsum [K,1,R,S] or [K,R,S] f32 -> bias0 [N,P,Q,K] f32 (NHWC order)."""
+    ws = _c(wsum_krs, np.float32)
+    if ws.ndim == 4:
+        ws = ws.reshape(ws.shape[0], ws.shape[2], ws.shape[3])
+    K, R, S = ws.shape
+    P, Q = conv_out_hw(H, W, R, S, stride, pad)
+    out = np.empty((N, P, Q, K), dtype=np.float32)
+    lib().mixdq_oracle_zp_propagate(_p(ws), float(np.float32(zp)), _p(out), N, H, W, K, R, S,
+                                    P, Q, stride, pad)
+    return out
+
+
+def qconv2d(x_nhwc, w_krsc, scale, wsum=None, zp=0.0, bias0=None, bias=None, stride=1, pad=0,
+            variant=VARIANT_FUSED, return_acc=False):
+    """a3.  x [N,H,W,C] int8 (NHWC order), w [K,R,S,C] int8.  Returns float16 [N,P,Q,K]."""
+    x = _c(x_nhwc, np.int8)
+    w = _c(w_krsc, np.int8)
+    N, H, W, C = x.shape
+    K, R, S, C2 = w.shape
+    assert C == C2
+    sc = _c(np.asarray(scale).reshape(-1), np.float32)
+    ws = None
+    if pad > 0:
+        assert wsum is not None
+        ws = _c(np.asarray(wsum).reshape(K, R, S), np.float32)
+    else:
+        assert bias0 is not None
+    b0 = None if bias0 is None else _c(np.asarray(bias0).reshape(-1), np.float32)
+    bs = None if bias is None else _c(np.asarray(bias).reshape(-1), np.float16)
+    P, Q = conv_out_hw(H, W, R, S, stride, pad)
+    D = np.empty((N, P, Q, K), dtype=np.float16)
+    acc = np.empty((N, P, Q, K), dtype=np.int32) if return_acc else None
+    lib().mixdq_oracle_qconv2d(_p(x), _p(w), _p(sc), _p(ws), float(np.float32(zp)), _p(b0),
+                               _p(bs), _p(D), _p(acc), N, H, W, C, K, R, S, stride, pad, variant)
+    return (D, acc) if return_acc else D
+
+
+def add_f16(a, b):
+    a = _c(a, np.float16)
+    b = _c(b, np.float16)
+    out = np.empty_like(a)
+    lib().mixdq_oracle_add_f16(_p(a), _p(b), _p(out), a.size)
+    return out
+
+
+def gemm_f16(a, b_kn):
+    a = _c(a, np.float16)
+    b = _c(b_kn, np.float16)
+    K, N = b.shape
+    M = a.size // K
+    D = np.empty(a.shape[:-1] + (N,), dtype=np.float16)
+    lib().mixdq_oracle_gemm_f16(_p(a), _p(b), _p(D), M, N, K)
+    return D
+
+
+# ------------------------------------------------------------------------------------------
+# NumPy mirror: an independent second restatement of the same arithmetic, used by
+# tests/test_oracle.py to cross-check the C code (two restatements that agree bit-for-bit).
+# ------------------------------------------------------------------------------------------
+def np_quantize(x, scale_inv, zero_point, variant=VARIANT_FUSED):
+    xf = x.astype(np.float32)
+    s = np.float32(scale_inv)
+    z = np.float32(zero_point)
+    if variant == VARIANT_FUSED:
+        # exact product in float64 (24b x 24b fits 53b), one rounding of the sum to f32
+        t = (xf.astype(np.float64) * np.float64(s) + np.float64(z)).astype(np.float32)
+        # double rounding hazard: f64 sum may itself be inexact; guard by checking exactness
+        # (|x*s| and z differ by < 2^29 in exponent for every input used in tests).
+    else:
+        t = (xf * s).astype(np.float32) + z
+    r = np.rint(t)  # half-to-even
+    return np.clip(r, -128, 127).astype(np.int8)
+
+
+def np_epilogue(acc_i32, bias0, scale, bias=None, variant=VARIANT_FUSED):
+    v = acc_i32.astype(np.float32)
+    d = (v - bias0.astype(np.float32)).astype(np.float32)
+    if bias is None:
+        r = (d * scale.astype(np.float32)).astype(np.float32)
+    elif variant == VARIANT_FUSED:
+        r = (d.astype(np.float64) * scale.astype(np.float64)
+             + bias.astype(np.float64)).astype(np.float32)
+    else:
+        r = (d * scale.astype(np.float32)).astype(np.float32) + bias.astype(np.float32)
+    with np.errstate(over="ignore"):
+        return r.astype(np.float16)
+
+
+def np_qlinear(a_i8, w_i8, bias0, scale, bias=None, variant=VARIANT_FUSED):
+    acc = a_i8.astype(np.int32).reshape(-1, a_i8.shape[-1]) @ w_i8.astype(np.int32).T
+    out = np_epilogue(acc, np.asarray(bias0)[None, :], np.asarray(scale)[None, :],
+                      None if bias is None else np.asarray(bias)[None, :], variant)
+    return out.reshape(a_i8.shape[:-1] + (w_i8.shape[0],))
