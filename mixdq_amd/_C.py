@@ -1,0 +1,317 @@
+"""`mixdq_extension._C` for MI355X: the five operator entry points of the reference's pybind
+module (csrc/main.cpp:9-13), same names, argument order, kwarg names and error behaviour, backed
+by libmixdq_hip.so (include/mixdq_hip.h) through ctypes.
+
+    quantize_per_tensor_to_int8(input, scale_inv, zero_point)              quantize.cc:9-30
+    quantize_per_tensor_to_int8_vectorized(input, scale_inv, zero_point)   quantize.cc:32-53
+    qlinear_w8_a8_ohalf(input_int8, weight_int8, weight_scale, input_scale, input_zero_point,
+                        weight_sum_by_input_channels, scale, bias0, bias=None)   qlinear.cc:13-137
+    qconv2d_w8_a8_ohalf(input_int8, weight_int8, weight_scale, input_scale, input_zero_point,
+                        scale, weight_sum_by_input_channels, bias0, bias=None, stride=1,
+                        padding=0, dilation=1)                               qconv2d.cc:27-206
+    qlinear_fp_reference(input, weight, bias=None)                           qlinear.cc:140-204
+
+PyTorch is plumbing here: device memory (torch.empty -> caching allocator, so hipGraph capture
+works), the current stream and error propagation.  There is NO CPU or eager fallback: if the HIP
+library is missing the import fails, and non-GPU tensors raise like the reference's TORCH_CHECKs.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libmixdq_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} not found: the HIP extension has not been built. Run "
+        "`python -m mixdq_amd.build` (needs hipcc). There is no CPU fallback.")
+
+_lib = ctypes.CDLL(LIB_PATH)
+
+_vp, _i64, _i32, _sz = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_size_t
+_lib.mixdq_status_string.restype = ctypes.c_char_p
+_lib.mixdq_status_string.argtypes = [_i32]
+_lib.mixdq_abi_version.restype = _i32
+_lib.mixdq_quantize_f16_i8.argtypes = [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp]
+_lib.mixdq_qlinear_w8a8.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]
+_lib.mixdq_qlinear_w8a8_rows.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32,
+                                         _i32, _i32, _i32, _i32, _vp]
+_lib.mixdq_qconv2d_workspace_bytes.restype = _sz
+_lib.mixdq_qconv2d_workspace_bytes.argtypes = [_i32] * 4
+_lib.mixdq_qconv2d_w8a8.argtypes = [_vp] * 9 + [_i32] * 11 + [_vp]
+_lib.mixdq_conv_border_table.argtypes = [_vp, _vp, _i32, _i32, _i32, _vp]
+_lib.mixdq_qconv2d_w8a8_table.argtypes = [_vp] * 8 + [_i32] * 10 + [_vp]
+_lib.mixdq_conv_zero_point_propagate.argtypes = [_vp, _vp, _vp] + [_i32] * 8 + [_vp]
+_lib.mixdq_gemm_f16.argtypes = [_vp, _vp, _vp, _i64, _i32, _i32, _vp]
+for _n in ("mixdq_quantize_f16_i8", "mixdq_qlinear_w8a8", "mixdq_qlinear_w8a8_rows",
+           "mixdq_qconv2d_w8a8", "mixdq_conv_border_table", "mixdq_qconv2d_w8a8_table",
+           "mixdq_conv_zero_point_propagate", "mixdq_gemm_f16"):
+    getattr(_lib, _n).restype = _i32
+
+ABI_VERSION = _lib.mixdq_abi_version()
+
+# Rounding variant of the fused multiply-adds: "A" (default) = FMA,
+# "B" = separate multiply and add.  Read once at import; no other global state.
+FLAGS = 1 if os.environ.get("MIXDQ_EPILOGUE_VARIANT", "A").upper() == "B" else 0
+
+
+def _check(cond: bool, msg: str):
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def _status(code: int, what: str):
+    if code != 0:
+        raise RuntimeError(f"{what}: {_lib.mixdq_status_string(code).decode()}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def _i64arr(vals):
+    return (ctypes.c_int64 * len(vals))(*vals)
+
+
+def _f32vec(t: torch.Tensor) -> torch.Tensor:
+    """Per-channel epilogue vectors are read with 16-byte loads: contiguous and aligned."""
+    t = t.contiguous()
+    if t.data_ptr() % 16:
+        t = t.clone()
+    return t
+
+
+def _quantize(input, scale_inv, zero_point):
+    _check(input.is_cuda, "input should be on CUDA")
+    _check(input.device == scale_inv.device, "input and scale should be on the same device")
+    _check(input.device == zero_point.device,
+           "input and zero_point should be on the same device")
+    _check(input.dtype == torch.float16, "input should be fp16")
+    _check(scale_inv.dtype == torch.float32, "scale_inv should be fp32")
+    _check(zero_point.dtype == torch.float32, "zero_point should be fp32")
+    out = torch.empty_like(input, dtype=torch.int8)
+    if input.numel() == 0:
+        return out
+    nd = input.dim()
+    sizes = list(input.shape) if nd else [1]
+    xs = list(input.stride()) if nd else [1]
+    os_ = list(out.stride()) if nd else [1]
+    with torch.cuda.device(input.device):
+        code = _lib.mixdq_quantize_f16_i8(input.data_ptr(), out.data_ptr(), _i64arr(sizes),
+                                          _i64arr(xs), _i64arr(os_), len(sizes),
+                                          scale_inv.data_ptr(), zero_point.data_ptr(), FLAGS,
+                                          _stream())
+    _status(code, "quantize_per_tensor_to_int8")
+    return out
+
+
+def quantize_per_tensor_to_int8(input, scale_inv, zero_point):
+    """Quantize to int 8 per tensor with scale and zero point."""
+    return _quantize(input, scale_inv, zero_point)
+
+
+def quantize_per_tensor_to_int8_vectorized(input, scale_inv, zero_point):
+    """Same kernel family as quantize_per_tensor_to_int8 (every path here is vectorised)."""
+    return _quantize(input, scale_inv, zero_point)
+
+
+def qlinear_w8_a8_ohalf(input_int8, weight_int8, weight_scale, input_scale, input_zero_point,
+                        weight_sum_by_input_channels, scale, bias0, bias=None, *,
+                        _out=None, _row_map=None):
+    _check(input_int8.is_cuda, "Input should be on GPU.")
+    dev = input_int8.device
+    _check(dev == weight_int8.device, "input and weight_int8 should be on the same device.")
+    _check(dev == weight_scale.device, "input and weight_scale should be on the same device.")
+    _check(dev == input_scale.device, "input and input_scale should be on the same device.")
+    _check(dev == input_zero_point.device,
+           "input and input_zero_point should be on the same device.")
+    _check(dev == weight_sum_by_input_channels.device,
+           "input and input_zero_point should be on the same device.")
+    if bias is not None:
+        _check(dev == bias.device, "input and bias should be on the same device.")
+    _check(input_int8.dtype == torch.int8, "input_int8 should be int8 type")
+    _check(weight_int8.dtype == torch.int8, "weight_int8 should be int8 type")
+    _check(weight_scale.dtype == torch.float32,
+           "Currently only support weight_scale with float32 type")
+    _check(input_scale.dtype == torch.float32,
+           "Currently only support input_scale with float32 type")
+    _check(input_zero_point.dtype == torch.float32,
+           "Currently only support input_zero_point with float32 type")
+    _check(weight_sum_by_input_channels.dtype == torch.float32,
+           "Currently only support weight_sum_by_input_channels with float32 type")
+    if bias is not None:
+        _check(bias.dtype == torch.float16, "Currently only support bias with float16 type")
+    _check(scale.dtype == torch.float32 and bias0.dtype == torch.float32,
+           "scale and bias0 should be float32")
+    N, K = weight_int8.size(0), weight_int8.size(1)
+    _check(weight_scale.numel() == N,
+           "The size of the weight_scale vector should be equal to output_channels.")
+    _check(weight_sum_by_input_channels.numel() == N,
+           "The size of weight_sum_by_input_channels should equal output_channels.")
+    _check(scale.numel() == N and bias0.numel() == N,
+           "The size of scale and bias0 should be equal to output_channels.")
+    if bias is not None:
+        _check(bias.numel() == N,
+               "The size of the bias vector should be equal to output_channels.")
+    _check(input_int8.size(-1) == K,
+           f"The last dimension of input and weight should match, got {input_int8.size(-1)} "
+           f"and {K}.")
+    a = input_int8.contiguous()
+    w = weight_int8.contiguous()
+    M = a.numel() // K if K else 0
+    D = _out if _out is not None else torch.empty(
+        list(input_int8.shape[:-1]) + [N], dtype=torch.float16, device=dev)
+    rm = _row_map or (0, 0, 0)
+    sc, b0 = _f32vec(scale), _f32vec(bias0)
+    bs = None if bias is None else bias.contiguous()
+    with torch.cuda.device(dev):
+        code = _lib.mixdq_qlinear_w8a8_rows(a.data_ptr(), w.data_ptr(), b0.data_ptr(),
+                                            sc.data_ptr(), _ptr(bs), D.data_ptr(), M, N, K,
+                                            rm[0], rm[1], rm[2], FLAGS, _stream())
+    _status(code, "qlinear_w8_a8_ohalf")
+    return D
+
+
+def _conv_geometry(input_int8, weight_int8, stride, padding, dilation):
+    N, C, H, W = input_int8.shape
+    K, _, R, S = weight_int8.shape
+    P = (H + 2 * padding - dilation * (R - 1) - 1) // stride + 1
+    Q = (W + 2 * padding - dilation * (S - 1) - 1) // stride + 1
+    return N, C, H, W, K, R, S, P, Q
+
+
+def qconv2d_w8_a8_ohalf(input_int8, weight_int8, weight_scale, input_scale, input_zero_point,
+                        scale, weight_sum_by_input_channels, bias0, bias=None, stride=1,
+                        padding=0, dilation=1, *, _table=None):
+    stride = 1 if stride is None else int(stride)
+    padding = 0 if padding is None else int(padding)
+    dilation = 1 if dilation is None else int(dilation)
+    _check(input_int8.is_cuda, "Input should be on GPU.")
+    dev = input_int8.device
+    _check(dev == weight_int8.device, "input and weight_int8 should be on the same device.")
+    _check(dev == weight_scale.device, "input and weight_scale should be on the same device.")
+    _check(dev == input_scale.device, "input and input_scale should be on the same device.")
+    _check(dev == input_zero_point.device,
+           "input and input_zero_point should be on the same device.")
+    wsum = weight_sum_by_input_channels
+    if wsum is not None:
+        _check(dev == wsum.device,
+               "input and weight_sum_by_input_channels should be on the same device.")
+    if bias0 is not None:
+        _check(dev == bias0.device, "input and bias0 should be on the same device.")
+    if bias is not None:
+        _check(dev == bias.device, "input and bias should be on the same device.")
+    _check(input_int8.dtype == torch.int8, "input_int8 should be int8 type")
+    _check(weight_int8.dtype == torch.int8, "weight_int8 should be int8 type")
+    _check(weight_scale.dtype == torch.float32,
+           "Currently only support weight_scale with float32 type")
+    _check(input_scale.dtype == torch.float32,
+           "Currently only support input_scale with float32 type")
+    _check(input_zero_point.dtype == torch.float32,
+           "Currently only support input_zero_point with float32 type")
+    if wsum is not None:
+        _check(wsum.dtype == torch.float32,
+               "Currently only support weight_sum_by_input_channels with float32 type")
+    if bias0 is not None:
+        _check(bias0.dtype == torch.float32, "Currently only support bias0 with float32 type")
+    if bias is not None:
+        _check(bias.dtype == torch.float16, "Currently only support bias with float16 type")
+    _check(scale.dtype == torch.float32, "scale should be float32")
+    _check(input_int8.dim() == 4 and weight_int8.dim() == 4, "input and weight should be 4-D")
+    N, C, H, W, K, R, S, P, Q = _conv_geometry(input_int8, weight_int8, stride, padding, dilation)
+    _check(weight_int8.size(1) == C, "input and weight channel counts should match")
+    _check(weight_scale.numel() == K,
+           "The size of the weight_scale vector should be equal to output_channels.")
+    if padding == 0:
+        _check(bias0 is not None and bias0.numel() == K,
+               "The size of bias0 should equal output_channels.")
+    else:
+        _check(wsum is not None and wsum.numel() == K * R * S,
+               "The size of weight_sum_by_input_channels should equal K*R*S.")
+    if bias is not None:
+        _check(bias.numel() == K,
+               "The size of the bias vector should be equal to output_channels.")
+    x = input_int8.contiguous(memory_format=torch.channels_last)
+    w = weight_int8.contiguous(memory_format=torch.channels_last)
+    D = torch.empty((N, K, P, Q), dtype=torch.float16, device=dev,
+                    memory_format=torch.channels_last)
+    sc = _f32vec(scale)
+    bs = None if bias is None else bias.contiguous()
+    with torch.cuda.device(dev):
+        if padding > 0 and _table is None:
+            ws_bytes = _lib.mixdq_qconv2d_workspace_bytes(K, R, S, padding)
+            workspace = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)
+            code = _lib.mixdq_qconv2d_w8a8(
+                x.data_ptr(), w.data_ptr(), sc.data_ptr(), wsum.contiguous().data_ptr(),
+                input_zero_point.data_ptr(), None, _ptr(bs), D.data_ptr(), workspace.data_ptr(),
+                N, H, W, C, K, R, S, stride, padding, dilation, FLAGS, _stream())
+        else:
+            _check(dilation == 1, "qconv2d_w8_a8_ohalf: unsupported configuration "
+                                  "(dilation must be 1)")
+            b0 = None if padding > 0 else _f32vec(bias0)
+            code = _lib.mixdq_qconv2d_w8a8_table(
+                x.data_ptr(), w.data_ptr(), sc.data_ptr(), _ptr(_table),
+                input_zero_point.data_ptr(), _ptr(b0), _ptr(bs), D.data_ptr(),
+                N, H, W, C, K, R, S, stride, padding, FLAGS, _stream())
+    _status(code, "qconv2d_w8_a8_ohalf")
+    return D
+
+
+def conv_border_table(weight_sum_by_input_channels):
+    """Tap-rectangle sums of wsum [K,1,R,S] -> [(R*R*S*S), K] f32 (include/mixdq_hip.h,
+    mixdq_conv_border_table).  Depends only on the weights: QuantizedConv2d caches it."""
+    wsum = weight_sum_by_input_channels.contiguous()
+    _check(wsum.is_cuda and wsum.dtype == torch.float32 and wsum.dim() == 4,
+           "weight_sum_by_input_channels should be a float32 [K,1,R,S] GPU tensor")
+    K, _, R, S = wsum.shape
+    table = torch.empty((R * R * S * S, K), dtype=torch.float32, device=wsum.device)
+    with torch.cuda.device(wsum.device):
+        code = _lib.mixdq_conv_border_table(wsum.data_ptr(), table.data_ptr(), K, R, S, _stream())
+    _status(code, "conv_border_table")
+    return table
+
+
+def conv_zero_point_propagate(weight_sum_by_input_channels, input_zero_point, N, H, W, stride,
+                              padding):
+    """The reference's materialised bias0 [N,K,P,Q] f32 channels-last
+    (conv_act_zero_point_propagate.cu:54-83); diagnostic, not on the fast path."""
+    wsum = weight_sum_by_input_channels.contiguous()
+    K, _, R, S = wsum.shape
+    P = (H + 2 * padding - (R - 1) - 1) // stride + 1
+    Q = (W + 2 * padding - (S - 1) - 1) // stride + 1
+    out = torch.empty((N, K, P, Q), dtype=torch.float32, device=wsum.device,
+                      memory_format=torch.channels_last)
+    with torch.cuda.device(wsum.device):
+        code = _lib.mixdq_conv_zero_point_propagate(
+            wsum.data_ptr(), input_zero_point.data_ptr(), out.data_ptr(), N, H, W, K, R, S,
+            stride, padding, _stream())
+    _status(code, "conv_zero_point_propagate")
+    return out
+
+
+def qlinear_fp_reference(input, weight, bias=None):
+    """FP16 debug GEMM: input [..., K] @ weight [K, N] (row-major, qlinear.cc:161).  `bias` is
+    accepted and ignored, as in the reference (op/qlinear.py:92)."""
+    _check(input.dtype == torch.float16, "input should be int8 type")      # sic, qlinear.cc:146
+    _check(weight.dtype == torch.float16, "weight should be int8 type")    # sic, qlinear.cc:148
+    _check(input.is_cuda and weight.is_cuda, "Input should be on GPU.")
+    if bias is not None:
+        _check(input.device == bias.device, "input and bias should be on the same device.")
+        _check(bias.dtype == torch.float16, "Currently only support bias with float16 type")
+    K, N = weight.size(0), weight.size(1)
+    a = input.contiguous()
+    b = weight.contiguous()
+    M = a.numel() // K if K else 0
+    D = torch.empty(list(input.shape[:-1]) + [N], dtype=torch.float16, device=input.device)
+    with torch.cuda.device(input.device):
+        code = _lib.mixdq_gemm_f16(a.data_ptr(), b.data_ptr(), D.data_ptr(), M, N, K, _stream())
+    _status(code, "qlinear_fp_reference")
+    return D

@@ -1,0 +1,47 @@
+"""Build libmixdq_hip.so (the C-ABI library, include/mixdq_hip.h) in-tree with hipcc for gfx950.
+
+    python -m mixdq_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  The .so is git-ignored but travels with the gpurun snapshot.
+"""
+import os
+import subprocess
+import sys
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, "csrc")
+LIB = os.path.join(PKG, "libmixdq_hip.so")
+SOURCES = ["quantize.hip", "igemm.hip"]
+HEADERS = ["common.h", os.path.join("..", "..", "include", "mixdq_hip.h")]
+# -ffp-contract=off: every fused multiply-add in the arithmetic specification is written
+# explicitly (__builtin_fmaf); the compiler must not introduce others.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+         "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.sep not in c or os.path.exists(c)):
+            return c
+    return "hipcc"
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if force or needs_build():
+        cmd = [_hipcc()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,584 @@
+// a2 + a3 (+ a4): INT8 x INT8 -> INT32 GEMM and NHWC implicit-GEMM conv2d for gfx950, with the
+// reference's FP32 epilogue  D = f16((f32(acc) - bias0) * scale [+ bias]).
+// Replaces qlinear.cc:13-137 + cutlassGemm_*Alignment.cu and qconv2d.cc:27-206 +
+// cutlassConv2d_*.cu + conv_act_zero_point_propagate.cu of the reference.
+//
+// Design (MI355X-first, not a CUTLASS translation):
+//   * one kernel family for Linear and Conv2d: both operands are "rows of K-contiguous bytes";
+//     the conv's activation row is a gather over (r, s, c) done by the per-lane SOURCE address
+//     of the LDS-DMA (global_load_lds_dwordx4); out-of-image taps, the M/N tails and the K tail
+//     read a 16-byte zero page instead, so the main loop has no predication.
+//   * v_mfma_i32_32x32x32_i8 with the WEIGHT tile as the A operand and the ACTIVATION tile as
+//     the B operand: the accumulator then has the output row (m) on the lane and 4 consecutive
+//     output channels per register quad, so the per-channel epilogue vectors are float4 loads and
+//     the f16 results go to LDS as 8-byte stores and out to HBM as whole 16-byte row segments.
+//   * LDS tiles are [rows][BK bytes] with the 16-byte chunk index XOR-swizzled by the row
+//     (ds_read_b128 conflict-free); because LDS-DMA writes lane-linear, the swizzle is applied to
+//     the source address and to the fragment read (both-sides rule).
+//   * 2 LDS stages; the next K-tile's DMA is in flight while the current one is multiplied.
+//   * padded convs: per-pixel bias0 = zp * (sum of in-bounds taps of wsum) is looked up from a
+//     (R*R*S*S) x K table of tap-rectangle sums indexed by the pixel's border class, instead of
+//     materialising an [N,P,Q,K] f32 tensor per call as the reference does.
+//   * blockIdx -> tile map is XCD-aware (blocks that share a weight panel share an L2).
+#include "common.h"
+
+namespace mixdq {
+namespace {
+
+__device__ uint4 g_zero16;   // the zero page (device globals are zero-initialised)
+
+struct IgemmParams {
+  const int8_t* A;       // activations: [M,Ktot] (linear) or [N,H,W,C] (conv)
+  const int8_t* Wt;      // weights [N, Ktot]  (conv: [K,R,S,C])
+  const float* bias0;    // [N] (null in table mode)
+  const float* scale;    // [N]
+  const __half* bias;    // [N] or null
+  const float* table;    // [ncls][N] tap-rectangle sums, or null
+  const float* zp;       // device scalar (table mode)
+  __half* D;             // [M,N]
+  int64_t M;
+  int N, Ktot;
+  int H, W, C, R, S, P, Q, stride, pad;   // conv geometry
+  int grp_rows, grp_stride, grp_off;      // output row map (grp_rows <= 0: identity)
+  int tiles_m, tiles_n;
+  int unfused;
+};
+
+template <int BK>
+__device__ __forceinline__ int swz(int row) {
+  // 256-B LDS bank row holds 4 (BK=64) or 2 (BK=128) tile rows; XOR so that the 16 lanes of a
+  // ds_read_b128 group (rows r..r+3, r+12.., r+20..) land in 16 distinct 16-byte slots.
+  return BK == 64 ? ((row >> 2) & 3) : ((row >> 1) & 7);
+}
+
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(
+      (const __attribute__((address_space(1))) void*)gsrc,
+      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int BM, int BN, int BK, bool CONV>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
+  constexpr int WTM = BM / 2, WTN = BN / 2;       // wave tile (2 x 2 waves)
+  constexpr int TM = WTM / 32, TN = WTN / 32;     // 32x32 MFMA tiles per wave
+  constexpr int A_STAGE = BM * BK, B_STAGE = BN * BK, STAGE = A_STAGE + B_STAGE;
+  constexpr int A_NI = A_STAGE / 1024 / 4;        // LDS-DMA instructions per wave per stage
+  constexpr int B_NI = B_STAGE / 1024 / 4;
+  constexpr int CS_STRIDE = BN * 2 + 16;          // epilogue tile row stride (bytes)
+  constexpr int SMEM = (2 * STAGE > BM * CS_STRIDE) ? 2 * STAGE : BM * CS_STRIDE;
+  static_assert(A_NI >= 1 && B_NI >= 1, "tile too small for 4 waves of 1-KiB DMA pieces");
+  static_assert(TM >= 1 && TN >= 1, "wave tile must hold a 32x32 MFMA tile");
+  __shared__ __attribute__((aligned(16))) char smem[SMEM];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wid >> 1, wn = wid & 1;
+
+  // ---- XCD-aware tile map: the blocks of one XCD (bid % 8) get a contiguous run of tiles,
+  //      m fastest, so neighbours share the weight panel in that XCD's L2 (bijective form).
+  const int nwg = gridDim.x;
+  const int bid = blockIdx.x;
+  const int xcd = bid % kNumXCD, q8 = nwg / kNumXCD, r8 = nwg % kNumXCD;
+  const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / kNumXCD;
+  const int tile_n = wg / p.tiles_m, tile_m = wg - tile_n * p.tiles_m;
+  const int64_t m0 = (int64_t)tile_m * BM;
+  const int n0 = tile_n * BN;
+
+  const char* zero = reinterpret_cast<const char*>(&g_zero16);
+  const int Ktot = p.Ktot;
+
+  // ---- per-lane staging state -------------------------------------------------------------
+  const int8_t* a_base[A_NI];   // linear: row pointer + chunk offset; conv: image base
+  int a_k[A_NI];                // linear: chunk's k offset within the K-tile
+  int a_h0[A_NI], a_w0[A_NI];   // conv: top-left input coordinate of the row's window
+  int a_r[A_NI], a_s[A_NI], a_c[A_NI];   // conv: current tap and channel of this lane's chunk
+  bool a_ok[A_NI];
+#pragma unroll
+  for (int j = 0; j < A_NI; ++j) {
+    const int byte = (wid * A_NI + j) * 1024 + lane * 16;
+    const int row = byte / BK;
+    const int lc = ((byte % BK) >> 4) ^ swz<BK>(row);
+    const int64_t m = m0 + row;
+    a_ok[j] = m < p.M;
+    if constexpr (!CONV) {
+      a_base[j] = p.A + m * Ktot + lc * 16;
+      a_k[j] = lc * 16;
+      a_h0[j] = a_w0[j] = a_r[j] = a_s[j] = a_c[j] = 0;
+    } else {
+      const int pq = p.P * p.Q;
+      const int64_t img = m / pq;
+      const int rem = (int)(m - img * pq);
+      const int pp = rem / p.Q, qq = rem - pp * p.Q;
+      a_base[j] = p.A + img * ((int64_t)p.H * p.W * p.C);
+      a_h0[j] = a_ok[j] ? pp * p.stride - p.pad : -(1 << 28);
+      a_w0[j] = qq * p.stride - p.pad;
+      const int kc = lc * 16;
+      const int tap = kc / p.C;
+      a_c[j] = kc - tap * p.C;
+      a_r[j] = tap / p.S;
+      a_s[j] = tap - a_r[j] * p.S;
+      a_k[j] = 0;
+    }
+  }
+  const int8_t* b_base[B_NI];
+  int b_k[B_NI];
+  bool b_ok[B_NI];
+#pragma unroll
+  for (int j = 0; j < B_NI; ++j) {
+    const int byte = (wid * B_NI + j) * 1024 + lane * 16;
+    const int row = byte / BK;
+    const int lc = ((byte % BK) >> 4) ^ swz<BK>(row);
+    const int n = n0 + row;
+    b_ok[j] = n < p.N;
+    b_base[j] = p.Wt + (int64_t)n * Ktot + lc * 16;
+    b_k[j] = lc * 16;
+  }
+
+  auto stage = [&](int buf, int kk) {
+    char* As = smem + buf * STAGE;
+    char* Bs = As + A_STAGE;
+#pragma unroll
+    for (int j = 0; j < A_NI; ++j) {
+      const void* src;
+      if constexpr (!CONV) {
+        const bool ok = a_ok[j] && (kk + a_k[j] < Ktot);
+        src = ok ? (const void*)(a_base[j] + kk) : (const void*)zero;
+      } else {
+        const int hh = a_h0[j] + a_r[j], ww = a_w0[j] + a_s[j];
+        const bool ok = (unsigned)hh < (unsigned)p.H && (unsigned)ww < (unsigned)p.W &&
+                        a_r[j] < p.R;
+        src = ok ? (const void*)(a_base[j] + ((int64_t)(hh * p.W + ww) * p.C + a_c[j]))
+                 : (const void*)zero;
+        a_c[j] += BK;
+        while (a_c[j] >= p.C) {
+          a_c[j] -= p.C;
+          if (++a_s[j] == p.S) { a_s[j] = 0; ++a_r[j]; }
+        }
+      }
+      glds16(src, As + (wid * A_NI + j) * 1024);
+    }
+#pragma unroll
+    for (int j = 0; j < B_NI; ++j) {
+      const bool ok = b_ok[j] && (kk + b_k[j] < Ktot);
+      const void* src = ok ? (const void*)(b_base[j] + kk) : (const void*)zero;
+      glds16(src, Bs + (wid * B_NI + j) * 1024);
+    }
+  };
+
+  // ---- fragment read addressing (loop invariant) ---------------------------------------------
+  const int lrow = lane & 31, lhalf = lane >> 5;
+  int a_rd[TM], a_sw[TM], b_rd[TN], b_sw[TN];
+#pragma unroll
+  for (int t = 0; t < TM; ++t) {
+    const int row = wm * WTM + t * 32 + lrow;
+    a_rd[t] = row * BK;
+    a_sw[t] = swz<BK>(row);
+  }
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    const int row = wn * WTN + t * 32 + lrow;
+    b_rd[t] = A_STAGE + row * BK;
+    b_sw[t] = swz<BK>(row);
+  }
+
+  v16i acc[TN][TM];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0;
+
+  // ---- main loop: 2 LDS stages, DMA of tile kt+1 in flight under the MFMAs of tile kt ----------
+  const int nk = (Ktot + BK - 1) / BK;
+  stage(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * BK);
+    const char* S0 = smem + (kt & 1) * STAGE;
+#pragma unroll
+    for (int ks = 0; ks < BK / 32; ++ks) {
+      v4i af[TM], bf[TN];
+#pragma unroll
+      for (int t = 0; t < TM; ++t)
+        af[t] = *reinterpret_cast<const v4i*>(S0 + a_rd[t] + (((ks * 2 + lhalf) ^ a_sw[t]) << 4));
+#pragma unroll
+      for (int t = 0; t < TN; ++t)
+        bf[t] = *reinterpret_cast<const v4i*>(S0 + b_rd[t] + (((ks * 2 + lhalf) ^ b_sw[t]) << 4));
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[a], af[b], acc[a][b], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: registers -> f16 tile in LDS -> whole-row 16-byte stores --------------------
+  __syncthreads();   // every wave is done reading the stage buffers
+  char* Cs = smem;
+  const bool has_bias = p.bias != nullptr;
+  const bool use_table = p.table != nullptr;
+  const bool unfused = p.unfused != 0;
+  const float zpv = use_table ? *p.zp : 0.f;
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int ml = wm * WTM + tm * 32 + lrow;
+    const float* b0row = p.bias0;
+    if (use_table) {
+      // border class of this output pixel: valid tap rectangle [rlo,rhi] x [slo,shi]
+      int64_t m = m0 + ml;
+      if (m >= p.M) m = 0;
+      const int pq = p.P * p.Q;
+      const int rem = (int)(m % pq);
+      const int pp = rem / p.Q, qq = rem - pp * p.Q;
+      const int hb = pp * p.stride - p.pad, wb = qq * p.stride - p.pad;
+      const int rlo = max(0, -hb), rhi = min(p.R - 1, p.H - 1 - hb);
+      const int slo = max(0, -wb), shi = min(p.S - 1, p.W - 1 - wb);
+      int cls = 0;   // empty rectangle -> class 0 holds... (rlo>rhi cannot index: clamp)
+      const int rh = max(rhi, 0), sh = max(shi, 0);
+      cls = ((min(rlo, p.R - 1) * p.R + rh) * p.S + min(slo, p.S - 1)) * p.S + sh;
+      b0row = p.table + (int64_t)cls * p.N;
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int nl = wn * WTN + tn * 32 + 8 * g + 4 * lhalf;
+        const int n = n0 + nl;
+        if (n < p.N) {   // N % 4 == 0: the quad is all-valid or all-invalid
+          const v4f b0 = *reinterpret_cast<const v4f*>(b0row + n);
+          const v4f sc = *reinterpret_cast<const v4f*>(p.scale + n);
+          uint2 hb2 = make_uint2(0u, 0u);
+          if (has_bias) hb2 = *reinterpret_cast<const uint2*>(p.bias + n);
+          uint32_t packed[2];
+#pragma unroll
+          for (int e2 = 0; e2 < 2; ++e2) {
+            uint32_t w = 0;
+#pragma unroll
+            for (int e1 = 0; e1 < 2; ++e1) {
+              const int e = e2 * 2 + e1;
+              const uint32_t hw = e2 ? hb2.y : hb2.x;
+              __half_raw br;
+              br.x = (unsigned short)(e1 ? (hw >> 16) : (hw & 0xffffu));
+              float b0v = b0[e];
+              if (use_table) b0v = __fmul_rn(b0v, zpv);
+              __half h = epilogue_one(acc[tn][tm][4 * g + e], b0v, sc[e],
+                                      __half2float(__half(br)), has_bias, unfused);
+              w |= (uint32_t)__half_as_ushort(h) << (16 * e1);
+            }
+            packed[e2] = w;
+          }
+          *reinterpret_cast<uint2*>(Cs + ml * CS_STRIDE + nl * 2) = make_uint2(packed[0], packed[1]);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  constexpr int CPRO = BN / 8;   // 16-byte chunks per output row of the tile
+  const bool n8 = (p.N & 7) == 0;
+  for (int t = tid; t < BM * CPRO; t += 256) {
+    const int row = t / CPRO, cc = t - row * CPRO;
+    const int64_t m = m0 + row;
+    const int n = n0 + cc * 8;
+    if (m < p.M && n < p.N) {
+      int64_t drow = m;
+      if (p.grp_rows > 0) {
+        const int64_t gq = m / p.grp_rows;
+        drow = gq * p.grp_stride + p.grp_off + (m - gq * p.grp_rows);
+      }
+      const uint4 v = *reinterpret_cast<const uint4*>(Cs + row * CS_STRIDE + cc * 16);
+      __half* dst = p.D + drow * p.N + n;
+      if (n8) {
+        *reinterpret_cast<uint4*>(dst) = v;
+      } else {   // N % 8 == 4: rows are only 8-byte aligned
+        *reinterpret_cast<uint2*>(dst) = make_uint2(v.x, v.y);
+        if (n + 8 <= p.N) *reinterpret_cast<uint2*>(dst + 4) = make_uint2(v.z, v.w);
+      }
+    }
+  }
+}
+
+// ---- small-alignment / generic fallback (K % 16 != 0 or C % 16 != 0): one output per thread.
+// Replaces the reference's *_smallAlignment CUTLASS instantiations (conv_in C=4, tests K=8).
+template <bool CONV>
+__global__ __launch_bounds__(256) void igemm_generic_kernel(const IgemmParams p) {
+  const int64_t total = p.M * p.N;
+  const float zpv = p.table ? *p.zp : 0.f;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = t / p.N;
+    const int n = (int)(t - m * p.N);
+    int acc = 0;
+    float b0;
+    if constexpr (!CONV) {
+      const int8_t* a = p.A + m * p.Ktot;
+      const int8_t* w = p.Wt + (int64_t)n * p.Ktot;
+      for (int k = 0; k < p.Ktot; ++k) acc += (int)a[k] * (int)w[k];
+      b0 = p.bias0[n];
+    } else {
+      const int pq = p.P * p.Q;
+      const int64_t img = m / pq;
+      const int rem = (int)(m - img * pq);
+      const int pp = rem / p.Q, qq = rem - pp * p.Q;
+      const int hb = pp * p.stride - p.pad, wb = qq * p.stride - p.pad;
+      for (int r = 0; r < p.R; ++r)
+        for (int s = 0; s < p.S; ++s) {
+          const int hh = hb + r, ww = wb + s;
+          if ((unsigned)hh >= (unsigned)p.H || (unsigned)ww >= (unsigned)p.W) continue;
+          const int8_t* a = p.A + ((img * p.H + hh) * p.W + ww) * (int64_t)p.C;
+          const int8_t* w = p.Wt + ((int64_t)n * p.R * p.S + r * p.S + s) * p.C;
+          for (int c = 0; c < p.C; ++c) acc += (int)a[c] * (int)w[c];
+        }
+      if (p.table) {
+        const int rlo = max(0, -hb), rhi = max(min(p.R - 1, p.H - 1 - hb), 0);
+        const int slo = max(0, -wb), shi = max(min(p.S - 1, p.W - 1 - wb), 0);
+        const int cls = ((min(rlo, p.R - 1) * p.R + rhi) * p.S + min(slo, p.S - 1)) * p.S + shi;
+        b0 = __fmul_rn(p.table[(int64_t)cls * p.N + n], zpv);
+      } else {
+        b0 = p.bias0[n];
+      }
+    }
+    int64_t drow = m;
+    if (p.grp_rows > 0) {
+      const int64_t gq = m / p.grp_rows;
+      drow = gq * p.grp_stride + p.grp_off + (m - gq * p.grp_rows);
+    }
+    const bool hb_ = p.bias != nullptr;
+    p.D[drow * p.N + n] = epilogue_one(acc, b0, p.scale[n], hb_ ? __half2float(p.bias[n]) : 0.f,
+                                       hb_, p.unfused != 0);
+  }
+}
+
+// table[cls][k] = sum of wsum[k][r][s] over r in [rlo,rhi], s in [slo,shi] (float adds in (r,s)
+// order, exact: integers < 2^24), cls = ((rlo*R + rhi)*S + slo)*S + shi.
+__global__ __launch_bounds__(256) void border_table_kernel(const float* __restrict__ wsum,
+                                                           float* __restrict__ table, int K,
+                                                           int R, int S) {
+  const int ncls = R * R * S * S;
+  const int64_t total = (int64_t)ncls * K;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(t % K);
+    int cls = (int)(t / K);
+    const int shi = cls % S; cls /= S;
+    const int slo = cls % S; cls /= S;
+    const int rhi = cls % R;
+    const int rlo = cls / R;
+    float acc = 0.f;
+    for (int r = rlo; r <= rhi; ++r)
+      for (int s = slo; s <= shi; ++s) acc += wsum[((int64_t)k * R + r) * S + s];
+    table[t] = acc;
+  }
+}
+
+// a4 stand-alone: the reference's materialised zero-point propagation
+// (conv_act_zero_point_propagate.cu:23-51), k fastest for coalesced stores.
+__global__ __launch_bounds__(256) void zp_propagate_kernel(const float* __restrict__ wsum,
+                                                           const float* __restrict__ zp_p,
+                                                           float* __restrict__ out, int N, int H,
+                                                           int W, int K, int R, int S, int P,
+                                                           int Q, int stride, int pad) {
+  const float zp = *zp_p;
+  const int64_t total = (int64_t)N * P * Q * K;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int k = (int)(t % K);
+    int64_t r_ = t / K;
+    const int qq = (int)(r_ % Q); r_ /= Q;
+    const int pp = (int)(r_ % P);
+    const int hb = pp * stride - pad, wb = qq * stride - pad;
+    float acc = 0.f;
+    for (int r = 0; r < R; ++r)
+      for (int s = 0; s < S; ++s) {
+        const int hh = hb + r, ww = wb + s;
+        if (hh >= 0 && hh < H && ww >= 0 && ww < W) acc += wsum[((int64_t)k * R + r) * S + s];
+      }
+    out[t] = __fmul_rn(acc, zp);
+  }
+}
+
+// FP16 debug GEMM (qlinear_fp_reference): one output per thread, k-ordered FP32 fmaf chain.
+__global__ __launch_bounds__(256) void gemm_f16_kernel(const __half* __restrict__ A,
+                                                       const __half* __restrict__ B,
+                                                       __half* __restrict__ D, int64_t M, int N,
+                                                       int K) {
+  const int64_t total = M * N;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = t / N;
+    const int n = (int)(t - m * N);
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k)
+      acc = __builtin_fmaf(__half2float(A[m * K + k]), __half2float(B[(int64_t)k * N + n]), acc);
+    D[t] = __float2half_rn(acc);
+  }
+}
+
+template <int BM, int BN, int BK, bool CONV>
+int launch_tile(IgemmParams& p, hipStream_t stream) {
+  p.tiles_m = (int)((p.M + BM - 1) / BM);
+  p.tiles_n = (p.N + BN - 1) / BN;
+  const int64_t grid = (int64_t)p.tiles_m * p.tiles_n;
+  if (grid <= 0 || grid > 0x7fffffff) return MIXDQ_ERR_INVALID_ARG;
+  igemm_kernel<BM, BN, BK, CONV><<<(int)grid, 256, 0, stream>>>(p);
+  return launch_status();
+}
+
+template <bool CONV>
+int dispatch(IgemmParams& p, hipStream_t stream) {
+  if (p.M <= 0 || p.N <= 0) return MIXDQ_OK;
+  const int align_k = CONV ? p.C : p.Ktot;
+  if (align_k % 4 != 0 || p.N % 4 != 0) return MIXDQ_ERR_ALIGNMENT;
+  const bool ptr_ok = ((uintptr_t)p.A % 16 == 0) && ((uintptr_t)p.Wt % 16 == 0) &&
+                      ((uintptr_t)p.D % 16 == 0) && ((uintptr_t)p.scale % 16 == 0) &&
+                      ((uintptr_t)p.bias0 % 16 == 0) && ((uintptr_t)p.table % 16 == 0) &&
+                      ((uintptr_t)p.bias % 8 == 0);
+  if (align_k % 16 != 0 || !ptr_ok) {
+    int64_t blocks = (p.M * p.N + 255) / 256;
+    if (blocks > kNumCU * 16) blocks = kNumCU * 16;
+    igemm_generic_kernel<CONV><<<(int)blocks, 256, 0, stream>>>(p);
+    return launch_status();
+  }
+  // Tile choice: the largest tile that still gives the 256 CUs at least ~1 block each.
+  auto blocks = [&](int bm, int bn) {
+    return ((p.M + bm - 1) / bm) * (int64_t)((p.N + bn - 1) / bn);
+  };
+  if (blocks(128, 128) >= kNumCU) return launch_tile<128, 128, 64, CONV>(p, stream);
+  if (blocks(64, 128) >= kNumCU) return launch_tile<64, 128, 64, CONV>(p, stream);
+  return launch_tile<64, 64, 64, CONV>(p, stream);
+}
+
+}  // namespace
+}  // namespace mixdq
+
+using namespace mixdq;
+
+extern "C" int mixdq_qlinear_w8a8_rows(const int8_t* A, const int8_t* W, const float* bias0,
+                                       const float* scale, const void* bias_f16_or_null,
+                                       void* D_f16, int64_t M, int N, int K, int group_rows,
+                                       int group_stride, int group_offset, int flags,
+                                       mixdq_stream_t stream) {
+  if (M < 0 || N < 0 || K < 0) return MIXDQ_ERR_INVALID_ARG;
+  if (M == 0 || N == 0) return MIXDQ_OK;
+  if (!A || !W || !bias0 || !scale || !D_f16) return MIXDQ_ERR_INVALID_ARG;
+  IgemmParams p{};
+  p.A = A; p.Wt = W; p.bias0 = bias0; p.scale = scale; p.bias = (const __half*)bias_f16_or_null;
+  p.table = nullptr; p.zp = nullptr; p.D = (__half*)D_f16;
+  p.M = M; p.N = N; p.Ktot = K;
+  p.H = p.W = p.P = p.Q = 1; p.C = K; p.R = p.S = 1; p.stride = 1; p.pad = 0;
+  p.grp_rows = group_rows; p.grp_stride = group_stride; p.grp_off = group_offset;
+  p.unfused = (flags & MIXDQ_FLAG_UNFUSED) ? 1 : 0;
+  return dispatch<false>(p, (hipStream_t)stream);
+}
+
+extern "C" int mixdq_qlinear_w8a8(const int8_t* A, const int8_t* W, const float* bias0,
+                                  const float* scale, const void* bias_f16_or_null, void* D_f16,
+                                  int64_t M, int N, int K, int flags, mixdq_stream_t stream) {
+  return mixdq_qlinear_w8a8_rows(A, W, bias0, scale, bias_f16_or_null, D_f16, M, N, K, 0, 0, 0,
+                                 flags, stream);
+}
+
+extern "C" size_t mixdq_qconv2d_workspace_bytes(int K, int R, int S, int pad) {
+  if (pad <= 0 || K <= 0 || R <= 0 || S <= 0) return 0;
+  return (size_t)R * R * S * S * K * sizeof(float);
+}
+
+extern "C" int mixdq_conv_border_table(const float* wsum_krs, float* table, int K, int R, int S,
+                                       mixdq_stream_t stream) {
+  if (!wsum_krs || !table || K <= 0 || R <= 0 || S <= 0) return MIXDQ_ERR_INVALID_ARG;
+  const int64_t total = (int64_t)R * R * S * S * K;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > kNumCU * 8) blocks = kNumCU * 8;
+  border_table_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(wsum_krs, table, K, R, S);
+  return launch_status();
+}
+
+extern "C" int mixdq_qconv2d_w8a8_table(const int8_t* X, const int8_t* Wt, const float* scale,
+                                        const float* table_or_null, const float* zero_point,
+                                        const float* bias0_or_null, const void* bias_f16_or_null,
+                                        void* D, int N, int H, int W, int C, int K, int R, int S,
+                                        int stride, int pad, int flags, mixdq_stream_t stream) {
+  if (N < 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || R <= 0 || S <= 0 || stride <= 0 || pad < 0)
+    return MIXDQ_ERR_INVALID_ARG;
+  if (!X || !Wt || !scale || !D) return MIXDQ_ERR_INVALID_ARG;
+  if (pad > 0 ? (!table_or_null || !zero_point) : !bias0_or_null) return MIXDQ_ERR_INVALID_ARG;
+  // every output pixel's window must overlap the image (border classes are non-empty rectangles)
+  if (pad >= R || pad >= S) return MIXDQ_ERR_UNSUPPORTED;
+  const int P = (H + 2 * pad - (R - 1) - 1) / stride + 1;
+  const int Q = (W + 2 * pad - (S - 1) - 1) / stride + 1;
+  if (P <= 0 || Q <= 0 || N == 0) return MIXDQ_OK;
+  IgemmParams p{};
+  p.A = X; p.Wt = Wt; p.scale = scale; p.bias = (const __half*)bias_f16_or_null;
+  p.bias0 = pad > 0 ? nullptr : bias0_or_null;
+  p.table = pad > 0 ? table_or_null : nullptr;
+  p.zp = zero_point; p.D = (__half*)D;
+  p.M = (int64_t)N * P * Q; p.N = K; p.Ktot = R * S * C;
+  p.H = H; p.W = W; p.C = C; p.R = R; p.S = S; p.P = P; p.Q = Q; p.stride = stride; p.pad = pad;
+  p.grp_rows = 0; p.grp_stride = 0; p.grp_off = 0;
+  p.unfused = (flags & MIXDQ_FLAG_UNFUSED) ? 1 : 0;
+  return dispatch<true>(p, (hipStream_t)stream);
+}
+
+extern "C" int mixdq_qconv2d_w8a8(const int8_t* X, const int8_t* Wt, const float* scale,
+                                  const float* wsum_krs_or_null, const float* zero_point,
+                                  const float* bias0_or_null, const void* bias_f16_or_null,
+                                  void* D, void* workspace, int N, int H, int W, int C, int K,
+                                  int R, int S, int stride, int pad, int dilation, int flags,
+                                  mixdq_stream_t stream) {
+  if (dilation != 1) return MIXDQ_ERR_UNSUPPORTED;
+  const float* table = nullptr;
+  if (pad > 0) {
+    if (!wsum_krs_or_null || !workspace) return MIXDQ_ERR_INVALID_ARG;
+    int st = mixdq_conv_border_table(wsum_krs_or_null, (float*)workspace, K, R, S, stream);
+    if (st != MIXDQ_OK) return st;
+    table = (const float*)workspace;
+  }
+  return mixdq_qconv2d_w8a8_table(X, Wt, scale, table, zero_point, bias0_or_null,
+                                  bias_f16_or_null, D, N, H, W, C, K, R, S, stride, pad, flags,
+                                  stream);
+}
+
+extern "C" int mixdq_conv_zero_point_propagate(const float* wsum_krs, const float* zero_point,
+                                               float* out, int N, int H, int W, int K, int R,
+                                               int S, int stride, int pad,
+                                               mixdq_stream_t stream) {
+  if (!wsum_krs || !zero_point || !out) return MIXDQ_ERR_INVALID_ARG;
+  const int P = (H + 2 * pad - (R - 1) - 1) / stride + 1;
+  const int Q = (W + 2 * pad - (S - 1) - 1) / stride + 1;
+  const int64_t total = (int64_t)N * P * Q * K;
+  if (total <= 0) return MIXDQ_OK;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > kNumCU * 8) blocks = kNumCU * 8;
+  zp_propagate_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>(wsum_krs, zero_point, out, N,
+                                                                     H, W, K, R, S, P, Q, stride,
+                                                                     pad);
+  return launch_status();
+}
+
+extern "C" int mixdq_gemm_f16(const void* A, const void* B, void* D, int64_t M, int N, int K,
+                              mixdq_stream_t stream) {
+  if (M < 0 || N < 0 || K < 0) return MIXDQ_ERR_INVALID_ARG;
+  if (M == 0 || N == 0) return MIXDQ_OK;
+  if (!A || !B || !D) return MIXDQ_ERR_INVALID_ARG;
+  int64_t blocks = (M * N + 255) / 256;
+  if (blocks > kNumCU * 16) blocks = kNumCU * 16;
+  gemm_f16_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>((const __half*)A, (const __half*)B,
+                                                                (__half*)D, M, N, K);
+  return launch_status();
+}
+
+extern "C" const char* mixdq_status_string(int status) {
+  switch (status) {
+    case MIXDQ_OK: return "ok";
+    case MIXDQ_ERR_INVALID_ARG: return "invalid argument (null pointer or bad size)";
+    case MIXDQ_ERR_ALIGNMENT:
+      return "Int8 kernel with input or output alignment not to 4 is not supported.";
+    case MIXDQ_ERR_UNSUPPORTED: return "unsupported configuration (dilation must be 1)";
+    case MIXDQ_ERR_LAUNCH: return "HIP kernel launch failed";
+    default: return "unknown status";
+  }
+}
+
+extern "C" int mixdq_abi_version(void) { return MIXDQ_ABI_VERSION; }
