@@ -1,0 +1,183 @@
+"""QuantizedConv2d for MI355X: counterpart of mixdq_extension/nn/Conv2d.py:16-347.
+
+Same constructor, `from_float(float_mod, split=0, ckpt=None)`, buffer names (incl. the `_0`
+buffers of a split up-block conv_shortcut) and forward semantics.
+
+Differences, all result-preserving:
+  * for padded convs the zero-point border table (include/mixdq_hip.h mixdq_conv_border_table)
+    depends only on the weights, so it is built once and cached next to
+    weight_sum_by_input_channels instead of recomputing an [N,P,Q,K] f32 tensor per call
+    (qconv2d.cc:131-136);
+  * the channel slices x[:, :split], x[:, split:] are quantized with their real strides (the
+    reference reads them linearly: right only at batch 1 / NCHW -- SURVEY.md section 0).
+"""
+from __future__ import annotations
+
+import logging
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.ao.quantization import QConfig
+
+from mixdq_amd import _C
+from mixdq_amd.nn.utils import create_qparams_from_dtype
+from mixdq_amd.op.quant import quantize_per_tensor_vectorized
+
+__all__ = ["QuantizedConv2d"]
+
+quant_op = quantize_per_tensor_vectorized
+
+_INT8 = (torch.qint8, torch.quint8)
+
+
+def _w8a8_ok(w, a) -> bool:
+    return bool(
+        w is not None and a is not None and w.dtype in _INT8 and a.dtype in _INT8
+        and w.qscheme == torch.per_channel_affine and a.qscheme == torch.per_tensor_affine
+        and torch.all(w.zero_points == 0.0).item())
+
+
+class QuantizedConv2d(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int, kernel_size, stride, padding,
+                 dilation, groups=1, bias=True, device=None, w_qparams=None, w_qparams_0=None,
+                 a_qparams=None, a_qparams_0=None, module_name=None, split=0) -> None:
+        super().__init__()
+        self.module_name = module_name
+        self.split = split   # > 0: up-block conv_shortcut, input = cat(hidden[:split], skip)
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.device = device
+        self.kernel_size = kernel_size
+        self.stride = stride
+        self.padding = padding
+        self.dilation = dilation
+        self.groups = groups
+        square = (len(set(stride)) == 1 and len(set(padding)) == 1 and len(set(dilation)) == 1
+                  and dilation[0] == 1 and groups == 1)
+        self.valid_for_acceleration = (
+            _w8a8_ok(w_qparams, a_qparams)
+            and (split == 0 or _w8a8_ok(w_qparams_0, a_qparams_0))
+            and square)
+        if self.valid_for_acceleration and (in_channels % 4 != 0 or out_channels % 4 != 0):
+            logging.warning(
+                f"Conv2d layer with in_channels = {in_channels} and out_channels = "
+                f"{out_channels} cannot use quantized kernel due to misalignment. "
+                "Falling back to FP kernels")
+            self.valid_for_acceleration = False
+        if self.valid_for_acceleration:
+            self._register_qparams("", w_qparams, a_qparams, device)
+            if split != 0:
+                self._register_qparams("_0", w_qparams_0, a_qparams_0, device)
+
+    def _register_qparams(self, sfx, w, a, device):
+        self.register_buffer("weight_scales" + sfx, w.scales.to(device).float())
+        self.register_buffer("weight_zero_points" + sfx, w.zero_points.to(device).float())
+        self.register_buffer("act_scales" + sfx, a.scales.to(device).float())
+        self.register_buffer("act_zero_points" + sfx, a.zero_points.to(device).float())
+        self.register_buffer("act_scales_inv" + sfx, 1 / getattr(self, "act_scales" + sfx))
+
+    def _register_weight(self, sfx, weight, w_qparams, pad):
+        scales = getattr(self, "weight_scales" + sfx)
+        azp = getattr(self, "act_zero_points" + sfx)
+        weight_int = torch.quantize_per_channel(
+            weight.float(), scales, getattr(self, "weight_zero_points" + sfx),
+            axis=w_qparams.axis, dtype=w_qparams.dtype).int_repr()
+        self.register_buffer("weight_int" + sfx, weight_int)
+        if pad == 0:
+            # per-channel zero-point term (nn/Conv2d.py:166-171)
+            self.register_buffer("bias0" + sfx, weight_int.float().sum(dim=[1, 2, 3]) * azp)
+            setattr(self, "weight_sum_by_input_channels" + sfx, None)
+        else:
+            # per-tap sums; the border-dependent term is applied in the kernel (:172-177)
+            self.register_buffer("weight_sum_by_input_channels" + sfx,
+                                 weight_int.float().sum(dim=1, keepdim=True))
+            setattr(self, "bias0" + sfx, None)
+        self.register_buffer("scale" + sfx, scales * getattr(self, "act_scales" + sfx))
+
+    @classmethod
+    def from_float(cls, float_mod, split=0, ckpt=None):
+        assert hasattr(float_mod, "qconfig") and isinstance(float_mod.qconfig, QConfig)
+        w_dtype = float_mod.qconfig.weight().dtype
+        a_dtype = float_mod.qconfig.activation().dtype
+        device = float_mod.weight.device
+        common = dict(device=device, num_kernels=float_mod.weight.shape[0], ckpt=ckpt,
+                      module_name=float_mod.module_name, split=split)
+        w_qparams, w_qparams_0 = create_qparams_from_dtype(
+            dtype=w_dtype, is_channel_wise=True, quant_type="weight",
+            bit_width=float_mod.w_bit, **common)
+        a_qparams = a_qparams_0 = None
+        if hasattr(float_mod, "a_bit"):
+            a_qparams, a_qparams_0 = create_qparams_from_dtype(
+                dtype=a_dtype, is_channel_wise=False, quant_type="act",
+                bit_width=float_mod.a_bit, **common)
+        new_mod = cls(float_mod.in_channels, float_mod.out_channels, float_mod.kernel_size,
+                      float_mod.stride, float_mod.padding, float_mod.dilation, float_mod.groups,
+                      float_mod.bias is not None, device=device, w_qparams=w_qparams,
+                      w_qparams_0=w_qparams_0, a_qparams=a_qparams, a_qparams_0=a_qparams_0,
+                      module_name=float_mod.module_name, split=split)
+        weight = float_mod.weight.detach()
+        pad = float_mod.padding[0]
+        if new_mod.valid_for_acceleration:
+            if split == 0:
+                new_mod._register_weight("", weight, w_qparams, pad)
+            else:
+                new_mod._register_weight("", weight[:, :split, ...], w_qparams, pad)
+                new_mod._register_weight("_0", weight[:, split:, ...], w_qparams_0, pad)
+        else:
+            new_mod.register_buffer("weight", weight)
+        if float_mod.bias is not None:
+            new_mod.register_buffer("bias", float_mod.bias.detach())
+        else:
+            new_mod.bias = None
+        return new_mod
+
+    def _get_name(self):
+        return "QuantizedConv2dW8A8" if self.valid_for_acceleration else "QuantizedConv2dFPFallback"
+
+    def forward_fallback(self, x: torch.Tensor):
+        def deq(sfx):
+            w = getattr(self, "weight_int" + sfx).float()
+            return (w * getattr(self, "weight_scales" + sfx)[:, None, None, None]).to(x.dtype)
+
+        bias = self.bias.to(x.dtype) if self.bias is not None else None
+        args = (self.stride, self.padding, self.dilation, self.groups)
+        if self.split == 0:
+            return F.conv2d(x, deq(""), bias, *args)
+        return (F.conv2d(x[:, :self.split], deq(""), bias, *args)
+                + F.conv2d(x[:, self.split:], deq("_0"), None, *args))
+
+    def _border_table(self, sfx):
+        """Cached tap-rectangle sums for padded convs (weights only => computed once)."""
+        if self.padding[0] == 0:
+            return None
+        wsum = getattr(self, "weight_sum_by_input_channels" + sfx)
+        cache = self.__dict__.setdefault("_tables", {})
+        key = (sfx, wsum.data_ptr(), wsum.device)
+        if key not in cache:
+            if len(cache) > 4:   # buffers were moved / replaced: drop stale tables
+                cache.clear()
+            cache[key] = _C.conv_border_table(wsum)
+        return cache[key]
+
+    def _conv(self, x_int, sfx, bias):
+        return _C.qconv2d_w8_a8_ohalf(
+            x_int, getattr(self, "weight_int" + sfx), getattr(self, "weight_scales" + sfx),
+            getattr(self, "act_scales" + sfx), getattr(self, "act_zero_points" + sfx),
+            getattr(self, "scale" + sfx), getattr(self, "weight_sum_by_input_channels" + sfx),
+            getattr(self, "bias0" + sfx), bias, self.stride[0], self.padding[0], 1,
+            _table=self._border_table(sfx))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not self.valid_for_acceleration:
+            return F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation,
+                            self.groups)
+        if x.dtype != torch.float16:
+            return self.forward_fallback(x)
+        if self.split == 0:
+            x_int = quant_op(x, self.act_scales_inv, self.act_zero_points)
+            return self._conv(x_int, "", self.bias)
+        x_int = quant_op(x[:, :self.split], self.act_scales_inv, self.act_zero_points)
+        x_int_0 = quant_op(x[:, self.split:], self.act_scales_inv_0, self.act_zero_points_0)
+        # bias is applied once, in the first half (nn/Conv2d.py:341-343)
+        return self._conv(x_int, "", self.bias) + self._conv(x_int_0, "_0", None)

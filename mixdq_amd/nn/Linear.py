@@ -1,0 +1,134 @@
+"""QuantizedLinear for MI355X: counterpart of mixdq_extension/nn/Linear.py:17-194.
+
+Same constructor, `from_float(float_mod, split=0, ckpt=None)`, buffer names and forward
+semantics.  W8A8 layers run  quantize (HIP) -> INT8 GEMM + epilogue (HIP);  anything else
+(4/2-bit weights, missing activation qparams, misaligned sizes) keeps the FP16 weight and runs
+F.linear, exactly as the reference does (nn/Linear.py:31,37-43,133-134,155-156).
+
+Differences, all result-preserving:
+  * the BOS path (attn2.to_k / to_v) quantizes the strided slice x[:, 1:, :] correctly at any
+    batch size (the reference reads it linearly, right only at batch 1 -- SURVEY.md section 0) and
+    the GEMM writes tokens 1..T-1 straight into the [B, T, N] result next to the precomputed
+    token-0 row, instead of torch.cat (nn/Linear.py:190-193).
+"""
+from __future__ import annotations
+
+import logging
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.ao.quantization import QConfig
+
+from mixdq_amd.nn.utils import create_qparams_from_dtype
+from mixdq_amd.op.quant import quantize_per_tensor_vectorized
+from mixdq_amd.op.qlinear import qlinear
+
+__all__ = ["QuantizedLinear"]
+
+quant_op = quantize_per_tensor_vectorized
+
+_INT8 = (torch.qint8, torch.quint8)
+
+
+def _w8a8_ok(w_qparams, a_qparams) -> bool:
+    """nn/Linear.py:27-36: per-channel symmetric int8 weights, per-tensor int8 activations."""
+    return bool(
+        w_qparams is not None and a_qparams is not None
+        and w_qparams.dtype in _INT8 and a_qparams.dtype in _INT8
+        and w_qparams.qscheme == torch.per_channel_affine
+        and a_qparams.qscheme == torch.per_tensor_affine
+        and torch.all(w_qparams.zero_points == 0.0).item())
+
+
+class QuantizedLinear(nn.Module):
+    def __init__(self, in_features: int, out_features: int, bias: bool = True, device=None,
+                 w_qparams=None, a_qparams=None, module_name=None) -> None:
+        super().__init__()
+        self.module_name = module_name
+        self.in_features = in_features
+        self.out_features = out_features
+        self.device = device
+        self.valid_for_acceleration = _w8a8_ok(w_qparams, a_qparams)
+        if self.valid_for_acceleration and (in_features % 4 != 0 or out_features % 4 != 0):
+            logging.warning(
+                f"Linear layer with in_features = {in_features} and out_features = "
+                f"{out_features} cannot use quantized kernel due to misalignment. "
+                "Falling back to FP kernels")
+            self.valid_for_acceleration = False
+        if self.valid_for_acceleration:
+            self.register_buffer("weight_scales", w_qparams.scales.to(device).float())
+            self.register_buffer("weight_zero_points", w_qparams.zero_points.to(device).float())
+            self.register_buffer("act_scales", a_qparams.scales.to(device).float())
+            self.register_buffer("act_zero_points", a_qparams.zero_points.to(device).float())
+            self.register_buffer("act_scales_inv", 1 / self.act_scales)
+
+    @classmethod
+    def from_float(cls, float_mod, split=0, ckpt=None):
+        assert hasattr(float_mod, "qconfig") and isinstance(float_mod.qconfig, QConfig)
+        w_dtype = float_mod.qconfig.weight().dtype
+        a_dtype = float_mod.qconfig.activation().dtype
+        device = float_mod.weight.device
+        common = dict(device=device, num_kernels=float_mod.weight.shape[0], ckpt=ckpt,
+                      module_name=float_mod.module_name, split=split)
+        w_qparams, _ = create_qparams_from_dtype(dtype=w_dtype, is_channel_wise=True,
+                                                 quant_type="weight", bit_width=float_mod.w_bit,
+                                                 **common)
+        a_qparams = None
+        if hasattr(float_mod, "a_bit"):   # no a_bit => activation stays fp16 => FP fallback
+            a_qparams, _ = create_qparams_from_dtype(dtype=a_dtype, is_channel_wise=False,
+                                                     quant_type="act", bit_width=float_mod.a_bit,
+                                                     **common)
+        new_mod = cls(float_mod.in_features, float_mod.out_features, float_mod.bias is not None,
+                      device=device, w_qparams=w_qparams, a_qparams=a_qparams,
+                      module_name=float_mod.module_name)
+        weight = float_mod.weight.detach()
+        name = float_mod.module_name
+        if "attn2" in name and ("to_k" in name or "to_v" in name):
+            new_mod.bos = float_mod.bos
+            new_mod.register_buffer("bos_pre_computed", float_mod.bos_pre_computed)
+        if new_mod.valid_for_acceleration:
+            weight_int = torch.quantize_per_channel(
+                weight.float(), new_mod.weight_scales, new_mod.weight_zero_points,
+                axis=w_qparams.axis, dtype=w_qparams.dtype).int_repr()
+            new_mod.register_buffer("weight_int", weight_int)
+            # auxiliary vectors of the epilogue  D = (acc - bias0) * scale + bias
+            wsum = weight_int.float().sum(dim=1)
+            new_mod.register_buffer("weight_sum_by_input_channels", wsum)
+            new_mod.register_buffer("scale", new_mod.weight_scales * new_mod.act_scales)
+            new_mod.register_buffer("bias0", wsum * new_mod.act_zero_points)
+        else:
+            new_mod.register_buffer("weight", weight)
+        if float_mod.bias is not None:
+            new_mod.register_buffer("bias", float_mod.bias.detach())
+        else:
+            new_mod.bias = None
+        return new_mod
+
+    def _get_name(self):
+        return "QuantizedLinearW8A8" if self.valid_for_acceleration else "QuantizedLinearFPFallback"
+
+    def forward_fallback(self, x):
+        w = (self.weight_int.float() * self.weight_scales[:, None]).to(x.dtype)
+        return F.linear(x, w, self.bias.to(x.dtype) if self.bias is not None else None)
+
+    def _gemm(self, x_int, out=None, row_map=None):
+        return qlinear(x_int, self.weight_int, self.weight_scales, self.act_scales,
+                       self.act_zero_points, self.weight_sum_by_input_channels, self.scale,
+                       self.bias0, self.bias, _out=out, _row_map=row_map)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if not self.valid_for_acceleration:
+            return F.linear(x, self.weight, self.bias)
+        if x.dtype != torch.float16:
+            return self.forward_fallback(x)
+        if not getattr(self, "bos", False):
+            return self._gemm(quant_op(x, self.act_scales_inv, self.act_zero_points))
+        # BOS carve-out: token 0 is a precomputed FP16 row, tokens 1.. go through the kernels
+        B, T = x.shape[0], x.shape[1]
+        x_int = quant_op(x[:, 1:, :], self.act_scales_inv, self.act_zero_points)
+        out = torch.empty((B, T, self.out_features), dtype=torch.float16, device=x.device)
+        out[:, :1, :] = self.bos_pre_computed
+        if T > 1:
+            self._gemm(x_int, out=out, row_map=(T - 1, T, 1))
+        return out

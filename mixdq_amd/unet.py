@@ -1,0 +1,345 @@
+"""SDXL(-Turbo) UNet graph with diffusers-compatible module names.
+
+diffusers is not installed anywhere this repo runs, and the reference's harness
+(kernels/quantize_sdxl.py:331-484) drives `pipeline.unet`.  This module is a structural clone of
+`UNet2DConditionModel` for the SDXL config (block channels 320/640/1280, transformer depth
+0/2/10 + mid 10, cross-attention dim 2048, text_time addition embedding 2816 -> 1280) whose
+`named_modules()` reproduce exactly the 794 quantizable layer names of the reference's bit-width
+yamls (743 Linear + 51 Conv2d), so `quantize_unet` drops in unchanged.
+Every Linear/Conv2d is a plain nn.Linear/nn.Conv2d until `mixdq_amd.quantize.convert` swaps it.
+
+The glue between quantized layers (GroupNorm, SiLU, LayerNorm, GEGLU, scaled-dot-product
+attention, nearest upsample) stays FP16 PyTorch, as in the reference (SURVEY.md section 0:
+the reference fuses none of it and runs attention in FP16).  Activations are kept channels-last
+so the INT8 NHWC conv never converts layouts (qconv2d.cc:91-95 would copy).
+
+Weights are synthetic (no network, no checkpoints): randn * 0.02, seeded per layer.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+SDXL_CONFIG = dict(
+    in_channels=4, out_channels=4,
+    block_out_channels=(320, 640, 1280),
+    layers_per_block=2,
+    transformer_layers_per_block=(0, 2, 10),   # 0 = plain DownBlock2D / UpBlock2D
+    mid_transformer_layers=10,
+    head_dim=64,
+    cross_attention_dim=2048,
+    time_embed_dim=1280,
+    addition_time_embed_dim=256,
+    projection_class_embeddings_input_dim=2816,
+    norm_num_groups=32,
+)
+
+
+def sinusoidal_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
+    """diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0)."""
+    half = dim // 2
+    exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=t.device) / half
+    emb = t.float()[:, None] * torch.exp(exponent)[None, :]
+    return torch.cat([torch.cos(emb), torch.sin(emb)], dim=-1)
+
+
+class TimestepEmbedding(nn.Module):
+    def __init__(self, in_dim, dim):
+        super().__init__()
+        self.linear_1 = nn.Linear(in_dim, dim)
+        self.linear_2 = nn.Linear(dim, dim)
+
+    def forward(self, x):
+        return self.linear_2(F.silu(self.linear_1(x)))
+
+
+class ResnetBlock2D(nn.Module):
+    def __init__(self, cin, cout, temb_dim, groups, split=0):
+        super().__init__()
+        self.norm1 = nn.GroupNorm(groups, cin, eps=1e-5)
+        self.conv1 = nn.Conv2d(cin, cout, 3, 1, 1)
+        self.time_emb_proj = nn.Linear(temb_dim, cout)
+        self.norm2 = nn.GroupNorm(groups, cout, eps=1e-5)
+        self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1)
+        self.conv_shortcut = nn.Conv2d(cin, cout, 1, 1, 0) if cin != cout else None
+        if self.conv_shortcut is not None and split:
+            # up-block: input = cat(hidden[:split], skip); the quantized shortcut uses separate
+            # activation scales for the two halves (quant_block_forward_func.py:153-157)
+            self.conv_shortcut.split = split
+
+    def forward(self, x, temb):
+        h = self.conv1(F.silu(self.norm1(x)))
+        h = h + self.time_emb_proj(F.silu(temb))[:, :, None, None]
+        h = self.conv2(F.silu(self.norm2(h)))
+        if self.conv_shortcut is not None:
+            x = self.conv_shortcut(x)
+        return x + h
+
+
+class Attention(nn.Module):
+    def __init__(self, dim, cross_dim, head_dim):
+        super().__init__()
+        self.heads = dim // head_dim
+        kv_dim = cross_dim if cross_dim is not None else dim
+        self.to_q = nn.Linear(dim, dim, bias=False)
+        self.to_k = nn.Linear(kv_dim, dim, bias=False)
+        self.to_v = nn.Linear(kv_dim, dim, bias=False)
+        self.to_out = nn.ModuleList([nn.Linear(dim, dim), nn.Identity()])
+
+    def forward(self, x, context=None):
+        context = x if context is None else context
+        B, T, C = x.shape
+        h = self.heads
+        q = self.to_q(x).view(B, T, h, C // h).transpose(1, 2)
+        k = self.to_k(context).view(B, -1, h, C // h).transpose(1, 2)
+        v = self.to_v(context).view(B, -1, h, C // h).transpose(1, 2)
+        o = F.scaled_dot_product_attention(q, k, v)   # FP16, as in the reference
+        return self.to_out[0](o.transpose(1, 2).reshape(B, T, C))
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim, inner):
+        super().__init__()
+        self.proj = nn.Linear(dim, inner * 2)
+
+    def forward(self, x):
+        x, gate = self.proj(x).chunk(2, dim=-1)
+        return x * F.gelu(gate)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.net = nn.ModuleList([GEGLU(dim, dim * 4), nn.Identity(), nn.Linear(dim * 4, dim)])
+
+    def forward(self, x):
+        return self.net[2](self.net[0](x))
+
+
+class BasicTransformerBlock(nn.Module):
+    def __init__(self, dim, cross_dim, head_dim):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn1 = Attention(dim, None, head_dim)
+        self.norm2 = nn.LayerNorm(dim)
+        self.attn2 = Attention(dim, cross_dim, head_dim)
+        self.norm3 = nn.LayerNorm(dim)
+        self.ff = FeedForward(dim)
+
+    def forward(self, x, context):
+        x = x + self.attn1(self.norm1(x))
+        x = x + self.attn2(self.norm2(x), context)
+        return x + self.ff(self.norm3(x))
+
+
+class Transformer2DModel(nn.Module):
+    def __init__(self, dim, depth, cross_dim, head_dim, groups):
+        super().__init__()
+        self.norm = nn.GroupNorm(groups, dim, eps=1e-6)
+        self.proj_in = nn.Linear(dim, dim)
+        self.transformer_blocks = nn.ModuleList(
+            [BasicTransformerBlock(dim, cross_dim, head_dim) for _ in range(depth)])
+        self.proj_out = nn.Linear(dim, dim)
+
+    def forward(self, x, context):
+        B, C, H, W = x.shape
+        res = x
+        h = self.norm(x).permute(0, 2, 3, 1).reshape(B, H * W, C)   # free when channels-last
+        h = self.proj_in(h)
+        for blk in self.transformer_blocks:
+            h = blk(h, context)
+        h = self.proj_out(h)
+        h = h.reshape(B, H, W, C).permute(0, 3, 1, 2)               # channels-last view
+        return h + res
+
+
+class Downsample2D(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, 3, 2, 1)
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class Upsample2D(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, 3, 1, 1)
+
+    def forward(self, x):
+        return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
+
+
+class DownBlock(nn.Module):
+    def __init__(self, cin, cout, temb, n_layers, depth, cfg, add_down):
+        super().__init__()
+        self.resnets = nn.ModuleList(
+            [ResnetBlock2D(cin if i == 0 else cout, cout, temb, cfg["norm_num_groups"])
+             for i in range(n_layers)])
+        if depth:
+            self.attentions = nn.ModuleList(
+                [Transformer2DModel(cout, depth, cfg["cross_attention_dim"], cfg["head_dim"],
+                                    cfg["norm_num_groups"]) for _ in range(n_layers)])
+        self.has_attn = bool(depth)
+        if add_down:
+            self.downsamplers = nn.ModuleList([Downsample2D(cout)])
+        self.has_down = add_down
+
+    def forward(self, x, temb, context):
+        outs = []
+        for i, res in enumerate(self.resnets):
+            x = res(x, temb)
+            if self.has_attn:
+                x = self.attentions[i](x, context)
+            outs.append(x)
+        if self.has_down:
+            x = self.downsamplers[0](x)
+            outs.append(x)
+        return x, outs
+
+
+class MidBlock(nn.Module):
+    def __init__(self, c, temb, depth, cfg):
+        super().__init__()
+        self.attentions = nn.ModuleList(
+            [Transformer2DModel(c, depth, cfg["cross_attention_dim"], cfg["head_dim"],
+                                cfg["norm_num_groups"])])
+        self.resnets = nn.ModuleList([ResnetBlock2D(c, c, temb, cfg["norm_num_groups"])
+                                      for _ in range(2)])
+
+    def forward(self, x, temb, context):
+        x = self.resnets[0](x, temb)
+        x = self.attentions[0](x, context)
+        return self.resnets[1](x, temb)
+
+
+class UpBlock(nn.Module):
+    def __init__(self, prev_c, cout, skip_channels, temb, depth, cfg, add_up):
+        super().__init__()
+        res = []
+        for i, skip in enumerate(skip_channels):
+            hidden = prev_c if i == 0 else cout
+            res.append(ResnetBlock2D(hidden + skip, cout, temb, cfg["norm_num_groups"],
+                                     split=hidden))
+        self.resnets = nn.ModuleList(res)
+        if depth:
+            self.attentions = nn.ModuleList(
+                [Transformer2DModel(cout, depth, cfg["cross_attention_dim"], cfg["head_dim"],
+                                    cfg["norm_num_groups"]) for _ in skip_channels])
+        self.has_attn = bool(depth)
+        if add_up:
+            self.upsamplers = nn.ModuleList([Upsample2D(cout)])
+        self.has_up = add_up
+
+    def forward(self, x, skips, temb, context):
+        for i, res in enumerate(self.resnets):
+            x = torch.cat([x, skips.pop()], dim=1)
+            x = res(x, temb)
+            if self.has_attn:
+                x = self.attentions[i](x, context)
+        if self.has_up:
+            x = self.upsamplers[0](x)
+        return x
+
+
+class SDXLUNet(nn.Module):
+    """forward(sample, timestep, encoder_hidden_states, added_cond_kwargs, return_dict=False)
+    -> (noise_pred,), the call shape of quantize_sdxl.py:375-385."""
+
+    def __init__(self, cfg=None):
+        super().__init__()
+        cfg = dict(SDXL_CONFIG, **(cfg or {}))
+        self.cfg = cfg
+        boc = cfg["block_out_channels"]
+        temb = cfg["time_embed_dim"]
+        self.conv_in = nn.Conv2d(cfg["in_channels"], boc[0], 3, 1, 1)
+        self.time_embedding = TimestepEmbedding(boc[0], temb)
+        self.add_embedding = TimestepEmbedding(cfg["projection_class_embeddings_input_dim"], temb)
+        n = cfg["layers_per_block"]
+        depths = cfg["transformer_layers_per_block"]
+        self.down_blocks = nn.ModuleList()
+        skip = [boc[0]]
+        cin = boc[0]
+        for i, cout in enumerate(boc):
+            last = i == len(boc) - 1
+            self.down_blocks.append(DownBlock(cin, cout, temb, n, depths[i], cfg, not last))
+            skip += [cout] * n + ([] if last else [cout])
+            cin = cout
+        self.mid_block = MidBlock(boc[-1], temb, cfg["mid_transformer_layers"], cfg)
+        self.up_blocks = nn.ModuleList()
+        prev = boc[-1]
+        for i, cout in enumerate(reversed(boc)):
+            last = i == len(boc) - 1
+            sk = [skip.pop() for _ in range(n + 1)]
+            self.up_blocks.append(UpBlock(prev, cout, sk, temb, list(reversed(depths))[i], cfg,
+                                          not last))
+            prev = cout
+        self.conv_norm_out = nn.GroupNorm(cfg["norm_num_groups"], boc[0], eps=1e-5)
+        self.conv_out = nn.Conv2d(boc[0], cfg["out_channels"], 3, 1, 1)
+
+    @property
+    def sample_size_for(self):
+        return {512: 64, 1024: 128}
+
+    def forward(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None,
+                return_dict=False):
+        cfg = self.cfg
+        B = sample.shape[0]
+        dtype = sample.dtype
+        t = timestep
+        if not torch.is_tensor(t):
+            t = torch.tensor([t], dtype=torch.float32, device=sample.device)
+        t = t.reshape(-1).expand(B)
+        emb = self.time_embedding(sinusoidal_embedding(t, cfg["block_out_channels"][0]).to(dtype))
+        time_ids = added_cond_kwargs["time_ids"]
+        text_embeds = added_cond_kwargs["text_embeds"]
+        tid = sinusoidal_embedding(time_ids.flatten(), cfg["addition_time_embed_dim"])
+        add = torch.cat([text_embeds, tid.reshape(B, -1).to(dtype)], dim=-1)
+        emb = emb + self.add_embedding(add)
+
+        x = sample.contiguous(memory_format=torch.channels_last)
+        x = self.conv_in(x)
+        skips = [x]
+        for blk in self.down_blocks:
+            x, outs = blk(x, emb, encoder_hidden_states)
+            skips += outs
+        x = self.mid_block(x, emb, encoder_hidden_states)
+        for blk in self.up_blocks:
+            x = blk(x, skips, emb, encoder_hidden_states)
+        x = self.conv_out(F.silu(self.conv_norm_out(x)))
+        return (x,)
+
+
+# ---------------------------------------------------------------------------------------------
+# synthetic weights, layer inventory
+# ---------------------------------------------------------------------------------------------
+def quantizable_layers(unet: nn.Module) -> "OrderedDict[str, nn.Module]":
+    """name -> nn.Linear / nn.Conv2d in named_modules() order: the keys of the bit-width yamls."""
+    return OrderedDict((n, m) for n, m in unet.named_modules()
+                       if isinstance(m, (nn.Linear, nn.Conv2d)))
+
+
+@torch.no_grad()
+def init_synthetic_weights(unet: nn.Module, seed: int = 42, std: float = 0.02):
+    """randn * 0.02, generator seeded with seed + layer index."""
+    for idx, (name, mod) in enumerate(quantizable_layers(unet).items()):
+        g = torch.Generator(device="cpu").manual_seed(seed + idx)
+        mod.weight.copy_(torch.randn(mod.weight.shape, generator=g) * std)
+        if mod.bias is not None:
+            mod.bias.copy_(torch.randn(mod.bias.shape, generator=g) * std)
+    return unet
+
+
+def build_unet(device=None, dtype=torch.float16, seed: int = 42, cfg=None) -> SDXLUNet:
+    unet = SDXLUNet(cfg)
+    init_synthetic_weights(unet, seed)
+    unet = unet.to(dtype=dtype)
+    if device is not None:
+        unet = unet.to(device)
+    unet = unet.to(memory_format=torch.channels_last)
+    return unet.eval()

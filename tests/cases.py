@@ -6,6 +6,8 @@ first 15 conv cases are the shapes of the reference's own self-tests (op/qlinear
 op/qconv2d.py:104-119).
 """
 import numpy as np
+import torch
+import torch.nn as nn
 
 from oracle import oracle as O
 from tests import detdata as dd
@@ -90,3 +92,59 @@ def conv_inputs(case):
     return x, wt, wscale, in_scale, in_zp, bias, scale, wsum, bias0
 
 
+
+
+# ---- module-level cases (run through the reference's own classes in gen_golden.py) ----------
+def make_float_module(c):
+    kw, kind, name, seed = c, c["kind"], c["name"], c["seed"]
+    if kind == "linear":
+        m = nn.Linear(kw["cin"], kw["cout"], bias=kw["bias"])
+        wshape = (kw["cout"], kw["cin"])
+    else:
+        m = nn.Conv2d(kw["cin"], kw["cout"], kw["ksize"], kw["stride"], kw["pad"], bias=kw["bias"])
+        wshape = (kw["cout"], kw["cin"], kw["ksize"], kw["ksize"])
+    w = dd.normal_f16(seed, wshape, std=0.05)
+    m.weight.data = torch.from_numpy(w.astype(np.float32))
+    if kw["bias"]:
+        m.bias.data = torch.from_numpy(dd.normal_f16(seed + 1, (kw["cout"],), std=0.1).astype(np.float32))
+    m.module_name = name
+    return m
+
+
+MODULE_CASES = [
+    dict(key="lin_basic", kind="linear", name="down_blocks.1.attentions.0.transformer_blocks.0.attn1.to_q",
+         cin=64, cout=32, bias=True, xshape=(2, 5, 64), seed=401),
+    dict(key="lin_nobias", kind="linear", name="mid_block.attentions.0.transformer_blocks.0.attn1.to_k",
+         cin=128, cout=48, bias=False, xshape=(1, 9, 128), seed=402),
+    dict(key="lin_bos", kind="linear", name="down_blocks.1.attentions.0.transformer_blocks.0.attn2.to_k",
+         cin=2048, cout=640, bias=False, xshape=(1, 77, 2048), seed=403, bos=True),
+    dict(key="conv_p1", kind="conv", name="down_blocks.0.resnets.0.conv1",
+         cin=64, cout=96, ksize=3, stride=1, pad=1, bias=True, xshape=(2, 64, 8, 8), seed=404),
+    dict(key="conv_s2", kind="conv", name="down_blocks.0.downsamplers.0.conv",
+         cin=64, cout=64, ksize=3, stride=2, pad=1, bias=True, xshape=(1, 64, 8, 8), seed=405),
+    dict(key="conv_1x1", kind="conv", name="down_blocks.1.resnets.0.conv_shortcut",
+         cin=64, cout=96, ksize=1, stride=1, pad=0, bias=True, xshape=(2, 64, 6, 6), seed=406),
+    dict(key="conv_split", kind="conv", name="up_blocks.0.resnets.0.conv_shortcut",
+         cin=96, cout=32, ksize=1, stride=1, pad=0, bias=True, xshape=(1, 96, 6, 6), seed=407,
+         split=64),
+]
+
+
+
+
+def module_input(c):
+    return torch.from_numpy(dd.normal_f16(c["seed"] + 10, c["xshape"], std=1.2))
+
+
+def module_ckpt(c, golden):
+    """Rebuild the kernel-format checkpoint of one module case from modules.npz."""
+    key, name = c["key"], c["name"]
+    ck = {}
+    for sfx in ("weight_quantizer", "act_quantizer", "weight_quantizer_0", "act_quantizer_0"):
+        k = f"{key}.ckpt.{sfx}.delta_list"
+        if k in golden:
+            ck[f"{name}.{sfx}"] = {
+                "delta_list": torch.from_numpy(golden[k]),
+                "zero_point_list": torch.from_numpy(golden[f"{key}.ckpt.{sfx}.zero_point_list"]),
+            }
+    return ck

@@ -44,7 +44,8 @@ REF = os.environ.get("MIXDQ_REFERENCE", "/root/reference")
 
 from oracle import oracle as O  # noqa: E402
 from tests import detdata as dd  # noqa: E402
-from tests.cases import (LINEAR_CASES, CONV_CASES, linear_inputs, conv_inputs)  # noqa: E402
+from tests.cases import (LINEAR_CASES, CONV_CASES, MODULE_CASES, linear_inputs, conv_inputs,  # noqa: E402
+                         make_float_module, module_input)
 
 
 def sha(a: np.ndarray) -> str:
@@ -177,21 +178,32 @@ def gen_quantize(small):
         small[f"q_edge_{nm}"] = a
         cases.append(dict(name=f"q_edge_{nm}", x="q_edge_x", scale_inv=s_inv, zp=zp,
                           expect=f"q_edge_{nm}"))
-    # fma-vs-(mul,add) separator: search values where the two variants differ
-    s_inv = float(np.float32(1.0) / np.float32(0.0123))
-    zp = 37.0
-    allh = np.arange(0, 0x7c00, dtype=np.uint16).view(np.float16)
+    # fma-vs-(mul,add) separators: (x, s_inv, zp) triples where the two variants round differently
+    # (about one in 10^7 of random triples), found by exhaustive search over all finite halves.
+    allh = np.arange(1, 0x7c00, dtype=np.uint16).view(np.float16)
     allh = np.concatenate([allh, -allh])
-    a = O.quantize(allh, s_inv, zp, 0)
-    b = O.quantize(allh, s_inv, zp, 1)
-    diff = np.nonzero(a != b)[0]
-    sep = allh[diff][:64]
-    small["q_sep_x"] = sep
-    small["q_sep_A"] = O.quantize(sep, s_inv, zp, 0)
-    small["q_sep_B"] = O.quantize(sep, s_inv, zp, 1)
-    cases.append(dict(name="q_sep", x="q_sep_x", scale_inv=s_inv, zp=zp, expect_A="q_sep_A",
-                      expect_B="q_sep_B", n_all_half_values_differing=int(diff.size),
-                      sha_all_A=sha(a), sha_all_B=sha(b)))
+    u = dd.uniform01(999, (4000,))
+    sx, ss, sz, sa, sb = [], [], [], [], []
+    for i in range(4000):
+        s_inv = float(np.float32(1.0) / np.float32(0.005 + 0.2 * u[i]))
+        zp = float(int(-128 + (i * 37) % 256))
+        a = O.quantize(allh, s_inv, zp, 0)
+        b = O.quantize(allh, s_inv, zp, 1)
+        for j in np.nonzero(a != b)[0][:2]:
+            sx.append(allh[j]); ss.append(s_inv); sz.append(zp); sa.append(a[j]); sb.append(b[j])
+    assert len(sx) >= 16
+    small["q_sep_x"] = np.asarray(sx, dtype=np.float16)
+    small["q_sep_sinv"] = np.asarray(ss, dtype=np.float32)
+    small["q_sep_zp"] = np.asarray(sz, dtype=np.float32)
+    small["q_sep_A"] = np.asarray(sa, dtype=np.int8)
+    small["q_sep_B"] = np.asarray(sb, dtype=np.int8)
+    cases.append(dict(name="q_sep", x="q_sep_x", scale_inv="q_sep_sinv", zp="q_sep_zp",
+                      expect_A="q_sep_A", expect_B="q_sep_B", n=len(sx)))
+    # one full sweep of every finite half for a fixed realistic scale (hash only)
+    s_inv = float(np.float32(1.0) / np.float32(0.0123))
+    a = O.quantize(allh, s_inv, 37.0, 0)
+    b = O.quantize(allh, s_inv, 37.0, 1)
+    cases.append(dict(name="q_allhalf", scale_inv=s_inv, zp=37.0, sha_A=sha(a), sha_B=sha(b)))
     # strided inputs (intended semantics; the reference reads linearly -- SURVEY section 0)
     x = dd.normal_f16(120, (2, 77, 64))
     small["q_bos_slice"] = O.quantize(x[:, 1:, :], 8.0, 3.0)
@@ -359,41 +371,6 @@ def set_bits(layer, w_bits, a_bits, split=0):
         q.bitwidth_refactor(b)
 
 
-def make_float_module(c):
-    kw, kind, name, seed = c, c["kind"], c["name"], c["seed"]
-    if kind == "linear":
-        m = nn.Linear(kw["cin"], kw["cout"], bias=kw["bias"])
-        wshape = (kw["cout"], kw["cin"])
-    else:
-        m = nn.Conv2d(kw["cin"], kw["cout"], kw["ksize"], kw["stride"], kw["pad"], bias=kw["bias"])
-        wshape = (kw["cout"], kw["cin"], kw["ksize"], kw["ksize"])
-    w = dd.normal_f16(seed, wshape, std=0.05)
-    m.weight.data = torch.from_numpy(w.astype(np.float32))
-    if kw["bias"]:
-        m.bias.data = torch.from_numpy(dd.normal_f16(seed + 1, (kw["cout"],), std=0.1).astype(np.float32))
-    m.module_name = name
-    return m
-
-
-MODULE_CASES = [
-    dict(key="lin_basic", kind="linear", name="down_blocks.1.attentions.0.transformer_blocks.0.attn1.to_q",
-         cin=64, cout=32, bias=True, xshape=(2, 5, 64), seed=401),
-    dict(key="lin_nobias", kind="linear", name="mid_block.attentions.0.transformer_blocks.0.attn1.to_k",
-         cin=128, cout=48, bias=False, xshape=(1, 9, 128), seed=402),
-    dict(key="lin_bos", kind="linear", name="down_blocks.1.attentions.0.transformer_blocks.0.attn2.to_k",
-         cin=2048, cout=640, bias=False, xshape=(1, 77, 2048), seed=403, bos=True),
-    dict(key="conv_p1", kind="conv", name="down_blocks.0.resnets.0.conv1",
-         cin=64, cout=96, ksize=3, stride=1, pad=1, bias=True, xshape=(2, 64, 8, 8), seed=404),
-    dict(key="conv_s2", kind="conv", name="down_blocks.0.downsamplers.0.conv",
-         cin=64, cout=64, ksize=3, stride=2, pad=1, bias=True, xshape=(1, 64, 8, 8), seed=405),
-    dict(key="conv_1x1", kind="conv", name="down_blocks.1.resnets.0.conv_shortcut",
-         cin=64, cout=96, ksize=1, stride=1, pad=0, bias=True, xshape=(2, 64, 6, 6), seed=406),
-    dict(key="conv_split", kind="conv", name="up_blocks.0.resnets.0.conv_shortcut",
-         cin=96, cout=32, ksize=1, stride=1, pad=0, bias=True, xshape=(1, 96, 6, 6), seed=407,
-         split=64),
-]
-
-
 def gen_modules(QuantizedLinear, QuantizedConv2d, ql_mod):
     from torch.ao.quantization import QConfig, PlaceholderObserver
     bos_dict = torch.load(os.path.join(REF, "kernels", "bos_pre_computed.pt"), map_location="cpu")
@@ -402,7 +379,7 @@ def gen_modules(QuantizedLinear, QuantizedConv2d, ql_mod):
     for c in MODULE_CASES:
         key, split = c["key"], c.get("split", 0)
         fm = make_float_module(c)
-        x = torch.from_numpy(dd.normal_f16(c["seed"] + 10, c["xshape"], std=1.2))
+        x = module_input(c)
         # ---- Path A: calibrate the reference QuantLayer on this input (fp32 on CPU) ----------
         layer, _ = calibrate_quantlayer(ql_mod, fm, x.float(), split)
         ckpt = ckpt_from_quantlayer(layer, c["name"], split)

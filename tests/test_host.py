@@ -1,0 +1,313 @@
+"""CPU tests of the host logic: QuantizedLinear / QuantizedConv2d buffer derivation against the
+buffers the REFERENCE's own from_float produced (modules.npz), forward dispatch (BOS, split,
+fallbacks) with the operators stubbed by the oracle, module swap, yaml registration, configs,
+calibration format."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+from torch.ao.quantization import PlaceholderObserver, QConfig
+
+from tests.cases import MODULE_CASES, make_float_module, module_ckpt, module_input
+
+
+def prepared(c, golden, w_bit=8, a_bit=8, with_act=True):
+    fm = make_float_module(c).half()
+    fm.module_name = c["name"]
+    wd = {8: torch.qint8, 4: torch.quint4x2, 2: torch.quint4x2}[w_bit]
+    fm.qconfig = QConfig(activation=PlaceholderObserver.with_args(dtype=torch.qint8),
+                         weight=PlaceholderObserver.with_args(dtype=wd))
+    fm.w_bit = w_bit
+    if with_act:
+        fm.a_bit = a_bit
+    if c.get("bos"):
+        fm.bos = True
+        fm.bos_pre_computed = torch.from_numpy(golden[f"{c['key']}.bos_pre_computed"])
+    return fm
+
+
+@pytest.fixture
+def oracle_ops(monkeypatch, oracle):
+    """Stand-ins for the three HIP operators, backed by the oracle, so forward() dispatch can be
+    exercised on a CPU-only box.  Test-only: the product has no such fallback."""
+    import mixdq_amd.nn.Linear as L
+    import mixdq_amd.nn.Conv2d as Cv
+
+    def quant(x, s_inv, zp):
+        out = torch.empty_like(x, dtype=torch.int8)
+        out.copy_(torch.from_numpy(oracle.quantize(x.numpy(), float(s_inv), float(zp))))
+        return out
+
+    def qlin(x_int, w, ws, a_s, a_zp, wsum, scale, bias0, bias=None, _out=None, _row_map=None):
+        D = torch.from_numpy(oracle.qlinear(x_int.contiguous().numpy(), w.numpy(), bias0.numpy(),
+                                            scale.numpy(), None if bias is None else bias.numpy()))
+        if _out is None:
+            return D
+        g, stride, off = _row_map
+        _out.view(-1, _out.shape[-1]).view(-1, stride, _out.shape[-1])[:, off:off + g] = \
+            D.reshape(-1, g, D.shape[-1])
+        return _out
+
+    def qconv(x_int, w, ws, a_s, a_zp, scale, wsum, bias0, bias=None, stride=1, padding=0,
+              dilation=1, _table=None):
+        D = oracle.qconv2d(x_int.permute(0, 2, 3, 1).contiguous().numpy(),
+                           w.permute(0, 2, 3, 1).contiguous().numpy(), scale.numpy(),
+                           None if wsum is None else wsum.numpy(), float(a_zp),
+                           None if bias0 is None else bias0.numpy(),
+                           None if bias is None else bias.numpy(), stride, padding)
+        return torch.from_numpy(D).permute(0, 3, 1, 2)
+
+    monkeypatch.setattr(L, "quant_op", quant)
+    monkeypatch.setattr(L, "qlinear", qlin)
+    monkeypatch.setattr(Cv, "quant_op", quant)
+    monkeypatch.setattr(Cv._C, "qconv2d_w8_a8_ohalf", qconv)
+    monkeypatch.setattr(Cv.QuantizedConv2d, "_border_table", lambda self, sfx: None)
+
+
+@pytest.mark.parametrize("c", MODULE_CASES, ids=[c["key"] for c in MODULE_CASES])
+def test_from_float_buffers_match_reference(modules_golden, c):
+    from mixdq_amd.nn import QuantizedConv2d, QuantizedLinear
+    import hashlib
+    cls = QuantizedLinear if c["kind"] == "linear" else QuantizedConv2d
+    qm = cls.from_float(prepared(c, modules_golden), split=c.get("split", 0),
+                        ckpt=module_ckpt(c, modules_golden))
+    assert qm.valid_for_acceleration
+    ref = {k[len(c["key"]) + 5:]: v for k, v in modules_golden.items()
+           if k.startswith(c["key"] + ".buf.")}
+    refsha = {k[len(c["key"]) + 8:]: v for k, v in modules_golden.items()
+              if k.startswith(c["key"] + ".bufsha.")}
+    mine = dict(qm.named_buffers())
+    assert set(mine) == set(ref) | set(refsha), (sorted(mine), sorted(ref), sorted(refsha))
+    for name, want in ref.items():
+        got = mine[name].numpy()
+        assert got.dtype == want.dtype and got.shape == want.shape, name
+        assert np.array_equal(got, want), name
+    for name, want in refsha.items():
+        got = hashlib.sha256(mine[name].contiguous().numpy().tobytes()).hexdigest()
+        assert got == str(want), name
+    # attributes the reference sets to None for the unused epilogue form (nn/Conv2d.py:171,177)
+    if c["kind"] == "conv":
+        if c["pad"] == 0:
+            assert qm.weight_sum_by_input_channels is None
+        else:
+            assert qm.bias0 is None
+
+
+@pytest.mark.parametrize("c", MODULE_CASES, ids=[c["key"] for c in MODULE_CASES])
+def test_forward_dispatch_matches_reference_output(modules_golden, oracle_ops, c):
+    """forward() over oracle-backed ops == the reference class's forward over the same ops."""
+    from mixdq_amd.nn import QuantizedConv2d, QuantizedLinear
+    cls = QuantizedLinear if c["kind"] == "linear" else QuantizedConv2d
+    qm = cls.from_float(prepared(c, modules_golden), split=c.get("split", 0),
+                        ckpt=module_ckpt(c, modules_golden))
+    with torch.no_grad():
+        y = qm(module_input(c))
+    want = modules_golden[f"{c['key']}.out"]
+    assert tuple(y.shape) == want.shape
+    assert np.array_equal(y.contiguous().numpy().view(np.uint16), want.view(np.uint16))
+
+
+def test_bos_forward_batch2_uses_strided_semantics(modules_golden, oracle_ops):
+    """At batch > 1 the reference quantizes x[:,1:,:] linearly (wrong tokens); this build uses the
+    slice's strides: each batch element equals its own batch-1 result."""
+    from mixdq_amd.nn import QuantizedLinear
+    c = next(c for c in MODULE_CASES if c["key"] == "lin_bos")
+    qm = QuantizedLinear.from_float(prepared(c, modules_golden), ckpt=module_ckpt(c, modules_golden))
+    x = module_input(c)
+    x2 = torch.cat([x, x.flip(1)], dim=0)
+    with torch.no_grad():
+        y2 = qm(x2)
+        y_a, y_b = qm(x), qm(x.flip(1))
+    assert torch.equal(y2[0], y_a[0]) and torch.equal(y2[1], y_b[0])
+    assert torch.equal(y2[:, 0], qm.bos_pre_computed.expand(2, -1, -1)[:, 0])
+
+
+@pytest.mark.parametrize("c", MODULE_CASES[:1] + MODULE_CASES[3:4], ids=["linear", "conv"])
+def test_fallback_rules(modules_golden, c):
+    """4-/2-bit weights, missing a_bit and misaligned sizes fall back to FP16 F.linear / F.conv2d
+    on the un-quantized weight (nn/Linear.py:31,37-43,133-134,155-156)."""
+    from mixdq_amd.nn import QuantizedConv2d, QuantizedLinear
+    cls = QuantizedLinear if c["kind"] == "linear" else QuantizedConv2d
+    ck = module_ckpt(c, modules_golden)
+    for kw in (dict(w_bit=4), dict(w_bit=2), dict(with_act=False)):
+        qm = cls.from_float(prepared(c, modules_golden, **kw), ckpt=ck)
+        assert not qm.valid_for_acceleration
+        assert "weight" in dict(qm.named_buffers()) and "weight_int" not in dict(qm.named_buffers())
+        assert "Fallback" in qm._get_name()
+        x = module_input(c).float()
+        qm = qm.float()
+        ref = make_float_module(c).half().float()
+        with torch.no_grad():
+            torch.testing.assert_close(qm(x), ref(x))
+
+
+def test_misaligned_linear_falls_back():
+    from mixdq_amd.nn import QuantizedLinear
+    from mixdq_amd.nn.utils import QParam
+    w = QParam(torch.per_channel_affine, torch.qint8, torch.ones(6), torch.zeros(6), 0)
+    a = QParam(torch.per_tensor_affine, torch.qint8, torch.tensor(0.1), torch.tensor(3.0), 0)
+    assert QuantizedLinear(8, 6, w_qparams=w, a_qparams=a).valid_for_acceleration is False
+    assert QuantizedLinear(8, 8, w_qparams=QParam(torch.per_channel_affine, torch.qint8,
+                                                  torch.ones(8), torch.zeros(8), 0),
+                           a_qparams=a).valid_for_acceleration is True
+    wz = QParam(torch.per_channel_affine, torch.qint8, torch.ones(8), torch.ones(8), 0)
+    assert QuantizedLinear(8, 8, w_qparams=wz, a_qparams=a).valid_for_acceleration is False
+
+
+def test_get_quant_para_and_uint4_helpers():
+    from mixdq_amd.nn.utils import (get_quant_para, quantize_per_tensor_uint4, unpack_uint4,
+                                    dequantize_per_tensor_uint4, bit_index)
+    assert [bit_index(b) for b in (2, 4, 8)] == [0, 1, 2]
+    ck = {"l.weight_quantizer": dict(delta_list=torch.arange(6.).reshape(3, 2),
+                                     zero_point_list=torch.zeros(3, 2)),
+          "l.act_quantizer": dict(delta_list=torch.tensor([.4, .2, .1]),
+                                  zero_point_list=torch.tensor([1., 7., 130.])),
+          "l.weight_quantizer_0": dict(delta_list=torch.ones(3, 2), zero_point_list=torch.zeros(3, 2)),
+          "l.act_quantizer_0": dict(delta_list=torch.tensor([.4, .2, .3]),
+                                    zero_point_list=torch.tensor([1., 7., 128.]))}
+    s, z, s0, z0 = get_quant_para(ck, 8, "l", "act")
+    assert float(s) == pytest.approx(0.1) and float(z) == 2.0 and s0 is None   # 130 - 128
+    s, z, s0, z0 = get_quant_para(ck, 4, "l", "weight", split=3)
+    assert s.tolist() == [2., 3.] and s0.tolist() == [1., 1.]
+    s, z, s0, z0 = get_quant_para(ck, 8, "l", "act", split=3)
+    assert float(z0) == 0.0
+    with pytest.raises(AssertionError):
+        get_quant_para(ck, 8, "missing", "act")
+    x = torch.tensor([[0.0, 1.0, 2.0, 15.0], [7.0, 8.0, 3.0, 20.0]])
+    packed = quantize_per_tensor_uint4(x, torch.tensor([1.0, 1.0]), torch.tensor([0.0, 0.0]))
+    assert packed.tolist() == [[0x01, 0x2F], [0x78, 0x3F]]       # high nibble = even index
+    assert unpack_uint4(packed).tolist() == [[0, 1, 2, 15], [7, 8, 3, 15]]
+    assert dequantize_per_tensor_uint4(packed, torch.tensor([2.0, 1.0]), torch.tensor([1.0, 0.0])
+                                       )[0].tolist() == [-2.0, 0.0, 2.0, 28.0]
+
+
+# ---------------------------------------------------------------------------- tiny UNet swaps
+TINY = dict(block_out_channels=(32, 64, 128), transformer_layers_per_block=(0, 1, 2),
+            mid_transformer_layers=1, head_dim=16, cross_attention_dim=64, time_embed_dim=128,
+            addition_time_embed_dim=16, projection_class_embeddings_input_dim=96 + 32,
+            norm_num_groups=8)
+
+
+def tiny_unet():
+    from mixdq_amd.unet import SDXLUNet, init_synthetic_weights
+    return init_synthetic_weights(SDXLUNet(TINY)).eval()
+
+
+def tiny_inputs(B=1, L=8):
+    g = torch.Generator().manual_seed(0)
+    return dict(sample=torch.rand(B, 4, L, L, generator=g), timestep=torch.tensor(999.),
+                encoder_hidden_states=torch.rand(B, 77, 64, generator=g),
+                added_cond_kwargs=dict(time_ids=torch.tensor([[64., 64, 0, 0, 64, 64]] * B),
+                                       text_embeds=torch.rand(B, 32, generator=g)))
+
+
+def test_unet_inventory_matches_packed_configs():
+    from mixdq_amd import cfgs
+    names = cfgs.layer_names()   # asserts the sha of the 794 names
+    assert len(names) == 794
+    w8, a8 = cfgs.load("weight/uniform_8"), cfgs.load("act/act_8.00")
+    assert len(w8) == 794 and set(w8.values()) == {8}
+    assert len(a8) == 785
+    assert sorted(set(w8) - set(a8)) == [
+        "conv_in", "conv_out", "down_blocks.0.resnets.0.conv2",
+        "down_blocks.2.attentions.1.transformer_blocks.5.ff.net.2",
+        "down_blocks.2.attentions.1.transformer_blocks.6.ff.net.2",
+        "down_blocks.2.attentions.1.transformer_blocks.7.ff.net.2",
+        "down_blocks.2.attentions.1.transformer_blocks.8.ff.net.2",
+        "up_blocks.0.attentions.0.transformer_blocks.0.ff.net.2",
+        "up_blocks.2.resnets.2.conv_shortcut"]
+    from collections import Counter
+    assert Counter(cfgs.load("weight/weight_4.00").values()) == {4: 347, 8: 238, 2: 209}
+    assert Counter(cfgs.load("weight/weight_8.00").values()) == {8: 790, 4: 4}
+    assert len(cfgs.bos_shapes()) == 140
+    import torch.nn as nn_
+    from mixdq_amd.unet import SDXLUNet, quantizable_layers
+    with torch.device("meta"):
+        q = quantizable_layers(SDXLUNet())
+    assert sum(isinstance(m, nn_.Linear) for m in q.values()) == 743
+    assert sum(isinstance(m, nn_.Conv2d) for m in q.values()) == 51
+    splits = [m.split for n, m in q.items() if "up_blocks" in n and "conv_shortcut" in n]
+    from mixdq_amd.quantize import SDXL_UP_SHORTCUT_SPLITS
+    assert tuple(splits) == SDXL_UP_SHORTCUT_SPLITS          # quantize.py:61 _SPLIT
+
+
+class Args:
+    def __init__(self, w, a):
+        self.w_config, self.a_config = w, a
+
+
+def tiny_quantized(oracle_ops=None, a_drop=()):
+    from mixdq_amd.calib import calibrate, precompute_bos
+    from mixdq_amd.quantize_sdxl import quantize_unet
+    from mixdq_amd.unet import quantizable_layers
+    unet = tiny_unet()
+    inp = tiny_inputs()
+    with torch.no_grad():
+        ref_out = unet(**inp)[0]
+    ckpt = calibrate(unet, [inp])
+    bos = precompute_bos(unet.half(), inp["encoder_hidden_states"].half())
+    names = list(quantizable_layers(unet))
+    w_cfg = {"model." + n: 8 for n in names}
+    a_cfg = {"model." + n: 8 for n in names if n not in a_drop}
+    quantize_unet(unet, Args(w_cfg, a_cfg), ckpt, bos=True, bos_dict=bos)
+    return unet, inp, ref_out, ckpt
+
+
+def test_quantize_unet_swaps_every_layer_and_is_repeatable():
+    from mixdq_amd.nn import QuantizedConv2d, QuantizedLinear
+    for _ in range(2):   # the reference raises IndexError on a second convert (global _NUM)
+        unet, inp, ref_out, ckpt = tiny_quantized(a_drop=("conv_in", "conv_out"))
+        kinds = [type(m) for m in unet.modules()]
+        assert nn.Linear not in kinds and nn.Conv2d not in kinds
+        q = [m for m in unet.modules() if isinstance(m, (QuantizedLinear, QuantizedConv2d))]
+        assert len(q) == sum(k.endswith(".act_quantizer") for k in ckpt)
+        assert not unet.conv_in.valid_for_acceleration        # no a_bit => FP fallback
+        assert unet.down_blocks[1].resnets[0].conv1.valid_for_acceleration
+        sc = unet.up_blocks[0].resnets[0].conv_shortcut
+        assert sc.split == 128 and hasattr(sc, "weight_int_0") and hasattr(sc, "act_scales_0")
+        k = unet.down_blocks[1].attentions[0].transformer_blocks[0].attn2.to_k
+        assert k.bos is True and k.bos_pre_computed.shape == (1, 1, 64)
+        assert not any(hasattr(m, "qconfig") for m in unet.modules())
+
+
+def test_register_qconfig_rejects_unknown_keys():
+    from mixdq_amd.quantize_sdxl import register_qconfig_from_input_files
+    unet = tiny_unet()
+    with pytest.raises(RuntimeError, match="weight yaml"):
+        register_qconfig_from_input_files(unet, Args({"model.nope.layer": 8}, None), False, {})
+    unet = tiny_unet()
+    with pytest.raises(RuntimeError, match="act yaml"):
+        register_qconfig_from_input_files(unet, Args({"model.conv_in": 8}, {"model.nope": 8}),
+                                          False, {})
+
+
+def test_quantized_tiny_unet_tracks_fp_on_cpu(oracle_ops):
+    """End to end on CPU with oracle-backed ops (test-only): the W8A8 tiny UNet stays close to
+    the FP32 one, i.e. scales, zero points, BOS and split plumbing are consistent."""
+    unet, inp, ref_out, _ = tiny_quantized()
+    half_inp = dict(sample=inp["sample"].half(), timestep=inp["timestep"],
+                    encoder_hidden_states=inp["encoder_hidden_states"].half(),
+                    added_cond_kwargs={k: v.half() for k, v in inp["added_cond_kwargs"].items()})
+    unet = unet.half()
+    with torch.no_grad():
+        out = unet(**half_inp)[0].float()
+    err = (out - ref_out).abs().max().item()
+    assert err < 0.05 * ref_out.abs().max().item() + 0.02, err
+
+
+def test_calibration_checkpoint_schema():
+    from mixdq_amd.calib import calibrate
+    unet = tiny_unet()
+    ckpt = calibrate(unet, [tiny_inputs(), tiny_inputs(B=2)])
+    e = ckpt["conv_in.weight_quantizer"]
+    assert e["delta_list"].shape == (3, 32) and e["delta_list"].dtype == torch.float16
+    assert torch.all(e["zero_point_list"] == 0)
+    a = ckpt["conv_in.act_quantizer"]
+    assert a["delta_list"].shape == (3,) and a["zero_point_list"].dtype == torch.float16
+    assert 0 <= float(a["zero_point_list"][2]) <= 255
+    assert "up_blocks.0.resnets.0.conv_shortcut.act_quantizer_0" in ckpt
+    assert "up_blocks.0.resnets.0.conv_shortcut.weight_quantizer_0" in ckpt
+    assert ckpt["up_blocks.0.resnets.0.conv_shortcut.weight_quantizer"]["delta_list"].shape == (3, 128)
+    # 8-bit step = absmax / 127 of each output channel
+    w = unet.conv_in.weight.detach().reshape(32, -1)
+    assert torch.equal(e["delta_list"][2], (w.abs().max(dim=1)[0] / 127).half())

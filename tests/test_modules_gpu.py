@@ -1,0 +1,143 @@
+"""GPU parity tests at module level: QuantizedLinear / QuantizedConv2d (incl. BOS and split)
+through the HIP kernels vs the outputs of the REFERENCE's classes (modules.npz, bit-exact) and
+vs the reference's Path A fake-quant simulation (fakequant.npz, the reference's 1e-2 tolerance);
+module swap + hipGraph capture of a small UNet."""
+import numpy as np
+import pytest
+import torch
+
+from tests.cases import MODULE_CASES, module_ckpt, module_input
+from tests.test_host import prepared, tiny_inputs, TINY, Args
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def build(c, golden):
+    from mixdq_amd.nn import QuantizedConv2d, QuantizedLinear
+    cls = QuantizedLinear if c["kind"] == "linear" else QuantizedConv2d
+    qm = cls.from_float(prepared(c, golden), split=c.get("split", 0), ckpt=module_ckpt(c, golden))
+    return qm.to(DEV)
+
+
+@pytest.mark.parametrize("c", MODULE_CASES, ids=[c["key"] for c in MODULE_CASES])
+def test_module_forward_bit_exact_vs_reference_classes(C, modules_golden, c):
+    qm = build(c, modules_golden)
+    assert qm.valid_for_acceleration
+    x = module_input(c).to(DEV)
+    if c["kind"] == "conv":
+        x = x.contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        y = qm(x)
+    want = modules_golden[f"{c['key']}.out"]
+    got = y.contiguous().cpu().numpy()
+    assert got.shape == want.shape and y.dtype == torch.float16
+    assert np.array_equal(got.view(np.uint16), want.view(np.uint16)), \
+        f"{(got.view(np.uint16) != want.view(np.uint16)).sum()} of {got.size} differ"
+    if c["kind"] == "conv":
+        assert y.is_contiguous(memory_format=torch.channels_last)
+
+
+@pytest.mark.parametrize("c", [c for c in MODULE_CASES if c["kind"] == "conv"],
+                         ids=[c["key"] for c in MODULE_CASES if c["kind"] == "conv"])
+def test_conv_module_accepts_nchw_input(C, modules_golden, c):
+    """NCHW-contiguous activations (what the reference's UNet feeds) give the same result."""
+    qm = build(c, modules_golden)
+    with torch.no_grad():
+        y = qm(module_input(c).to(DEV).contiguous())
+    want = modules_golden[f"{c['key']}.out"]
+    assert np.array_equal(y.contiguous().cpu().numpy().view(np.uint16), want.view(np.uint16))
+
+
+@pytest.mark.parametrize("c", MODULE_CASES, ids=[c["key"] for c in MODULE_CASES])
+def test_module_within_reference_tolerance_of_fake_quant(C, modules_golden, fakequant_golden, c):
+    """INT8 kernels vs the qdiff simulation: rtol = atol = 1e-2 (op/qlinear.py:101,
+    op/qconv2d.py:100)."""
+    qm = build(c, modules_golden)
+    with torch.no_grad():
+        y = qm(module_input(c).to(DEV)).float().cpu()
+    ref = torch.from_numpy(fakequant_golden[f"{c['key']}.pathA_w8a8"])
+    if c.get("bos"):     # the simulation has no layer-level BOS splice: compare tokens 1..
+        y, ref = y[:, 1:], ref[:, 1:]
+    torch.testing.assert_close(y, ref, rtol=1e-2, atol=1e-2)
+
+
+def test_bos_batch2(C, modules_golden):
+    c = next(c for c in MODULE_CASES if c["key"] == "lin_bos")
+    qm = build(c, modules_golden)
+    x = module_input(c).to(DEV)
+    x2 = torch.cat([x, x.flip(1)], dim=0)
+    with torch.no_grad():
+        y2, ya, yb = qm(x2), qm(x), qm(x.flip(1))
+    assert torch.equal(y2[0], ya[0]) and torch.equal(y2[1], yb[0])
+    assert torch.equal(y2[:, 0], qm.bos_pre_computed.expand(2, -1, -1)[:, 0])
+
+
+def test_split_shortcut_batch2_channels_last_and_nchw(C, modules_golden):
+    c = next(c for c in MODULE_CASES if c["key"] == "conv_split")
+    qm = build(c, modules_golden)
+    x = module_input(c).to(DEV)
+    x2 = torch.cat([x, x.flip(2)], dim=0)
+    with torch.no_grad():
+        y_nchw = qm(x2.contiguous())
+        y_cl = qm(x2.contiguous(memory_format=torch.channels_last))
+        y1 = qm(x)
+    assert torch.equal(y_nchw, y_cl)
+    assert torch.equal(y_nchw[:1], y1)
+
+
+def test_non_fp16_input_uses_dequantised_weight_fallback(C, modules_golden):
+    c = MODULE_CASES[0]
+    qm = build(c, modules_golden)
+    x = module_input(c).to(DEV).float()
+    with torch.no_grad():
+        y = qm(x)
+    w = qm.weight_int.float() * qm.weight_scales[:, None]
+    torch.testing.assert_close(y, torch.nn.functional.linear(x, w, qm.bias.float()))
+
+
+def _tiny_quantized_gpu():
+    from mixdq_amd.calib import calibrate, precompute_bos
+    from mixdq_amd.quantize_sdxl import quantize_unet
+    from mixdq_amd.unet import build_unet, quantizable_layers
+    unet = build_unet(DEV, cfg=TINY)
+    inp = tiny_inputs(B=2, L=16)
+    inp = dict(sample=inp["sample"].half().to(DEV), timestep=inp["timestep"].to(DEV),
+               encoder_hidden_states=inp["encoder_hidden_states"].half().to(DEV),
+               added_cond_kwargs={k: v.half().to(DEV) for k, v in inp["added_cond_kwargs"].items()})
+    with torch.no_grad():
+        ref = unet(**inp)[0].float()
+    ckpt = calibrate(unet, [inp])
+    bos = precompute_bos(unet, inp["encoder_hidden_states"])
+    names = list(quantizable_layers(unet))
+    quantize_unet(unet, Args({"model." + n: 8 for n in names}, {"model." + n: 8 for n in names}),
+                  ckpt, bos=True, bos_dict=bos)
+    return unet, inp, ref
+
+
+def test_quantized_unet_runs_on_hip_kernels_and_tracks_fp16(C):
+    from mixdq_amd.nn import QuantizedConv2d, QuantizedLinear
+    unet, inp, ref = _tiny_quantized_gpu()
+    q = [m for m in unet.modules() if isinstance(m, (QuantizedLinear, QuantizedConv2d))]
+    assert q and all(m.valid_for_acceleration for m in q)
+    with torch.no_grad():
+        out = unet(**inp)[0].float()
+    assert torch.isfinite(out).all()
+    err = (out - ref).abs().max().item()
+    assert err < 0.05 * ref.abs().max().item() + 0.02, err
+
+
+def test_quantized_unet_hip_graph_replay_is_bit_identical(C):
+    from mixdq_amd.quantize_sdxl import hip_graph_opt
+    unet, inp, _ = _tiny_quantized_gpu()
+    with torch.no_grad():
+        eager = unet(**inp)[0].clone()
+    hip_graph_opt(unet)
+    with torch.no_grad():
+        g1 = unet(**inp)[0].clone()
+        inp2 = dict(inp, sample=inp["sample"].flip(0).contiguous())
+        g2 = unet(**inp2)[0].clone()
+        eager2 = unet.forward.__wrapped__(**inp2)[0]
+    assert torch.equal(eager, g1)
+    assert torch.equal(eager2, g2)
+    assert len(unet.forward._cached) == 1

@@ -71,17 +71,20 @@ def test_quantize_edges(C, ops_golden, ops_small, name):
 
 
 def test_quantize_fma_separator(C, oracle, ops_golden, ops_small):
-    """Inputs where fma(x, s, zp) and (x*s)+zp round differently: the default build is variant A."""
+    """(x, s_inv, zp) triples where fma(x, s, zp) and (x*s)+zp round differently: the HIP build
+    follows the selected variant (default A = fused)."""
     case = next(c for c in ops_golden["quantize"] if c["name"] == "q_sep")
-    x = ops_small[case["x"]]
-    q = C.quantize_per_tensor_to_int8(t(x), scal(case["scale_inv"]), scal(case["zp"]))
+    x, si, zp = ops_small[case["x"]], ops_small[case["scale_inv"]], ops_small[case["zp"]]
     want = ops_small[case["expect_B" if C.FLAGS & 1 else "expect_A"]]
-    assert_bits_equal(q.cpu().numpy(), want, "q_sep")
-    # every finite half value, both signs
-    allh = np.arange(0, 0x7c00, dtype=np.uint16).view(np.float16)
+    for i in range(x.size):
+        q = C.quantize_per_tensor_to_int8(t(x[i:i + 1]), scal(si[i]), scal(zp[i]))
+        assert int(q.item()) == int(want[i]), (i, x[i], si[i], zp[i])
+    # every finite half value, both signs, one realistic scale
+    case = next(c for c in ops_golden["quantize"] if c["name"] == "q_allhalf")
+    allh = np.arange(1, 0x7c00, dtype=np.uint16).view(np.float16)
     allh = np.concatenate([allh, -allh])
     q = C.quantize_per_tensor_to_int8(t(allh), scal(case["scale_inv"]), scal(case["zp"]))
-    assert sha(q.cpu().numpy()) == case["sha_all_B" if C.FLAGS & 1 else "sha_all_A"]
+    assert sha(q.cpu().numpy()) == case["sha_B" if C.FLAGS & 1 else "sha_A"]
 
 
 def test_quantize_strided_bos_slice(C, ops_golden, ops_small):
