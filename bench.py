@@ -1,0 +1,328 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: one SDXL-Turbo UNet forward ("step") with every yaml-listed Linear /
+Conv2d running  quantize (HIP) -> INT8 GEMM / implicit-GEMM conv + epilogue (HIP), synthetic
+inputs resident in HBM, captured in a hipGraph (the reference measures with CUDA graphs too:
+kernels/README.md:94, quantize_sdxl.py:184-286).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+N = 1 workload: BASELINE.json configs[1] -- W8A8 SDXL-Turbo UNet, 1024x1024 (latent 128), batch 1,
+1 step, one MI355X.  N > 1: weak scaling, the same per-GPU batch on every rank (batch-sharded
+replicas, rank 0's quantized weights broadcast once over RCCL, no collective in the step loop).
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline      dominant kernel (an igemm_kernel<BM,BN,BK,CONV> instantiation): algorithmic int8
+                ops of its launches / their summed duration, each launch bracketed by HIP events
+                on the launch stream, vs the dense INT8 MFMA peak (MI355X_MICROARCH.md);
+  cpu_baseline  the reference's CPU-runnable path (qdiff fake-quant, Path A) restated in
+                oracle/fakequant.py, timed on this box's host cores on a bounded sample;
+  fp16          the same UNet graph with nn.Linear / nn.Conv2d in FP16 on the same GPU.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.nn as nn  # noqa: E402
+
+INT8_MFMA_PEAK_TOPS = 5000.0   # dense, ~2x the 2.5 PF bf16 figure (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1, help="UNet batch per GPU")
+    ap.add_argument("--px", type=int, default=1024, choices=[512, 1024])
+    ap.add_argument("--w-config", default="weight/uniform_8")
+    ap.add_argument("--a-config", default="act/act_8.00")
+    ap.add_argument("--no-bos", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches (host-bound)")
+    ap.add_argument("--no-fp16", action="store_true", help="skip the FP16 comparison")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--sweep-reps", type=int, default=3)
+    return ap.parse_args()
+
+
+class Cfg:
+    def __init__(self, w, a):
+        self.w_config, self.a_config = w, a
+
+
+def time_steps(fn, steps, warmup, device):
+    """W untimed steps, then exactly K steps between barrier + synchronize; max over ranks."""
+    from mixdq_amd import shard
+    with torch.no_grad():
+        for _ in range(warmup):
+            fn()
+        torch.cuda.synchronize(device)
+        shard.barrier()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize(device)
+        shard.barrier()
+        dt = time.perf_counter() - t0
+    return shard.max_over_ranks(dt, device)
+
+
+def layer_shapes(unet, inputs):
+    """Input shape of every quantizable layer for these inputs (forward pre-hooks)."""
+    from mixdq_amd.unet import quantizable_layers
+    shapes, hooks = {}, []
+    for name, mod in quantizable_layers(unet).items():
+        hooks.append(mod.register_forward_pre_hook(
+            lambda m, a, name=name: shapes.__setitem__(name, tuple(a[0].shape))))
+    with torch.no_grad():
+        unet(**inputs)
+    for h in hooks:
+        h.remove()
+    return shapes
+
+
+def layer_work(mod, in_shape):
+    """(M, N, K) of the GEMM a layer maps to."""
+    if isinstance(mod, nn.Linear) or hasattr(mod, "in_features"):
+        K, N = mod.in_features, mod.out_features
+        M = 1
+        for d in in_shape[:-1]:
+            M *= d
+        return M, N, K
+    B, C, H, W = in_shape
+    R, S = mod.kernel_size
+    P = (H + 2 * mod.padding[0] - R) // mod.stride[0] + 1
+    Q = (W + 2 * mod.padding[1] - S) // mod.stride[1] + 1
+    return B * P * Q, mod.out_channels, R * S * C
+
+
+def roofline_sweep(unet, shapes, device, reps):
+    """Launch only the INT8 GEMM / conv kernels of one UNet forward, layer by layer in model
+    order, on pre-quantized random inputs; every launch is bracketed by its own HIP event pair on
+    the launch stream.  Returns per-kernel-instantiation totals."""
+    import mixdq_amd._C as C
+    from mixdq_amd.nn import QuantizedConv2d, QuantizedLinear
+    calls = []   # (kernel name, ops, callable)
+    g = torch.Generator(device="cpu").manual_seed(7)
+
+    def rnd(shape):
+        return torch.randint(-128, 128, shape, generator=g, dtype=torch.int8).to(device)
+
+    for name, mod in unet.named_modules():
+        if not isinstance(mod, (QuantizedLinear, QuantizedConv2d)) or not mod.valid_for_acceleration:
+            continue
+        shp = shapes[name]
+        if isinstance(mod, QuantizedLinear):
+            if getattr(mod, "bos", False):
+                shp = (shp[0], shp[1] - 1, shp[2])
+            x = rnd(shp)
+            M, N, K = layer_work(mod, shp)
+            bm, bn, bk = C.igemm_select(M, N, K)
+            calls.append((f"igemm_kernel<{bm},{bn},{bk},linear>", 2.0 * M * N * K,
+                          lambda mod=mod, x=x: mod._gemm(x)))
+        else:
+            halves = [("", shp[1])] if mod.split == 0 else [("", mod.split), ("_0", shp[1] - mod.split)]
+            for sfx, cin in halves:
+                x = rnd((shp[0], cin, shp[2], shp[3])).contiguous(memory_format=torch.channels_last)
+                R, S = mod.kernel_size
+                P = (shp[2] + 2 * mod.padding[0] - R) // mod.stride[0] + 1
+                Q = (shp[3] + 2 * mod.padding[0] - S) // mod.stride[0] + 1
+                M, N, K = shp[0] * P * Q, mod.out_channels, R * S * cin
+                bm, bn, bk = C.igemm_select(M, N, cin)
+                calls.append((f"igemm_kernel<{bm},{bn},{bk},conv>", 2.0 * M * N * K,
+                              lambda mod=mod, x=x, sfx=sfx: mod._conv(x, sfx, None)))
+    stats = {}
+    with torch.no_grad():
+        for rep in range(reps + 1):
+            evs = []
+            for kname, ops, fn in calls:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fn()
+                e1.record()
+                evs.append((kname, ops, e0, e1))
+            torch.cuda.synchronize(device)
+            if rep == 0:
+                continue   # warm-up sweep
+            for kname, ops, e0, e1 in evs:
+                s = stats.setdefault(kname, dict(ms=0.0, ops=0.0, launches=0))
+                s["ms"] += e0.elapsed_time(e1)
+                s["ops"] += ops
+                s["launches"] += 1
+    return stats
+
+
+def cpu_fake_quant_baseline(seconds_budget):
+    """Path A (qdiff fake-quant) of the 794-layer inventory at 512 px, batch 1, FP32 on the host
+    cores: every 8th layer in inventory order (neighbouring layers are alike), extrapolated x8."""
+    from oracle.fakequant import quant_layer_forward
+    from mixdq_amd.calib import ActRange, weight_delta
+    from mixdq_amd.quantize_sdxl import example_inputs
+    from mixdq_amd.unet import SDXLUNet, quantizable_layers
+    with torch.device("meta"):
+        unet = SDXLUNet().half()
+        inp = example_inputs(1, 64, "meta")
+    shapes = layer_shapes(unet, inp)
+    layers = list(quantizable_layers(unet).items())
+    stride = 8
+    t_total, n_done, macs_done, macs_all = 0.0, 0, 0.0, 0.0
+    for name, mod in layers:
+        M, N, K = layer_work(mod, shapes[name])
+        macs_all += float(M) * N * K
+    torch.manual_seed(0)
+    t_begin = time.perf_counter()
+    for idx in range(0, len(layers), stride):
+        name, mod = layers[idx]
+        shp = shapes[name]
+        x = torch.randn(shp)
+        w = torch.randn(tuple(mod.weight.shape)) * 0.02
+        b = torch.zeros(w.shape[0]) if mod.bias is not None else None
+        rng = ActRange()
+        rng.update(x)
+        a_delta, a_zp = rng.params(2)
+        w_delta = weight_delta(w, 8)
+        kw = None
+        if isinstance(mod, nn.Conv2d):
+            kw = dict(stride=mod.stride, padding=mod.padding, dilation=mod.dilation, groups=1)
+        with torch.no_grad():
+            t0 = time.perf_counter()
+            quant_layer_forward(x, w, b, w_delta, a_delta, a_zp, 8, 8, kw)
+            t_total += time.perf_counter() - t0
+        n_done += 1
+        M, N, K = layer_work(mod, shp)
+        macs_done += float(M) * N * K
+        if time.perf_counter() - t_begin > 4 * seconds_budget:
+            break
+    est_forward_s = t_total * (len(layers) / max(n_done, 1))
+    return dict(value=1.0 / est_forward_s, unit="images/s", cores=torch.get_num_threads(),
+                kind="port", seconds_per_forward_est=est_forward_s,
+                sample=f"qdiff fake-quant (Path A) W8A8 512px bs1 FP32 on CPU: {n_done} of "
+                       f"{len(layers)} layers (every {stride}th in model order, "
+                       f"{100 * macs_done / macs_all:.1f}% of the MACs) in {t_total:.1f} s, "
+                       f"scaled by layer count; host os.cpu_count()={os.cpu_count()}")
+
+
+def main():
+    args = parse_args()
+    from mixdq_amd import shard
+    rank, local_rank, world = shard.init_distributed()
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU fallback)"
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+
+    import mixdq_amd._C as C
+    from mixdq_amd import cfgs
+    from mixdq_amd.calib import calibrate, precompute_bos
+    from mixdq_amd.nn import QuantizedConv2d, QuantizedLinear
+    from mixdq_amd.quantize_sdxl import example_inputs, hip_graph_opt, quantize_unet
+    from mixdq_amd.unet import build_unet
+
+    L = args.px // 8
+    B = args.batch
+    t_setup = time.perf_counter()
+    unet = build_unet(device)
+    inputs = example_inputs(B, L, device, seed=42 + rank)
+    shapes = layer_shapes(unet, inputs)
+    ckpt = calibrate(unet, [inputs], bos=not args.no_bos)
+    bos_dict = precompute_bos(unet, inputs["encoder_hidden_states"])
+
+    def run_once():
+        return unet(**inputs)[0]
+
+    fp16 = None
+    if not args.no_fp16:
+        if not args.no_graph:
+            hip_graph_opt(unet)
+        dt = time_steps(run_once, args.steps, args.warmup, device)
+        fp16 = dict(ms_per_step=1e3 * dt / args.steps, images_per_s=world * B * args.steps / dt)
+        if not args.no_graph:
+            unet.forward = unet.forward.__wrapped__   # drop the FP16 graph
+
+    quantize_unet(unet, Cfg(cfgs.load(args.w_config), cfgs.load(args.a_config)), ckpt,
+                  bos=not args.no_bos, bos_dict=bos_dict)
+    bcast_bytes = shard.broadcast_module_state(unet, src=0)
+    qmods = [m for m in unet.modules() if isinstance(m, (QuantizedLinear, QuantizedConv2d))]
+    n_accel = sum(m.valid_for_acceleration for m in qmods)
+    torch.cuda.empty_cache()
+    weight_bytes = sum(b.numel() * b.element_size() for b in unet.buffers()) + sum(
+        p.numel() * p.element_size() for p in unet.parameters())
+
+    roof_stats = None
+    if not args.no_roofline and rank == 0:
+        roof_stats = roofline_sweep(unet, shapes, device, args.sweep_reps)
+    shard.barrier()
+
+    if not args.no_graph:
+        hip_graph_opt(unet)
+    setup_s = time.perf_counter() - t_setup
+    dt = time_steps(run_once, args.steps, args.warmup, device)
+    ms = 1e3 * dt / args.steps
+    value = world * B * args.steps / dt
+
+    if rank != 0:
+        return
+    out = {
+        "metric": "sdxl_turbo_unet_w8a8_images_per_sec",
+        "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "int8", "data": "synthetic",
+        "config": {
+            "workload": f"sdxl_turbo_unet_w8a8_{args.px}px_bs{B}_1step",
+            "global_batch": world * B, "per_gpu_batch": B, "px": args.px, "latent": L,
+            "w_config": args.w_config, "a_config": args.a_config, "bos": not args.no_bos,
+            "parallelism": f"dp{world} (batch-sharded replicas, no step-loop collective)",
+            "hip_graph": not args.no_graph,
+            "accelerated_layers": n_accel, "quantizable_layers": len(qmods),
+            "epilogue_variant": "B" if C.FLAGS & 1 else "A",
+        },
+        "unet_step_latency_ms": ms,
+        "weights_mb": weight_bytes / 2 ** 20,
+        "weight_broadcast_bytes": bcast_bytes,
+        "setup_s": setup_s,
+    }
+    if fp16:
+        out["fp16"] = fp16
+        out["speedup_vs_fp16"] = fp16["ms_per_step"] / ms
+    if roof_stats:
+        dom = max(roof_stats, key=lambda k: roof_stats[k]["ms"])
+        s = roof_stats[dom]
+        achieved = s["ops"] / (s["ms"] * 1e-3) / 1e12
+        tot_ops = sum(v["ops"] for v in roof_stats.values())
+        tot_ms = sum(v["ms"] for v in roof_stats.values())
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
+        if os.path.exists(pmc):
+            with open(pmc) as f:
+                traffic = json.load(f).get(dom, {}).get("hbm_bytes_per_launch")
+        out["roofline"] = {
+            "bound": "mfma", "kernel": dom, "achieved": achieved, "peak": INT8_MFMA_PEAK_TOPS,
+            "unit": "TFLOP/s", "frac": achieved / INT8_MFMA_PEAK_TOPS, "traffic": traffic,
+            "launches_per_step": s["launches"] // args.sweep_reps,
+            "avg_launch_us": 1e3 * s["ms"] / s["launches"],
+            "ops_per_launch": s["ops"] / s["launches"],
+            "all_igemm": {"tops": tot_ops / (tot_ms * 1e-3) / 1e12,
+                          "ms_per_step": tot_ms / args.sweep_reps,
+                          "int8_ops_per_step": tot_ops / args.sweep_reps},
+            "per_kernel": {k: {"ms_per_step": v["ms"] / args.sweep_reps,
+                               "launches": v["launches"] // args.sweep_reps,
+                               "tops": v["ops"] / (v["ms"] * 1e-3) / 1e12}
+                           for k, v in sorted(roof_stats.items())},
+        }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_fake_quant_baseline(args.cpu_seconds)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

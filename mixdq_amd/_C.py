@@ -52,7 +52,18 @@ for _n in ("mixdq_quantize_f16_i8", "mixdq_qlinear_w8a8", "mixdq_qlinear_w8a8_ro
            "mixdq_conv_zero_point_propagate", "mixdq_gemm_f16"):
     getattr(_lib, _n).restype = _i32
 
+_lib.mixdq_igemm_select.argtypes = [_i64, _i32, _i32, _vp, _vp, _vp]
+_lib.mixdq_igemm_select.restype = _i32
+
 ABI_VERSION = _lib.mixdq_abi_version()
+
+
+def igemm_select(M: int, N: int, k_align: int):
+    """(BM, BN, BK) of the igemm_kernel instantiation used for this problem; (0,0,0) = generic."""
+    bm, bn, bk = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    _status(_lib.mixdq_igemm_select(M, N, k_align, ctypes.byref(bm), ctypes.byref(bn),
+                                    ctypes.byref(bk)), "igemm_select")
+    return bm.value, bn.value, bk.value
 
 # Rounding variant of the fused multiply-adds (SURVEY.md Appendix B): "A" (default) = FMA,
 # "B" = separate multiply and add.  Read once at import; no other global state.

@@ -426,6 +426,17 @@ int launch_tile(IgemmParams& p, hipStream_t stream) {
   return launch_status();
 }
 
+// Tile choice: the largest tile that still gives the 256 CUs at least ~1 block each.
+inline void select_tile(int64_t M, int N, int& bm, int& bn, int& bk) {
+  auto blocks = [&](int tm, int tn) {
+    return ((M + tm - 1) / tm) * (int64_t)((N + tn - 1) / tn);
+  };
+  bk = 64;
+  if (blocks(128, 128) >= kNumCU) { bm = 128; bn = 128; return; }
+  if (blocks(64, 128) >= kNumCU) { bm = 64; bn = 128; return; }
+  bm = 64; bn = 64;
+}
+
 template <bool CONV>
 int dispatch(IgemmParams& p, hipStream_t stream) {
   if (p.M <= 0 || p.N <= 0) return MIXDQ_OK;
@@ -441,12 +452,10 @@ int dispatch(IgemmParams& p, hipStream_t stream) {
     igemm_generic_kernel<CONV><<<(int)blocks, 256, 0, stream>>>(p);
     return launch_status();
   }
-  // Tile choice: the largest tile that still gives the 256 CUs at least ~1 block each.
-  auto blocks = [&](int bm, int bn) {
-    return ((p.M + bm - 1) / bm) * (int64_t)((p.N + bn - 1) / bn);
-  };
-  if (blocks(128, 128) >= kNumCU) return launch_tile<128, 128, 64, CONV>(p, stream);
-  if (blocks(64, 128) >= kNumCU) return launch_tile<64, 128, 64, CONV>(p, stream);
+  int bm, bn, bk;
+  select_tile(p.M, p.N, bm, bn, bk);
+  if (bm == 128 && bn == 128) return launch_tile<128, 128, 64, CONV>(p, stream);
+  if (bm == 64 && bn == 128) return launch_tile<64, 128, 64, CONV>(p, stream);
   return launch_tile<64, 64, 64, CONV>(p, stream);
 }
 
@@ -582,3 +591,11 @@ extern "C" const char* mixdq_status_string(int status) {
 }
 
 extern "C" int mixdq_abi_version(void) { return MIXDQ_ABI_VERSION; }
+
+extern "C" int mixdq_igemm_select(int64_t M, int N, int k_align, int* bm, int* bn, int* bk) {
+  if (!bm || !bn || !bk || M <= 0 || N <= 0) return MIXDQ_ERR_INVALID_ARG;
+  if (k_align % 4 != 0 || N % 4 != 0) return MIXDQ_ERR_ALIGNMENT;
+  if (k_align % 16 != 0) { *bm = *bn = *bk = 0; return MIXDQ_OK; }   // generic kernel
+  select_tile(M, N, *bm, *bn, *bk);
+  return MIXDQ_OK;
+}
