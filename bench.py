@@ -50,7 +50,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--sweep-reps", type=int, default=3)
+    ap.add_argument("--sweep-reps", type=int, default=5)
     return ap.parse_args()
 
 
@@ -107,9 +107,8 @@ def layer_work(mod, in_shape):
 
 
 def roofline_sweep(unet, shapes, device, reps):
-    """Launch only the INT8 GEMM / conv kernels of one UNet forward, layer by layer in model
-    order, on pre-quantized random inputs; every launch is bracketed by its own HIP event pair on
-    the launch stream.  Returns per-kernel-instantiation totals."""
+    """Launch only the INT8 GEMM / conv kernels of one UNet forward on pre-quantized random
+    inputs and time them per kernel instantiation with HIP events.  Returns per-kernel totals."""
     import mixdq_amd._C as C
     from mixdq_amd.nn import QuantizedConv2d, QuantizedLinear
     calls = []   # (kernel name, ops, callable)
@@ -127,8 +126,8 @@ def roofline_sweep(unet, shapes, device, reps):
                 shp = (shp[0], shp[1] - 1, shp[2])
             x = rnd(shp)
             M, N, K = layer_work(mod, shp)
-            bm, bn, bk = C.igemm_select(M, N, K)
-            calls.append((f"igemm_kernel<{bm},{bn},{bk},linear>", 2.0 * M * N * K,
+            bm, bn, bk, st = C.igemm_select(M, N, K)
+            calls.append((f"igemm_kernel<{bm},{bn},{bk},{st},linear>", 2.0 * M * N * K,
                           lambda mod=mod, x=x: mod._gemm(x)))
         else:
             halves = [("", shp[1])] if mod.split == 0 else [("", mod.split), ("_0", shp[1] - mod.split)]
@@ -138,27 +137,38 @@ def roofline_sweep(unet, shapes, device, reps):
                 P = (shp[2] + 2 * mod.padding[0] - R) // mod.stride[0] + 1
                 Q = (shp[3] + 2 * mod.padding[0] - S) // mod.stride[0] + 1
                 M, N, K = shp[0] * P * Q, mod.out_channels, R * S * cin
-                bm, bn, bk = C.igemm_select(M, N, cin)
-                calls.append((f"igemm_kernel<{bm},{bn},{bk},conv>", 2.0 * M * N * K,
+                bm, bn, bk, st = C.igemm_select(M, N, cin)
+                calls.append((f"igemm_kernel<{bm},{bn},{bk},{st},conv>", 2.0 * M * N * K,
                               lambda mod=mod, x=x, sfx=sfx: mod._conv(x, sfx, None)))
+    # Group the launches by kernel instantiation, capture each group (model order) in a hipGraph so
+    # no host gap sits between launches, and bracket `reps` replays with HIP events recorded on
+    # the launch stream (torch's current stream is the stream the kernels are launched on).
+    groups = {}
+    for kname, ops, fn in calls:
+        g_ = groups.setdefault(kname, dict(fns=[], ops=0.0))
+        g_["fns"].append(fn)
+        g_["ops"] += ops
     stats = {}
     with torch.no_grad():
-        for rep in range(reps + 1):
-            evs = []
-            for kname, ops, fn in calls:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
+        for kname, g_ in groups.items():
+            for fn in g_["fns"]:      # warm-up (also builds the cached border tables)
                 fn()
-                e1.record()
-                evs.append((kname, ops, e0, e1))
             torch.cuda.synchronize(device)
-            if rep == 0:
-                continue   # warm-up sweep
-            for kname, ops, e0, e1 in evs:
-                s = stats.setdefault(kname, dict(ms=0.0, ops=0.0, launches=0))
-                s["ms"] += e0.elapsed_time(e1)
-                s["ops"] += ops
-                s["launches"] += 1
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                for fn in g_["fns"]:
+                    fn()
+            graph.replay()
+            torch.cuda.synchronize(device)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                graph.replay()
+            e1.record()
+            torch.cuda.synchronize(device)
+            stats[kname] = dict(ms=e0.elapsed_time(e1), ops=g_["ops"] * reps,
+                                launches=len(g_["fns"]) * reps)
+            del graph
     return stats
 
 

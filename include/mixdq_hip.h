@@ -160,9 +160,10 @@ int mixdq_gemm_f16(const void* A_f16, const void* B_f16_kn, void* D_f16,
 
 /* Which kernel instantiation mixdq_qlinear_w8a8 / mixdq_qconv2d_w8a8 will launch for a problem of
  * M rows x N output channels (k_align = K for Linear, C for Conv2d): the block tile BM x BN x BK
- * of `igemm_kernel<BM,BN,BK,CONV>`, or 0/0/0 for the small-alignment generic kernel.  Host-only
+ * and LDS stage count of `igemm_kernel<BM,BN,BK,STAGES,CONV>`, or zeros for the small-alignment
+ * generic kernel.  Host-only
  * query, used by bench.py to attribute measured time to kernel names.  No reference counterpart. */
-int mixdq_igemm_select(int64_t M, int N, int k_align, int* bm, int* bn, int* bk);
+int mixdq_igemm_select(int64_t M, int N, int k_align, int* bm, int* bn, int* bk, int* stages);
 
 #ifdef __cplusplus
 }

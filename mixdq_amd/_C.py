@@ -52,18 +52,26 @@ for _n in ("mixdq_quantize_f16_i8", "mixdq_qlinear_w8a8", "mixdq_qlinear_w8a8_ro
            "mixdq_conv_zero_point_propagate", "mixdq_gemm_f16"):
     getattr(_lib, _n).restype = _i32
 
-_lib.mixdq_igemm_select.argtypes = [_i64, _i32, _i32, _vp, _vp, _vp]
+_lib.mixdq_igemm_select.argtypes = [_i64, _i32, _i32, _vp, _vp, _vp, _vp]
 _lib.mixdq_igemm_select.restype = _i32
 
 ABI_VERSION = _lib.mixdq_abi_version()
 
 
 def igemm_select(M: int, N: int, k_align: int):
-    """(BM, BN, BK) of the igemm_kernel instantiation used for this problem; (0,0,0) = generic."""
-    bm, bn, bk = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    """(BM, BN, BK, STAGES) of the igemm_kernel instantiation used for this problem; zeros =
+    the generic small-alignment kernel."""
+    bm, bn, bk, st = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
     _status(_lib.mixdq_igemm_select(M, N, k_align, ctypes.byref(bm), ctypes.byref(bn),
-                                    ctypes.byref(bk)), "igemm_select")
-    return bm.value, bn.value, bk.value
+                                    ctypes.byref(bk), ctypes.byref(st)), "igemm_select")
+    return bm.value, bn.value, bk.value, st.value
+
+# Kernel configurations of the INT8 GEMM / conv family (csrc/igemm.hip MIXDQ_IGEMM_CONFIGS):
+# id -> (BM, BN, BK, STAGES).  `_cfg=id` forces one (tuning and tests); 0 = automatic.
+IGEMM_CONFIGS = {1: (64, 64, 64, 2), 2: (64, 128, 64, 2), 3: (128, 128, 64, 2),
+                 4: (64, 64, 128, 3), 5: (64, 64, 128, 4), 6: (64, 128, 128, 3),
+                 7: (128, 128, 128, 3), 8: (128, 128, 64, 4), 9: (64, 64, 64, 4),
+                 10: (128, 64, 128, 3), 11: (64, 128, 128, 4), 12: (128, 128, 128, 4)}
 
 # Rounding variant of the fused multiply-adds (SURVEY.md Appendix B): "A" (default) = FMA,
 # "B" = separate multiply and add.  Read once at import; no other global state.
@@ -136,7 +144,7 @@ def quantize_per_tensor_to_int8_vectorized(input, scale_inv, zero_point):
 
 def qlinear_w8_a8_ohalf(input_int8, weight_int8, weight_scale, input_scale, input_zero_point,
                         weight_sum_by_input_channels, scale, bias0, bias=None, *,
-                        _out=None, _row_map=None):
+                        _out=None, _row_map=None, _cfg=0):
     _check(input_int8.is_cuda, "Input should be on GPU.")
     dev = input_int8.device
     _check(dev == weight_int8.device, "input and weight_int8 should be on the same device.")
@@ -186,7 +194,7 @@ def qlinear_w8_a8_ohalf(input_int8, weight_int8, weight_scale, input_scale, inpu
     with torch.cuda.device(dev):
         code = _lib.mixdq_qlinear_w8a8_rows(a.data_ptr(), w.data_ptr(), b0.data_ptr(),
                                             sc.data_ptr(), _ptr(bs), D.data_ptr(), M, N, K,
-                                            rm[0], rm[1], rm[2], FLAGS, _stream())
+                                            rm[0], rm[1], rm[2], FLAGS | (_cfg << 8), _stream())
     _status(code, "qlinear_w8_a8_ohalf")
     return D
 
@@ -201,7 +209,7 @@ def _conv_geometry(input_int8, weight_int8, stride, padding, dilation):
 
 def qconv2d_w8_a8_ohalf(input_int8, weight_int8, weight_scale, input_scale, input_zero_point,
                         scale, weight_sum_by_input_channels, bias0, bias=None, stride=1,
-                        padding=0, dilation=1, *, _table=None):
+                        padding=0, dilation=1, *, _table=None, _cfg=0):
     stride = 1 if stride is None else int(stride)
     padding = 0 if padding is None else int(padding)
     dilation = 1 if dilation is None else int(dilation)
@@ -263,7 +271,7 @@ def qconv2d_w8_a8_ohalf(input_int8, weight_int8, weight_scale, input_scale, inpu
             code = _lib.mixdq_qconv2d_w8a8(
                 x.data_ptr(), w.data_ptr(), sc.data_ptr(), wsum.contiguous().data_ptr(),
                 input_zero_point.data_ptr(), None, _ptr(bs), D.data_ptr(), workspace.data_ptr(),
-                N, H, W, C, K, R, S, stride, padding, dilation, FLAGS, _stream())
+                N, H, W, C, K, R, S, stride, padding, dilation, FLAGS | (_cfg << 8), _stream())
         else:
             _check(dilation == 1, "qconv2d_w8_a8_ohalf: unsupported configuration "
                                   "(dilation must be 1)")
@@ -271,7 +279,7 @@ def qconv2d_w8_a8_ohalf(input_int8, weight_int8, weight_scale, input_scale, inpu
             code = _lib.mixdq_qconv2d_w8a8_table(
                 x.data_ptr(), w.data_ptr(), sc.data_ptr(), _ptr(_table),
                 input_zero_point.data_ptr(), _ptr(b0), _ptr(bs), D.data_ptr(),
-                N, H, W, C, K, R, S, stride, padding, FLAGS, _stream())
+                N, H, W, C, K, R, S, stride, padding, FLAGS | (_cfg << 8), _stream())
     _status(code, "qconv2d_w8_a8_ohalf")
     return D
 

@@ -57,7 +57,7 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
       (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int BM, int BN, int BK, bool CONV>
+template <int BM, int BN, int BK, int STAGES, bool CONV>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   constexpr int WTM = BM / 2, WTN = BN / 2;       // wave tile (2 x 2 waves)
   constexpr int TM = WTM / 32, TN = WTN / 32;     // 32x32 MFMA tiles per wave
@@ -65,10 +65,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   constexpr int A_NI = A_STAGE / 1024 / 4;        // LDS-DMA instructions per wave per stage
   constexpr int B_NI = B_STAGE / 1024 / 4;
   constexpr int CS_STRIDE = BN * 2 + 16;          // epilogue tile row stride (bytes)
-  constexpr int SMEM = (2 * STAGE > BM * CS_STRIDE) ? 2 * STAGE : BM * CS_STRIDE;
+  constexpr int NI = A_NI + B_NI;                 // ... in total: the unit of the vmcnt count
+  constexpr int PRE = STAGES - 1;                 // K-tiles in flight ahead of the one computed
   static_assert(A_NI >= 1 && B_NI >= 1, "tile too small for 4 waves of 1-KiB DMA pieces");
   static_assert(TM >= 1 && TN >= 1, "wave tile must hold a 32x32 MFMA tile");
-  __shared__ __attribute__((aligned(16))) char smem[SMEM];
+  static_assert(STAGES >= 2 && (PRE - 1) * NI <= 63, "vmcnt is a 6-bit counter");
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // igemm_smem_bytes<...>()
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -190,14 +192,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0;
 
-  // ---- main loop: 2 LDS stages, DMA of tile kt+1 in flight under the MFMAs of tile kt ----------
+  // ---- main loop: STAGES LDS buffers, STAGES-1 K-tiles of LDS-DMA in flight.  Per K-tile ONE
+  //      counted wait (never vmcnt(0)) + ONE raw s_barrier: the wait retires this wave's DMA
+  //      pieces of tile kt, the barrier makes every wave's pieces visible and guarantees that
+  //      buffer (kt-1) % STAGES is no longer read, so tile kt+PRE may be staged into it.
+  //      Tiles past the end of K stage zero-page reads so the count stays uniform.
   const int nk = (Ktot + BK - 1) / BK;
-  stage(0, 0);
+#pragma unroll
+  for (int s = 0; s < PRE; ++s) stage(s, s * BK);
+  int buf_c = 0, buf_s = PRE;   // buffer computed / buffer staged next
   for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < nk) stage((kt + 1) & 1, (kt + 1) * BK);
-    const char* S0 = smem + (kt & 1) * STAGE;
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((PRE - 1) * NI) : "memory");
+    stage(buf_s, (kt + PRE) * BK);
+    const char* S0 = smem + buf_c * STAGE;
 #pragma unroll
     for (int ks = 0; ks < BK / 32; ++ks) {
       v4i af[TM], bf[TN];
@@ -213,7 +220,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         for (int b = 0; b < TM; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[a], af[b], acc[a][b], 0, 0, 0);
     }
+    buf_c = (buf_c + 1 == STAGES) ? 0 : buf_c + 1;
+    buf_s = (buf_s + 1 == STAGES) ? 0 : buf_s + 1;
   }
+  // the zero-page DMAs staged for tiles >= nk are still in flight: drain before LDS is reused
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // ---- epilogue: registers -> f16 tile in LDS -> whole-row 16-byte stores --------------------
   __syncthreads();   // every wave is done reading the stage buffers
@@ -416,29 +427,65 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const __half* __restrict_
   }
 }
 
-template <int BM, int BN, int BK, bool CONV>
+template <int BM, int BN, int BK, int STAGES>
+constexpr int igemm_smem_bytes() {
+  return (STAGES * (BM + BN) * BK > BM * (BN * 2 + 16)) ? STAGES * (BM + BN) * BK
+                                                        : BM * (BN * 2 + 16);
+}
+
+template <int BM, int BN, int BK, int STAGES, bool CONV>
 int launch_tile(IgemmParams& p, hipStream_t stream) {
+  constexpr int SMEM = igemm_smem_bytes<BM, BN, BK, STAGES>();
+  static_assert(SMEM <= 160 * 1024, "LDS is 160 KiB per CU");
+  if constexpr (SMEM > 64 * 1024) {   // opt in to > 64 KiB of dynamic LDS, once per instantiation
+    static const hipError_t attr = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&igemm_kernel<BM, BN, BK, STAGES, CONV>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+    if (attr != hipSuccess) return MIXDQ_ERR_LAUNCH;
+  }
   p.tiles_m = (int)((p.M + BM - 1) / BM);
   p.tiles_n = (p.N + BN - 1) / BN;
   const int64_t grid = (int64_t)p.tiles_m * p.tiles_n;
   if (grid <= 0 || grid > 0x7fffffff) return MIXDQ_ERR_INVALID_ARG;
-  igemm_kernel<BM, BN, BK, CONV><<<(int)grid, 256, 0, stream>>>(p);
+  igemm_kernel<BM, BN, BK, STAGES, CONV><<<(int)grid, 256, SMEM, stream>>>(p);
   return launch_status();
 }
 
-// Tile choice: the largest tile that still gives the 256 CUs at least ~1 block each.
-inline void select_tile(int64_t M, int N, int& bm, int& bn, int& bk) {
+// Kernel configurations.  id 0 = automatic choice; ids 1.. can be forced through bits 8..15 of
+// the `flags` argument of the C entry points (tuning / tests only).
+#define MIXDQ_IGEMM_CONFIGS(X) \
+  X(1, 64, 64, 64, 2)          \
+  X(2, 64, 128, 64, 2)         \
+  X(3, 128, 128, 64, 2)        \
+  X(4, 64, 64, 128, 3)         \
+  X(5, 64, 64, 128, 4)         \
+  X(6, 64, 128, 128, 3)        \
+  X(7, 128, 128, 128, 3)       \
+  X(8, 128, 128, 64, 4)        \
+  X(9, 64, 64, 64, 4)          \
+  X(10, 128, 64, 128, 3)       \
+  X(11, 64, 128, 128, 4)       \
+  X(12, 128, 128, 128, 4)
+
+struct TileCfg { int id, bm, bn, bk, stages; };
+constexpr TileCfg kTileCfgs[] = {
+#define X(ID, BM, BN, BK, ST) {ID, BM, BN, BK, ST},
+    MIXDQ_IGEMM_CONFIGS(X)
+#undef X
+};
+
+// Automatic choice: the largest tile that still gives the 256 CUs at least ~1 block each.
+inline int select_cfg(int64_t M, int N) {
   auto blocks = [&](int tm, int tn) {
     return ((M + tm - 1) / tm) * (int64_t)((N + tn - 1) / tn);
   };
-  bk = 64;
-  if (blocks(128, 128) >= kNumCU) { bm = 128; bn = 128; return; }
-  if (blocks(64, 128) >= kNumCU) { bm = 64; bn = 128; return; }
-  bm = 64; bn = 64;
+  if (blocks(128, 128) >= kNumCU) return 3;    // 128x128x64, 2 stages
+  if (blocks(64, 128) >= kNumCU) return 6;     // 64x128x128, 3 stages
+  return 4;                                    // 64x64x128, 3 stages
 }
 
 template <bool CONV>
-int dispatch(IgemmParams& p, hipStream_t stream) {
+int dispatch(IgemmParams& p, hipStream_t stream, int forced_cfg) {
   if (p.M <= 0 || p.N <= 0) return MIXDQ_OK;
   const int align_k = CONV ? p.C : p.Ktot;
   if (align_k % 4 != 0 || p.N % 4 != 0) return MIXDQ_ERR_ALIGNMENT;
@@ -452,11 +499,14 @@ int dispatch(IgemmParams& p, hipStream_t stream) {
     igemm_generic_kernel<CONV><<<(int)blocks, 256, 0, stream>>>(p);
     return launch_status();
   }
-  int bm, bn, bk;
-  select_tile(p.M, p.N, bm, bn, bk);
-  if (bm == 128 && bn == 128) return launch_tile<128, 128, 64, CONV>(p, stream);
-  if (bm == 64 && bn == 128) return launch_tile<64, 128, 64, CONV>(p, stream);
-  return launch_tile<64, 64, 64, CONV>(p, stream);
+  int cfg = forced_cfg > 0 ? forced_cfg : select_cfg(p.M, p.N);
+  switch (cfg) {
+#define X(ID, BM, BN, BK, ST) \
+  case ID: return launch_tile<BM, BN, BK, ST, CONV>(p, stream);
+    MIXDQ_IGEMM_CONFIGS(X)
+#undef X
+    default: return MIXDQ_ERR_INVALID_ARG;
+  }
 }
 
 }  // namespace
@@ -479,7 +529,7 @@ extern "C" int mixdq_qlinear_w8a8_rows(const int8_t* A, const int8_t* W, const f
   p.H = p.W = p.P = p.Q = 1; p.C = K; p.R = p.S = 1; p.stride = 1; p.pad = 0;
   p.grp_rows = group_rows; p.grp_stride = group_stride; p.grp_off = group_offset;
   p.unfused = (flags & MIXDQ_FLAG_UNFUSED) ? 1 : 0;
-  return dispatch<false>(p, (hipStream_t)stream);
+  return dispatch<false>(p, (hipStream_t)stream, (flags >> 8) & 0xff);
 }
 
 extern "C" int mixdq_qlinear_w8a8(const int8_t* A, const int8_t* W, const float* bias0,
@@ -527,7 +577,7 @@ extern "C" int mixdq_qconv2d_w8a8_table(const int8_t* X, const int8_t* Wt, const
   p.H = H; p.W = W; p.C = C; p.R = R; p.S = S; p.P = P; p.Q = Q; p.stride = stride; p.pad = pad;
   p.grp_rows = 0; p.grp_stride = 0; p.grp_off = 0;
   p.unfused = (flags & MIXDQ_FLAG_UNFUSED) ? 1 : 0;
-  return dispatch<true>(p, (hipStream_t)stream);
+  return dispatch<true>(p, (hipStream_t)stream, (flags >> 8) & 0xff);
 }
 
 extern "C" int mixdq_qconv2d_w8a8(const int8_t* X, const int8_t* Wt, const float* scale,
@@ -592,10 +642,13 @@ extern "C" const char* mixdq_status_string(int status) {
 
 extern "C" int mixdq_abi_version(void) { return MIXDQ_ABI_VERSION; }
 
-extern "C" int mixdq_igemm_select(int64_t M, int N, int k_align, int* bm, int* bn, int* bk) {
-  if (!bm || !bn || !bk || M <= 0 || N <= 0) return MIXDQ_ERR_INVALID_ARG;
+extern "C" int mixdq_igemm_select(int64_t M, int N, int k_align, int* bm, int* bn, int* bk,
+                                  int* stages) {
+  if (!bm || !bn || !bk || !stages || M <= 0 || N <= 0) return MIXDQ_ERR_INVALID_ARG;
   if (k_align % 4 != 0 || N % 4 != 0) return MIXDQ_ERR_ALIGNMENT;
-  if (k_align % 16 != 0) { *bm = *bn = *bk = 0; return MIXDQ_OK; }   // generic kernel
-  select_tile(M, N, *bm, *bn, *bk);
+  if (k_align % 16 != 0) { *bm = *bn = *bk = *stages = 0; return MIXDQ_OK; }   // generic kernel
+  const int cfg = select_cfg(M, N);
+  for (const TileCfg& c : kTileCfgs)
+    if (c.id == cfg) { *bm = c.bm; *bn = c.bn; *bk = c.bk; *stages = c.stages; }
   return MIXDQ_OK;
 }
