@@ -158,6 +158,41 @@ int mixdq_conv_zero_point_propagate(const float* wsum_krs, const float* zero_poi
 int mixdq_gemm_f16(const void* A_f16, const void* B_f16_kn, void* D_f16,
                    int64_t M, int N, int K, mixdq_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Producer fusions (no reference counterpart: the reference runs stock
+ * PyTorch FP16 ops followed by its quantize kernel).  Each keeps the rounding points of the unfused
+ * sequence -- normalised value -> FP16, SiLU / GELU -> FP16, product -> FP16 -- and then applies the
+ * a1 quantizer to that FP16 value.  Reduction orders are fixed and the transcendental steps are
+ * include/mixdq_math.h, so the oracle reproduces them bit-for-bit.
+ *
+ * GroupNorm (+SiLU) + quantize on an NHWC tensor x [N, HW, C] (fp16), G groups, gamma/beta fp16 [C].
+ * Writes int8 [N, HW, C] (if out_q != null) and/or the fp16 activation (if out_f16 != null).
+ * Needs C % 8 == 0 and groups that an 8-channel run straddles at most once
+ * (MIXDQ_ERR_UNSUPPORTED otherwise).  `workspace`: mixdq_groupnorm_workspace_bytes() bytes. */
+size_t mixdq_groupnorm_workspace_bytes(int N, int64_t HW, int C, int G);
+int mixdq_groupnorm_silu_quantize(const void* x_nhwc_f16, const void* gamma_f16,
+                                  const void* beta_f16, float eps, int apply_silu,
+                                  const float* scale_inv, const float* zero_point,
+                                  int8_t* out_q_or_null, void* out_f16_or_null, void* workspace,
+                                  int N, int64_t HW, int C, int G, int flags,
+                                  mixdq_stream_t stream);
+
+/* LayerNorm over the last dimension of x [M, C] (fp16) + up to three quantizers of the same
+ * normalised FP16 value (to_q / to_k / to_v have their own activation scales).  HOST arrays of
+ * n_out device pointers.  C % 8 == 0, C <= 2048. */
+int mixdq_layernorm_quantize(const void* x_f16, const void* gamma_f16, const void* beta_f16,
+                             float eps, int64_t M, int C, int n_out,
+                             const float* const* scale_inv, const float* const* zero_point,
+                             int8_t* const* out_q, void* out_f16_or_null, int flags,
+                             mixdq_stream_t stream);
+
+/* GEGLU + quantize: h [M, 2D] fp16 (ff.net.0.proj output) -> fp16(h[:, :D] * fp16(gelu(h[:, D:])))
+ * -> int8 [M, D] and/or fp16 [M, D].  D % 8 == 0. */
+int mixdq_geglu_quantize(const void* h_f16, int64_t M, int D,
+                         const float* scale_inv, const float* zero_point,
+                         int8_t* out_q_or_null, void* out_f16_or_null, int flags,
+                         mixdq_stream_t stream);
+
 /* Which kernel instantiation mixdq_qlinear_w8a8 / mixdq_qconv2d_w8a8 will launch for a problem of
  * M rows x N output channels (k_align = K for Linear, C for Conv2d): the block tile BM x BN x BK
  * and LDS stage count of `igemm_kernel<BM,BN,BK,STAGES,CONV>`, or zeros for the small-alignment

@@ -334,3 +334,95 @@ def qlinear_fp_reference(input, weight, bias=None):
         code = _lib.mixdq_gemm_f16(a.data_ptr(), b.data_ptr(), D.data_ptr(), M, N, K, _stream())
     _status(code, "qlinear_fp_reference")
     return D
+
+
+# ---------------------------------------------------------------------------------------------
+# Producer fusions (include/mixdq_hip.h, csrc/fused_norm.hip).  Not part of the reference's `_C`:
+# used by mixdq_amd.unet's fused forward.  Same no-fallback rule: GPU tensors only.
+# ---------------------------------------------------------------------------------------------
+_lib.mixdq_groupnorm_workspace_bytes.restype = _sz
+_lib.mixdq_groupnorm_workspace_bytes.argtypes = [_i32, _i64, _i32, _i32]
+_lib.mixdq_groupnorm_silu_quantize.restype = _i32
+_lib.mixdq_groupnorm_silu_quantize.argtypes = [_vp, _vp, _vp, ctypes.c_float, _i32, _vp, _vp, _vp,
+                                               _vp, _vp, _i32, _i64, _i32, _i32, _i32, _vp]
+_lib.mixdq_layernorm_quantize.restype = _i32
+_lib.mixdq_layernorm_quantize.argtypes = [_vp, _vp, _vp, ctypes.c_float, _i64, _i32, _i32, _vp, _vp,
+                                          _vp, _vp, _i32, _vp]
+_lib.mixdq_geglu_quantize.restype = _i32
+_lib.mixdq_geglu_quantize.argtypes = [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp]
+
+
+def groupnorm_supported(N, HW, C, G) -> bool:
+    return _lib.mixdq_groupnorm_workspace_bytes(N, HW, C, G) > 0
+
+
+def groupnorm_silu_quantize(x, num_groups, weight, bias, eps, scale_inv=None, zero_point=None,
+                            silu=True, want_f16=False):
+    """x: fp16 [N, C, H, W] in channels-last memory (or [N, HW, C] contiguous).  Returns
+    (int8 or None, fp16 or None) with x's shape and strides."""
+    _check(x.is_cuda and x.dtype == torch.float16, "x should be an fp16 GPU tensor")
+    if x.dim() == 4:
+        _check(x.is_contiguous(memory_format=torch.channels_last),
+               "groupnorm_silu_quantize needs channels-last input")
+        N, C, HW = x.shape[0], x.shape[1], x.shape[2] * x.shape[3]
+    else:
+        _check(x.dim() == 3 and x.is_contiguous(), "x should be [N, HW, C] contiguous")
+        N, HW, C = x.shape
+    want_q = scale_inv is not None
+    _check(want_q or want_f16, "nothing to compute")
+    ws_bytes = _lib.mixdq_groupnorm_workspace_bytes(N, HW, C, num_groups)
+    _check(ws_bytes > 0, "groupnorm_silu_quantize: unsupported configuration")
+    ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
+    out_q = torch.empty_like(x, dtype=torch.int8) if want_q else None
+    out_h = torch.empty_like(x) if want_f16 else None
+    w, b = weight.contiguous(), bias.contiguous()
+    _check(w.dtype == torch.float16 and b.dtype == torch.float16, "gamma/beta should be fp16")
+    with torch.cuda.device(x.device):
+        code = _lib.mixdq_groupnorm_silu_quantize(
+            x.data_ptr(), w.data_ptr(), b.data_ptr(), float(eps), int(bool(silu)),
+            _ptr(scale_inv), _ptr(zero_point), _ptr(out_q), _ptr(out_h), ws.data_ptr(),
+            N, HW, C, num_groups, FLAGS, _stream())
+    _status(code, "groupnorm_silu_quantize")
+    return out_q, out_h
+
+
+def layernorm_quantize(x, weight, bias, eps, qparams, want_f16=False):
+    """x: fp16 [..., C] contiguous; qparams: up to three (scale_inv, zero_point) device-scalar
+    pairs.  Returns ([int8 ...], fp16 or None)."""
+    _check(x.is_cuda and x.dtype == torch.float16 and x.is_contiguous(),
+           "x should be a contiguous fp16 GPU tensor")
+    C = x.shape[-1]
+    M = x.numel() // C if C else 0
+    n = len(qparams)
+    _check(n <= 3 and (n > 0 or want_f16), "layernorm_quantize: 1..3 quantizers or want_f16")
+    outs = [torch.empty_like(x, dtype=torch.int8) for _ in range(n)]
+    out_h = torch.empty_like(x) if want_f16 else None
+    arr = ctypes.c_void_p * max(n, 1)
+    si = arr(*[p[0].data_ptr() for p in qparams])
+    zp = arr(*[p[1].data_ptr() for p in qparams])
+    oq = arr(*[o.data_ptr() for o in outs])
+    w, b = weight.contiguous(), bias.contiguous()
+    _check(w.dtype == torch.float16 and b.dtype == torch.float16, "gamma/beta should be fp16")
+    with torch.cuda.device(x.device):
+        code = _lib.mixdq_layernorm_quantize(x.data_ptr(), w.data_ptr(), b.data_ptr(), float(eps),
+                                             M, C, n, si, zp, oq, _ptr(out_h), FLAGS, _stream())
+    _status(code, "layernorm_quantize")
+    return outs, out_h
+
+
+def geglu_quantize(h, scale_inv=None, zero_point=None, want_f16=False):
+    """h: fp16 [..., 2D] contiguous -> (int8 [..., D] or None, fp16 [..., D] or None)."""
+    _check(h.is_cuda and h.dtype == torch.float16 and h.is_contiguous(),
+           "h should be a contiguous fp16 GPU tensor")
+    D = h.shape[-1] // 2
+    M = h.numel() // (2 * D) if D else 0
+    want_q = scale_inv is not None
+    _check(want_q or want_f16, "nothing to compute")
+    shape = list(h.shape[:-1]) + [D]
+    out_q = torch.empty(shape, dtype=torch.int8, device=h.device) if want_q else None
+    out_h = torch.empty(shape, dtype=torch.float16, device=h.device) if want_f16 else None
+    with torch.cuda.device(h.device):
+        code = _lib.mixdq_geglu_quantize(h.data_ptr(), M, D, _ptr(scale_inv), _ptr(zero_point),
+                                         _ptr(out_q), _ptr(out_h), FLAGS, _stream())
+    _status(code, "geglu_quantize")
+    return out_q, out_h

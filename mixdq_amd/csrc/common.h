@@ -31,6 +31,14 @@ __device__ __forceinline__ int quantize_one(float x, float s_inv, float zp) {
   return min(max(i, -128), 127);
 }
 
+// FP32 -> FP16 with the FP32 value made opaque first.  Without the barrier hipcc folds
+// `__float2half_rn(a * b + c)` into v_fma_mixlo_f16, which rounds the exact product-sum ONCE to
+// FP16 (and adds +0, turning -0 into +0): not the specified "round to FP32, then to FP16".
+__device__ __forceinline__ __half f32_to_f16_rn(float v) {
+  asm("" : "+v"(v));
+  return __float2half_rn(v);
+}
+
 // Epilogue: (f32(acc) - bias0) * scale [+ bias] -> f16 (RNE, overflow -> inf).
 __device__ __forceinline__ __half epilogue_one(int acc, float bias0, float scale, float bias,
                                                bool has_bias, bool unfused) {
@@ -43,7 +51,7 @@ __device__ __forceinline__ __half epilogue_one(int acc, float bias0, float scale
   } else {
     r = __builtin_fmaf(v, scale, bias);
   }
-  return __float2half_rn(r);
+  return f32_to_f16_rn(r);
 }
 
 }  // namespace mixdq

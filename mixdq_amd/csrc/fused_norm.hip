@@ -1,0 +1,385 @@
+// Producer fusions: the FP16 normalisation that feeds a quantized layer,
+// fused with that layer's activation quantizer, so the INT8 tensor is produced in one pass instead
+// of  norm -> (silu) -> [layout copy] -> quantize.
+//
+//   GroupNorm (+SiLU) + quantize, NHWC   -> ResnetBlock2D.norm1/norm2 -> conv1/conv2,
+//                                           Transformer2DModel.norm -> proj_in
+//   LayerNorm + quantize (up to 3 scales) -> BasicTransformerBlock.norm1/2/3 -> to_q,k,v / ff
+//   GEGLU + quantize                      -> ff.net.0 -> ff.net.2
+//
+// The reference fuses none of this (stock PyTorch FP16 ops, then its quantize kernel); the fused
+// kernels keep the same rounding points: normalised value -> FP16, SiLU/GELU -> FP16, product ->
+// FP16, then the a1 quantizer on that FP16 value.  All reductions have a FIXED order, and the
+// transcendental steps are the shared specification include/mixdq_math.h, so the CPU oracle
+// (oracle/mixdq_oracle.c) reproduces every kernel bit-for-bit.  HBM-bound.
+#include "common.h"
+#include "../../include/mixdq_math.h"
+
+namespace mixdq {
+namespace {
+
+struct alignas(16) Half8 { uint32_t w[4]; };
+struct alignas(8) Char8 { uint32_t w[2]; };
+
+__device__ __forceinline__ float half_at(const Half8& h, int j) {
+  const uint32_t w = h.w[j >> 1];
+  __half_raw r;
+  r.x = (unsigned short)((j & 1) ? (w >> 16) : (w & 0xffffu));
+  return __half2float(__half(r));
+}
+
+__device__ __forceinline__ float round_f16(float v) { return __half2float(f32_to_f16_rn(v)); }
+
+__device__ __forceinline__ void put_half(Half8& h, int j, float v) {
+  const uint32_t b = __half_as_ushort(f32_to_f16_rn(v));
+  if (j & 1) h.w[j >> 1] = (h.w[j >> 1] & 0x0000ffffu) | (b << 16);
+  else h.w[j >> 1] = (h.w[j >> 1] & 0xffff0000u) | b;
+}
+
+__device__ __forceinline__ void put_q(Char8& c, int j, int q) {
+  const int sh = 8 * (j & 3);
+  c.w[j >> 2] = (c.w[j >> 2] & ~(0xffu << sh)) | ((uint32_t)(q & 0xff) << sh);
+}
+
+// ------------------------------------------------------------------------------- GroupNorm
+// Thread geometry shared by stats and apply (and restated in the oracle):
+//   OC = C / 8 channel-octets per pixel, PP = max(1, 256 / OC) pixels per block-iteration,
+//   blockDim = OC * PP; thread t owns octet o = t % OC of pixel lane pp = t / OC.
+//   An octet spans at most two groups (cg = C / G >= 4): elements j < jb belong to group g0,
+//   the rest to g0 + 1.
+struct GnGeom {
+  int C, G, cg, OC, PP;
+  int64_t HW;
+  int ppb;      // pixels per block (multiple of PP)
+  int nchunk;   // blocks per image
+};
+
+__global__ void gn_stats_kernel(const __half* __restrict__ x, float2* __restrict__ partial,
+                                GnGeom g) {
+  extern __shared__ float lds[];   // [blockDim][4]: s0, q0, s1, q1
+  const int t = threadIdx.x;
+  const int o = t % g.OC, pp = t / g.OC;
+  const int n = blockIdx.y, chunk = blockIdx.x;
+  const int g0 = (8 * o) / g.cg;
+  const int jb = min(8, (g0 + 1) * g.cg - 8 * o);
+  const int64_t p_begin = (int64_t)chunk * g.ppb;
+  const int64_t p_end = min(g.HW, p_begin + g.ppb);
+  const __half* base = x + ((int64_t)n * g.HW) * g.C + 8 * o;
+  float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+  for (int64_t p = p_begin + pp; p < p_end; p += g.PP) {
+    const Half8 h = *reinterpret_cast<const Half8*>(base + p * g.C);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = half_at(h, j);
+      if (j < jb) { s0 = __fadd_rn(s0, v); q0 = __builtin_fmaf(v, v, q0); }
+      else        { s1 = __fadd_rn(s1, v); q1 = __builtin_fmaf(v, v, q1); }
+    }
+  }
+  lds[4 * t + 0] = s0; lds[4 * t + 1] = q0; lds[4 * t + 2] = s1; lds[4 * t + 3] = q1;
+  __syncthreads();
+  if (t < g.G) {   // group t: octets olo..ohi, pixel lanes ascending, fixed order
+    const int olo = (t * g.cg) / 8, ohi = ((t + 1) * g.cg - 1) / 8;
+    float s = 0.f, q = 0.f;
+    for (int l = 0; l < g.PP; ++l)
+      for (int oo = olo; oo <= ohi; ++oo) {
+        const int tt = l * g.OC + oo;
+        const int first = (8 * oo) / g.cg;          // group of that octet's leading part
+        const int part = (first == t) ? 0 : 2;      // leading or trailing accumulator
+        if (first == t || first + 1 == t) {
+          s = __fadd_rn(s, lds[4 * tt + part]);
+          q = __fadd_rn(q, lds[4 * tt + part + 1]);
+        }
+      }
+    partial[((int64_t)n * g.nchunk + chunk) * g.G + t] = make_float2(s, q);
+  }
+}
+
+__global__ void gn_finalize_kernel(const float2* __restrict__ partial, float2* __restrict__ stats,
+                                   GnGeom g, float eps) {
+  const int n = blockIdx.x, t = threadIdx.x;
+  if (t >= g.G) return;
+  float s = 0.f, q = 0.f;
+  for (int c = 0; c < g.nchunk; ++c) {
+    const float2 v = partial[((int64_t)n * g.nchunk + c) * g.G + t];
+    s = __fadd_rn(s, v.x);
+    q = __fadd_rn(q, v.y);
+  }
+  const float cnt = (float)((double)g.HW * g.cg);
+  const float mean = s / cnt;
+  float var = __builtin_fmaf(-mean, mean, q / cnt);
+  var = fmaxf(var, 0.f);
+  const float rstd = 1.0f / sqrtf(__fadd_rn(var, eps));
+  stats[(int64_t)n * g.G + t] = make_float2(mean, rstd);
+}
+
+template <bool SILU, bool UNFUSED>
+__global__ void gn_apply_kernel(const __half* __restrict__ x, const float2* __restrict__ stats,
+                                const __half* __restrict__ gamma, const __half* __restrict__ beta,
+                                const float* __restrict__ s_inv_p, const float* __restrict__ zp_p,
+                                int8_t* __restrict__ out_q, __half* __restrict__ out_h, GnGeom g) {
+  const int t = threadIdx.x;
+  const int o = t % g.OC, pp = t / g.OC;
+  const int n = blockIdx.y, chunk = blockIdx.x;
+  const int g0 = (8 * o) / g.cg;
+  const int jb = min(8, (g0 + 1) * g.cg - 8 * o);
+  const float2 st0 = stats[(int64_t)n * g.G + g0];
+  const float2 st1 = stats[(int64_t)n * g.G + min(g0 + 1, g.G - 1)];
+  float a[8], b[8];
+  const Half8 gm = *reinterpret_cast<const Half8*>(gamma + 8 * o);
+  const Half8 bt = *reinterpret_cast<const Half8*>(beta + 8 * o);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float mean = j < jb ? st0.x : st1.x, rstd = j < jb ? st0.y : st1.y;
+    a[j] = __fmul_rn(rstd, half_at(gm, j));
+    b[j] = __builtin_fmaf(-mean, a[j], half_at(bt, j));
+  }
+  const bool want_q = out_q != nullptr;
+  const float s_inv = want_q ? *s_inv_p : 0.f, zp = want_q ? *zp_p : 0.f;
+  const int64_t p_begin = (int64_t)chunk * g.ppb;
+  const int64_t p_end = min(g.HW, p_begin + g.ppb);
+  const int64_t img = ((int64_t)n * g.HW) * g.C + 8 * o;
+  for (int64_t p = p_begin + pp; p < p_end; p += g.PP) {
+    const Half8 h = *reinterpret_cast<const Half8*>(x + img + p * g.C);
+    Half8 oh;
+    Char8 oq;
+    oq.w[0] = oq.w[1] = 0;
+    oh.w[0] = oh.w[1] = oh.w[2] = oh.w[3] = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float y = round_f16(__builtin_fmaf(half_at(h, j), a[j], b[j]));   // GroupNorm -> fp16
+      if (SILU) y = round_f16(mixdq_siluf(y));                          // SiLU -> fp16
+      put_half(oh, j, y);
+      put_q(oq, j, quantize_one<UNFUSED>(y, s_inv, zp));
+    }
+    if (want_q) *reinterpret_cast<Char8*>(out_q + img + p * g.C) = oq;
+    if (out_h) *reinterpret_cast<Half8*>(out_h + img + p * g.C) = oh;
+  }
+}
+
+inline bool make_gn_geom(int N, int64_t HW, int C, int G, GnGeom& g) {
+  if (N <= 0 || HW <= 0 || C <= 0 || G <= 0 || C % G != 0 || C % 8 != 0) return false;
+  g.C = C; g.G = G; g.cg = C / G; g.OC = C / 8; g.HW = HW;
+  if (g.OC > 1024) return false;
+  for (int o = 0; o < g.OC; ++o)                  // an octet may span at most two groups
+    if ((8 * o + 7) / g.cg - (8 * o) / g.cg > 1) return false;
+  g.PP = g.OC >= 256 ? 1 : 256 / g.OC;
+  if (G > g.OC * g.PP) return false;              // the block reduces with G threads
+  // Blocks per image: about 512 blocks in total, a whole number of block-iterations each.
+  // (Fixed rule: the oracle restates it, because it fixes the summation order.)
+  const int64_t target = (512 + N - 1) / N;
+  int64_t ppb = (HW + target - 1) / target;
+  ppb = ((ppb + g.PP - 1) / g.PP) * g.PP;
+  g.ppb = (int)ppb;
+  g.nchunk = (int)((HW + ppb - 1) / ppb);
+  return true;
+}
+
+// ------------------------------------------------------------------------------- LayerNorm
+// One wave per row.  Lane l owns the 8-element chunks l, l + 64, l + 128, ... (at most 4);
+// per-lane sequential sums, then a 6-step xor butterfly (every lane ends with the same bits).
+constexpr int kLnMaxChunks = 4;   // C <= 2048
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = __fadd_rn(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+template <bool UNFUSED>
+__global__ __launch_bounds__(256) void ln_quant_kernel(
+    const __half* __restrict__ x, const __half* __restrict__ gamma, const __half* __restrict__ beta,
+    float eps, int64_t M, int C, const float* __restrict__ s_inv0, const float* __restrict__ zp0,
+    int8_t* __restrict__ q0, const float* __restrict__ s_inv1, const float* __restrict__ zp1,
+    int8_t* __restrict__ q1, const float* __restrict__ s_inv2, const float* __restrict__ zp2,
+    int8_t* __restrict__ q2, __half* __restrict__ out_h) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nch = C / 8;
+  const __half* xr = x + row * C;
+  Half8 h[kLnMaxChunks];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < kLnMaxChunks; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      h[i] = *reinterpret_cast<const Half8*>(xr + 8 * c);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s = __fadd_rn(s, half_at(h[i], j));
+    }
+  }
+  const float mean = wave_sum(s) / (float)C;
+  float v = 0.f;
+#pragma unroll
+  for (int i = 0; i < kLnMaxChunks; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float d = __fsub_rn(half_at(h[i], j), mean);
+        v = __builtin_fmaf(d, d, v);
+      }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(__fadd_rn(wave_sum(v) / (float)C, eps));
+  const float si0 = q0 ? *s_inv0 : 0.f, z0 = q0 ? *zp0 : 0.f;
+  const float si1 = q1 ? *s_inv1 : 0.f, z1 = q1 ? *zp1 : 0.f;
+  const float si2 = q2 ? *s_inv2 : 0.f, z2 = q2 ? *zp2 : 0.f;
+#pragma unroll
+  for (int i = 0; i < kLnMaxChunks; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
+      const Half8 gm = *reinterpret_cast<const Half8*>(gamma + 8 * c);
+      const Half8 bt = *reinterpret_cast<const Half8*>(beta + 8 * c);
+      Half8 oh;
+      Char8 a, b, d;
+      a.w[0] = a.w[1] = b.w[0] = b.w[1] = d.w[0] = d.w[1] = 0;
+      oh.w[0] = oh.w[1] = oh.w[2] = oh.w[3] = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float nrm = __fmul_rn(__fsub_rn(half_at(h[i], j), mean), rstd);
+        const float y = round_f16(__builtin_fmaf(nrm, half_at(gm, j), half_at(bt, j)));
+        put_half(oh, j, y);
+        put_q(a, j, quantize_one<UNFUSED>(y, si0, z0));
+        put_q(b, j, quantize_one<UNFUSED>(y, si1, z1));
+        put_q(d, j, quantize_one<UNFUSED>(y, si2, z2));
+      }
+      const int64_t off = row * C + 8 * c;
+      if (q0) *reinterpret_cast<Char8*>(q0 + off) = a;
+      if (q1) *reinterpret_cast<Char8*>(q1 + off) = b;
+      if (q2) *reinterpret_cast<Char8*>(q2 + off) = d;
+      if (out_h) *reinterpret_cast<Half8*>(out_h + off) = oh;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------- GEGLU
+// h [M, 2D] (ff.net.0.proj output): y = fp16(fp16(h[:, :D]) * fp16(gelu(h[:, D:]))) -> quantize.
+template <bool UNFUSED>
+__global__ __launch_bounds__(256) void geglu_quant_kernel(
+    const __half* __restrict__ h, int64_t M, int D, const float* __restrict__ s_inv_p,
+    const float* __restrict__ zp_p, int8_t* __restrict__ out_q, __half* __restrict__ out_h) {
+  const int dch = D / 8;
+  const int64_t total = M * dch;
+  const bool want_q = out_q != nullptr;
+  const float s_inv = want_q ? *s_inv_p : 0.f, zp = want_q ? *zp_p : 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / dch;
+    const int c = (int)(i - m * dch);
+    const Half8 xv = *reinterpret_cast<const Half8*>(h + m * 2 * D + 8 * c);
+    const Half8 gv = *reinterpret_cast<const Half8*>(h + m * 2 * D + D + 8 * c);
+    Half8 oh;
+    Char8 oq;
+    oq.w[0] = oq.w[1] = 0;
+    oh.w[0] = oh.w[1] = oh.w[2] = oh.w[3] = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float ge = round_f16(mixdq_geluf(half_at(gv, j)));
+      const float y = round_f16(__fmul_rn(half_at(xv, j), ge));
+      put_half(oh, j, y);
+      put_q(oq, j, quantize_one<UNFUSED>(y, s_inv, zp));
+    }
+    if (want_q) *reinterpret_cast<Char8*>(out_q + m * D + 8 * c) = oq;
+    if (out_h) *reinterpret_cast<Half8*>(out_h + m * D + 8 * c) = oh;
+  }
+}
+
+}  // namespace
+}  // namespace mixdq
+
+using namespace mixdq;
+
+extern "C" size_t mixdq_groupnorm_workspace_bytes(int N, int64_t HW, int C, int G) {
+  GnGeom g;
+  if (!make_gn_geom(N, HW, C, G, g)) return 0;
+  return ((size_t)N * g.nchunk * G + (size_t)N * G) * sizeof(float2);
+}
+
+extern "C" int mixdq_groupnorm_silu_quantize(const void* x_nhwc, const void* gamma,
+                                             const void* beta, float eps, int apply_silu,
+                                             const float* scale_inv, const float* zero_point,
+                                             int8_t* out_q_or_null, void* out_f16_or_null,
+                                             void* workspace, int N, int64_t HW, int C, int G,
+                                             int flags, mixdq_stream_t stream_) {
+  GnGeom g;
+  if (!make_gn_geom(N, HW, C, G, g)) return MIXDQ_ERR_UNSUPPORTED;
+  if (!x_nhwc || !gamma || !beta || !workspace || (!out_q_or_null && !out_f16_or_null))
+    return MIXDQ_ERR_INVALID_ARG;
+  if (out_q_or_null && (!scale_inv || !zero_point)) return MIXDQ_ERR_INVALID_ARG;
+  if (((uintptr_t)x_nhwc | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)out_f16_or_null) % 16 ||
+      (uintptr_t)out_q_or_null % 8)
+    return MIXDQ_ERR_ALIGNMENT;
+  hipStream_t stream = (hipStream_t)stream_;
+  float2* partial = (float2*)workspace;
+  float2* stats = partial + (size_t)N * g.nchunk * G;
+  const int threads = g.OC * g.PP;
+  const dim3 grid(g.nchunk, N);
+  gn_stats_kernel<<<grid, threads, threads * 4 * sizeof(float), stream>>>((const __half*)x_nhwc,
+                                                                           partial, g);
+  gn_finalize_kernel<<<N, 64, 0, stream>>>(partial, stats, g, eps);
+  const bool unfused = flags & MIXDQ_FLAG_UNFUSED;
+#define GN_APPLY(S, U)                                                                          \
+  gn_apply_kernel<S, U><<<grid, threads, 0, stream>>>(                                          \
+      (const __half*)x_nhwc, stats, (const __half*)gamma, (const __half*)beta, scale_inv,       \
+      zero_point, out_q_or_null, (__half*)out_f16_or_null, g)
+  if (apply_silu) { if (unfused) GN_APPLY(true, true); else GN_APPLY(true, false); }
+  else            { if (unfused) GN_APPLY(false, true); else GN_APPLY(false, false); }
+#undef GN_APPLY
+  return launch_status();
+}
+
+extern "C" int mixdq_layernorm_quantize(const void* x, const void* gamma, const void* beta,
+                                        float eps, int64_t M, int C, int n_out,
+                                        const float* const* scale_inv,
+                                        const float* const* zero_point, int8_t* const* out_q,
+                                        void* out_f16_or_null, int flags, mixdq_stream_t stream_) {
+  if (M < 0 || C <= 0 || n_out < 0 || n_out > 3) return MIXDQ_ERR_INVALID_ARG;
+  if (C % 8 != 0 || C / 8 > 64 * kLnMaxChunks) return MIXDQ_ERR_UNSUPPORTED;
+  if (M == 0) return MIXDQ_OK;
+  if (!x || !gamma || !beta || (n_out == 0 && !out_f16_or_null)) return MIXDQ_ERR_INVALID_ARG;
+  const float* si[3] = {nullptr, nullptr, nullptr};
+  const float* zp[3] = {nullptr, nullptr, nullptr};
+  int8_t* q[3] = {nullptr, nullptr, nullptr};
+  for (int i = 0; i < n_out; ++i) {
+    if (!scale_inv || !zero_point || !out_q || !scale_inv[i] || !zero_point[i] || !out_q[i])
+      return MIXDQ_ERR_INVALID_ARG;
+    si[i] = scale_inv[i]; zp[i] = zero_point[i]; q[i] = out_q[i];
+    if ((uintptr_t)q[i] % 8) return MIXDQ_ERR_ALIGNMENT;
+  }
+  if (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)out_f16_or_null) % 16)
+    return MIXDQ_ERR_ALIGNMENT;
+  const int grid = (int)((M + 3) / 4);
+  hipStream_t stream = (hipStream_t)stream_;
+  if (flags & MIXDQ_FLAG_UNFUSED)
+    ln_quant_kernel<true><<<grid, 256, 0, stream>>>(
+        (const __half*)x, (const __half*)gamma, (const __half*)beta, eps, M, C, si[0], zp[0], q[0],
+        si[1], zp[1], q[1], si[2], zp[2], q[2], (__half*)out_f16_or_null);
+  else
+    ln_quant_kernel<false><<<grid, 256, 0, stream>>>(
+        (const __half*)x, (const __half*)gamma, (const __half*)beta, eps, M, C, si[0], zp[0], q[0],
+        si[1], zp[1], q[1], si[2], zp[2], q[2], (__half*)out_f16_or_null);
+  return launch_status();
+}
+
+extern "C" int mixdq_geglu_quantize(const void* h, int64_t M, int D, const float* scale_inv,
+                                    const float* zero_point, int8_t* out_q_or_null,
+                                    void* out_f16_or_null, int flags, mixdq_stream_t stream_) {
+  if (M < 0 || D <= 0) return MIXDQ_ERR_INVALID_ARG;
+  if (D % 8 != 0) return MIXDQ_ERR_UNSUPPORTED;
+  if (M == 0) return MIXDQ_OK;
+  if (!h || (!out_q_or_null && !out_f16_or_null)) return MIXDQ_ERR_INVALID_ARG;
+  if (out_q_or_null && (!scale_inv || !zero_point)) return MIXDQ_ERR_INVALID_ARG;
+  if (((uintptr_t)h | (uintptr_t)out_f16_or_null) % 16 || (uintptr_t)out_q_or_null % 8)
+    return MIXDQ_ERR_ALIGNMENT;
+  int64_t blocks = (M * (D / 8) + 255) / 256;
+  if (blocks > kNumCU * 8) blocks = kNumCU * 8;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (flags & MIXDQ_FLAG_UNFUSED)
+    geglu_quant_kernel<true><<<(int)blocks, 256, 0, stream>>>(
+        (const __half*)h, M, D, scale_inv, zero_point, out_q_or_null, (__half*)out_f16_or_null);
+  else
+    geglu_quant_kernel<false><<<(int)blocks, 256, 0, stream>>>(
+        (const __half*)h, M, D, scale_inv, zero_point, out_q_or_null, (__half*)out_f16_or_null);
+  return launch_status();
+}

@@ -423,7 +423,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const __half* __restrict_
     float acc = 0.f;
     for (int k = 0; k < K; ++k)
       acc = __builtin_fmaf(__half2float(A[m * K + k]), __half2float(B[(int64_t)k * N + n]), acc);
-    D[t] = __float2half_rn(acc);
+    D[t] = f32_to_f16_rn(acc);
   }
 }
 

@@ -243,3 +243,172 @@ void mixdq_oracle_gemm_f16(const uint16_t* A, const uint16_t* B, uint16_t* D, in
       D[m * N + n] = f2h(acc);
     }
 }
+
+/* =============================================================================================
+ * Producer fusions (mixdq_amd/csrc/fused_norm.hip).  No reference counterpart: the reference runs
+ * stock PyTorch FP16 ops and then its quantizer.  These restate the fused kernels' arithmetic
+ * INCLUDING their fixed reduction orders (the order is part of the specification), with the
+ * transcendental steps from include/mixdq_math.h; tests/ additionally hold them to PyTorch's
+ * fp32-reference GroupNorm / LayerNorm / SiLU / GELU within one FP16 ulp.
+ * ============================================================================================= */
+#include "../include/mixdq_math.h"
+
+static float rh(float v) { return h2f(f2h(v)); } /* round to fp16 and back */
+
+/* Geometry rule of make_gn_geom() (fused_norm.hip): returns 0 if unsupported. */
+static int gn_geom(int N, int64_t HW, int C, int G, int* cg, int* OC, int* PP, int* ppb,
+                   int* nchunk) {
+  if (N <= 0 || HW <= 0 || C <= 0 || G <= 0 || C % G != 0 || C % 8 != 0) return 0;
+  *cg = C / G;
+  *OC = C / 8;
+  if (*OC > 1024) return 0;
+  for (int o = 0; o < *OC; o++)
+    if ((8 * o + 7) / *cg - (8 * o) / *cg > 1) return 0;
+  *PP = *OC >= 256 ? 1 : 256 / *OC;
+  if (G > *OC * *PP) return 0;
+  int64_t target = (512 + N - 1) / N;
+  int64_t p = (HW + target - 1) / target;
+  p = ((p + *PP - 1) / *PP) * *PP;
+  *ppb = (int)p;
+  *nchunk = (int)((HW + p - 1) / p);
+  return 1;
+}
+
+/* gn_stats_kernel + gn_finalize_kernel: mean / rstd per (n, group), in the kernels' summation
+ * order.  Returns 0 when the shape is unsupported. */
+int mixdq_oracle_groupnorm_stats(const uint16_t* x, float eps, float* mean, float* rstd, int N,
+                                 int64_t HW, int C, int G) {
+  int cg, OC, PP, ppb, nchunk;
+  if (!gn_geom(N, HW, C, G, &cg, &OC, &PP, &ppb, &nchunk)) return 0;
+  const int T = OC * PP;
+  float* acc = (float*)malloc(sizeof(float) * 4 * T);
+  float* ps = (float*)malloc(sizeof(float) * (size_t)nchunk * G);
+  float* pq = (float*)malloc(sizeof(float) * (size_t)nchunk * G);
+  for (int n = 0; n < N; n++) {
+    for (int chunk = 0; chunk < nchunk; chunk++) {
+      int64_t pb = (int64_t)chunk * ppb, pe = pb + ppb < HW ? pb + ppb : HW;
+      for (int t = 0; t < T; t++) { /* gn_stats_kernel, one "thread" at a time */
+        int o = t % OC, pp = t / OC, g0 = (8 * o) / cg;
+        int jb = (g0 + 1) * cg - 8 * o;
+        if (jb > 8) jb = 8;
+        float s0 = 0, q0 = 0, s1 = 0, q1 = 0;
+        for (int64_t p = pb + pp; p < pe; p += PP)
+          for (int j = 0; j < 8; j++) {
+            float v = h2f(x[((int64_t)n * HW + p) * C + 8 * o + j]);
+            if (j < jb) { s0 = s0 + v; q0 = fmaf(v, v, q0); }
+            else        { s1 = s1 + v; q1 = fmaf(v, v, q1); }
+          }
+        acc[4 * t] = s0; acc[4 * t + 1] = q0; acc[4 * t + 2] = s1; acc[4 * t + 3] = q1;
+      }
+      for (int g = 0; g < G; g++) {
+        int olo = (g * cg) / 8, ohi = ((g + 1) * cg - 1) / 8;
+        float s = 0, q = 0;
+        for (int l = 0; l < PP; l++)
+          for (int oo = olo; oo <= ohi; oo++) {
+            int tt = l * OC + oo, first = (8 * oo) / cg, part = (first == g) ? 0 : 2;
+            if (first == g || first + 1 == g) { s = s + acc[4 * tt + part]; q = q + acc[4 * tt + part + 1]; }
+          }
+        ps[(size_t)chunk * G + g] = s;
+        pq[(size_t)chunk * G + g] = q;
+      }
+    }
+    for (int g = 0; g < G; g++) { /* gn_finalize_kernel */
+      float s = 0, q = 0;
+      for (int c = 0; c < nchunk; c++) { s = s + ps[(size_t)c * G + g]; q = q + pq[(size_t)c * G + g]; }
+      float cnt = (float)((double)HW * cg);
+      float m = s / cnt;
+      float var = fmaf(-m, m, q / cnt);
+      if (!(var > 0.f)) var = 0.f;
+      mean[n * G + g] = m;
+      rstd[n * G + g] = 1.0f / sqrtf(var + eps);
+    }
+  }
+  free(acc); free(ps); free(pq);
+  return 1;
+}
+
+/* x [N,HW,C] fp16 bits.  out_q / out_h may be NULL.  Returns 0 when the shape is unsupported. */
+int mixdq_oracle_groupnorm_silu_quantize(const uint16_t* x, const uint16_t* gamma,
+                                         const uint16_t* beta, float eps, int apply_silu,
+                                         float s_inv, float zp, int8_t* out_q, uint16_t* out_h,
+                                         int N, int64_t HW, int C, int G, int variant) {
+  const int cg = (G > 0 && C % G == 0) ? C / G : 1;
+  float* mean = (float*)malloc(sizeof(float) * (size_t)(N > 0 ? N : 1) * (G > 0 ? G : 1));
+  float* rstd = (float*)malloc(sizeof(float) * (size_t)(N > 0 ? N : 1) * (G > 0 ? G : 1));
+  if (!mixdq_oracle_groupnorm_stats(x, eps, mean, rstd, N, HW, C, G)) {
+    free(mean); free(rstd);
+    return 0;
+  }
+  for (int n = 0; n < N; n++) /* gn_apply_kernel (elementwise: order irrelevant) */
+    for (int64_t p = 0; p < HW; p++)
+      for (int c = 0; c < C; c++) {
+        int g = c / cg;
+        float a = rstd[n * G + g] * h2f(gamma[c]);
+        float b = fmaf(-mean[n * G + g], a, h2f(beta[c]));
+        int64_t i = ((int64_t)n * HW + p) * C + c;
+        float y = rh(fmaf(h2f(x[i]), a, b));
+        if (apply_silu) y = rh(mixdq_siluf(y));
+        if (out_h) out_h[i] = f2h(y);
+        if (out_q) out_q[i] = quant1(y, s_inv, zp, variant);
+      }
+  free(mean); free(rstd);
+  return 1;
+}
+
+/* ln_quant_kernel: one 64-lane wave per row, lane l owns chunks l, l+64, ...; xor butterfly. */
+static float wave_sum64(float* v) {
+  for (int off = 32; off >= 1; off >>= 1) {
+    float t[64];
+    for (int l = 0; l < 64; l++) t[l] = v[l] + v[l ^ off];
+    for (int l = 0; l < 64; l++) v[l] = t[l];
+  }
+  return v[0];
+}
+
+void mixdq_oracle_layernorm_quantize(const uint16_t* x, const uint16_t* gamma, const uint16_t* beta,
+                                     float eps, int64_t M, int C, int n_out, const float* s_inv,
+                                     const float* zp, int8_t** out_q, uint16_t* out_h,
+                                     int variant) {
+  const int nch = C / 8;
+  for (int64_t r = 0; r < M; r++) {
+    const uint16_t* xr = x + r * C;
+    float part[64];
+    for (int l = 0; l < 64; l++) {
+      float s = 0;
+      for (int c = l; c < nch; c += 64)
+        for (int j = 0; j < 8; j++) s = s + h2f(xr[8 * c + j]);
+      part[l] = s;
+    }
+    const float mean = wave_sum64(part) / (float)C;
+    for (int l = 0; l < 64; l++) {
+      float v = 0;
+      for (int c = l; c < nch; c += 64)
+        for (int j = 0; j < 8; j++) { float d = h2f(xr[8 * c + j]) - mean; v = fmaf(d, d, v); }
+      part[l] = v;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum64(part) / (float)C + eps);
+    for (int c = 0; c < C; c++) {
+      volatile float nrm = (h2f(xr[c]) - mean) * rstd;
+      float y = rh(fmaf(nrm, h2f(gamma[c]), h2f(beta[c])));
+      if (out_h) out_h[r * C + c] = f2h(y);
+      for (int k = 0; k < n_out; k++) out_q[k][r * C + c] = quant1(y, s_inv[k], zp[k], variant);
+    }
+  }
+}
+
+void mixdq_oracle_geglu_quantize(const uint16_t* h, int64_t M, int D, float s_inv, float zp,
+                                 int8_t* out_q, uint16_t* out_h, int variant) {
+  for (int64_t m = 0; m < M; m++)
+    for (int d = 0; d < D; d++) {
+      float ge = rh(mixdq_geluf(h2f(h[m * 2 * D + D + d])));
+      volatile float prod = h2f(h[m * 2 * D + d]) * ge;
+      float y = rh(prod);
+      if (out_h) out_h[m * D + d] = f2h(y);
+      if (out_q) out_q[m * D + d] = quant1(y, s_inv, zp, variant);
+    }
+}
+
+float mixdq_oracle_expf(float x) { return mixdq_expf(x); }
+float mixdq_oracle_erff(float x) { return mixdq_erff(x); }
+float mixdq_oracle_siluf(float x) { return mixdq_siluf(x); }
+float mixdq_oracle_geluf(float x) { return mixdq_geluf(x); }

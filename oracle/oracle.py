@@ -50,6 +50,17 @@ def lib() -> ctypes.CDLL:
         L.mixdq_oracle_add_f16.restype = None
         L.mixdq_oracle_gemm_f16.argtypes = [vp, vp, vp, i64, i32, i32]
         L.mixdq_oracle_gemm_f16.restype = None
+        L.mixdq_oracle_groupnorm_silu_quantize.argtypes = [vp, vp, vp, f32, i32, f32, f32, vp, vp,
+                                                            i32, i64, i32, i32, i32]
+        L.mixdq_oracle_groupnorm_silu_quantize.restype = i32
+        L.mixdq_oracle_layernorm_quantize.argtypes = [vp, vp, vp, f32, i64, i32, i32, vp, vp, vp,
+                                                      vp, i32]
+        L.mixdq_oracle_layernorm_quantize.restype = None
+        L.mixdq_oracle_geglu_quantize.argtypes = [vp, i64, i32, f32, f32, vp, vp, i32]
+        L.mixdq_oracle_geglu_quantize.restype = None
+        for fn in ("expf", "erff", "siluf", "geluf"):
+            getattr(L, "mixdq_oracle_" + fn).argtypes = [f32]
+            getattr(L, "mixdq_oracle_" + fn).restype = f32
         L.mixdq_oracle_h2f.argtypes = [ctypes.c_uint16]
         L.mixdq_oracle_h2f.restype = f32
         L.mixdq_oracle_f2h.argtypes = [f32]
@@ -165,6 +176,54 @@ def gemm_f16(a, b_kn):
     D = np.empty(a.shape[:-1] + (N,), dtype=np.float16)
     lib().mixdq_oracle_gemm_f16(_p(a), _p(b), _p(D), M, N, K)
     return D
+
+
+def groupnorm_silu_quantize(x_nhwc, gamma, beta, eps, num_groups, silu, scale_inv, zero_point,
+                            variant=VARIANT_FUSED):
+    """Fused GroupNorm(+SiLU)+quantize on x [N, HW, C] (or [N,H,W,C]) float16.
+    Returns (int8, float16) of x's shape."""
+    x = _c(x_nhwc, np.float16)
+    N, C = x.shape[0], x.shape[-1]
+    HW = x.size // (N * C)
+    g, b = _c(gamma, np.float16), _c(beta, np.float16)
+    q = np.empty(x.shape, np.int8)
+    h = np.empty(x.shape, np.float16)
+    ok = lib().mixdq_oracle_groupnorm_silu_quantize(
+        _p(x), _p(g), _p(b), float(np.float32(eps)), int(bool(silu)),
+        float(np.float32(scale_inv)), float(np.float32(zero_point)), _p(q), _p(h), N, HW, C,
+        num_groups, variant)
+    if not ok:
+        raise ValueError("unsupported GroupNorm geometry")
+    return q, h
+
+
+def layernorm_quantize(x, gamma, beta, eps, qparams, variant=VARIANT_FUSED):
+    """Fused LayerNorm+quantize on x [..., C] float16; qparams = [(scale_inv, zp), ...] (<= 3).
+    Returns ([int8, ...], float16)."""
+    x = _c(x, np.float16)
+    C = x.shape[-1]
+    M = x.size // C
+    g, b = _c(gamma, np.float16), _c(beta, np.float16)
+    outs = [np.empty(x.shape, np.int8) for _ in qparams]
+    h = np.empty(x.shape, np.float16)
+    si = np.asarray([p[0] for p in qparams], dtype=np.float32)
+    zp = np.asarray([p[1] for p in qparams], dtype=np.float32)
+    ptrs = (ctypes.c_void_p * max(len(outs), 1))(*[o.ctypes.data for o in outs])
+    lib().mixdq_oracle_layernorm_quantize(_p(x), _p(g), _p(b), float(np.float32(eps)), M, C,
+                                          len(outs), _p(si), _p(zp), ptrs, _p(h), variant)
+    return outs, h
+
+
+def geglu_quantize(h, scale_inv, zero_point, variant=VARIANT_FUSED):
+    """Fused GEGLU+quantize on h [..., 2D] float16 -> (int8 [..., D], float16 [..., D])."""
+    h = _c(h, np.float16)
+    D = h.shape[-1] // 2
+    M = h.size // (2 * D)
+    q = np.empty(h.shape[:-1] + (D,), np.int8)
+    o = np.empty(h.shape[:-1] + (D,), np.float16)
+    lib().mixdq_oracle_geglu_quantize(_p(h), M, D, float(np.float32(scale_inv)),
+                                      float(np.float32(zero_point)), _p(q), _p(o), variant)
+    return q, o
 
 
 # ------------------------------------------------------------------------------------------

@@ -1,0 +1,140 @@
+"""GPU parity tests of the producer fusions (GroupNorm+SiLU+quantize, LayerNorm+quantize,
+GEGLU+quantize): bit-exact vs the oracle's restatement (which fixes the reduction order and uses
+the shared transcendental specification include/mixdq_math.h), and within one FP16 ulp of PyTorch's
+fp32-reference GroupNorm / LayerNorm / SiLU / GELU (the ops the reference leaves to stock PyTorch;
+one ulp per FP16 rounding point)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests import detdata as dd
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def scal(v):
+    return torch.tensor(float(v), dtype=torch.float32, device=DEV)
+
+
+def ulp_f16(ref):
+    a = ref.float().abs().clamp(min=2.0 ** -14)
+    return 2.0 ** (torch.floor(torch.log2(a)) - 10)
+
+
+GN_CASES = [  # N, H, W, C, G, silu
+    (1, 16, 16, 320, 32, True), (2, 8, 8, 640, 32, True), (1, 8, 8, 1280, 32, False),
+    (1, 12, 12, 960, 32, True), (1, 4, 4, 1920, 32, True), (1, 4, 4, 2560, 32, True),
+    (3, 5, 7, 64, 8, True), (2, 16, 16, 32, 8, False), (1, 1, 1, 128, 8, True),
+    (1, 128, 128, 320, 32, True),
+]
+
+
+@pytest.mark.parametrize("case", GN_CASES, ids=[f"n{c[0]}_{c[1]}x{c[2]}_c{c[3]}_g{c[4]}_{'silu' if c[5] else 'plain'}" for c in GN_CASES])
+def test_groupnorm_silu_quantize(C, oracle, case):
+    N, H, W, Cc, G, silu = case
+    x = (dd.normal_f16(11, (N, H, W, Cc), 1.5).astype(np.float32) +
+         dd.normal_f16(12, (1, 1, 1, Cc), 0.7).astype(np.float32)).astype(np.float16)
+    gamma = (dd.normal_f16(13, (Cc,), 0.3).astype(np.float32) + 1).astype(np.float16)
+    beta = dd.normal_f16(14, (Cc,), 0.2)
+    s_inv, zp = float(np.float32(1) / np.float32(0.031)), -20.0
+    xd = t(x).permute(0, 3, 1, 2)     # NCHW view of NHWC memory
+    q, h = C.groupnorm_silu_quantize(xd, G, t(gamma), t(beta), 1e-5, scal(s_inv), scal(zp),
+                                     silu=silu, want_f16=True)
+    assert q.shape == xd.shape and q.is_contiguous(memory_format=torch.channels_last) or N * H * W == 1 or Cc == 1
+    q_ref, h_ref = oracle.groupnorm_silu_quantize(x, gamma, beta, 1e-5, G, silu, s_inv, zp,
+                                                  C.FLAGS & 1)
+    got_h = h.permute(0, 2, 3, 1).contiguous().cpu().numpy()
+    got_q = q.permute(0, 2, 3, 1).contiguous().cpu().numpy()
+    assert np.array_equal(got_h.view(np.uint16), h_ref.view(np.uint16)), \
+        f"{(got_h.view(np.uint16) != h_ref.view(np.uint16)).sum()} fp16 values differ"
+    assert np.array_equal(got_q, q_ref)
+    # against PyTorch, one rounding point at a time (fp32 math, FP16 rounding after the norm and
+    # after SiLU): the normalised value within 1 ulp of F.group_norm, and SiLU of OUR normalised
+    # value within 1 ulp of F.silu of that same value (SiLU amplifies an input ulp for x << 0).
+    _, pre = C.groupnorm_silu_quantize(xd, G, t(gamma), t(beta), 1e-5, silu=False, want_f16=True)
+    ref = F.group_norm(xd.float(), G, t(gamma).float(), t(beta).float(), 1e-5).half()
+    # (+2e-6: where a*x + b cancels to ~0 the FP32 rounding of the O(1) terms exceeds an FP16 ulp)
+    assert ((pre.float() - ref.float()).abs() <= 1.001 * ulp_f16(ref) + 2e-6).all()
+    if silu:
+        ref = F.silu(pre.float()).half()
+        assert ((h.float() - ref.float()).abs() <= 1.001 * ulp_f16(ref)).all()
+    # int8-only and fp16-only variants agree with the combined call
+    q2, none = C.groupnorm_silu_quantize(xd, G, t(gamma), t(beta), 1e-5, scal(s_inv), scal(zp),
+                                         silu=silu)
+    assert none is None and torch.equal(q2, q)
+    none, h2 = C.groupnorm_silu_quantize(xd, G, t(gamma), t(beta), 1e-5, silu=silu, want_f16=True)
+    assert none is None and torch.equal(h2, h)
+
+
+def test_groupnorm_equals_unfused_pipeline_on_its_own_fp16(C):
+    """quantize(fused fp16 output) == fused int8 output: the fusion only removes a round trip."""
+    x = t(dd.normal_f16(21, (2, 8, 8, 640), 2.0)).permute(0, 3, 1, 2)
+    g, b = t(dd.normal_f16(22, (640,), 1.0)), t(dd.normal_f16(23, (640,), 0.3))
+    s_inv, zp = scal(17.3), scal(5.0)
+    q, h = C.groupnorm_silu_quantize(x, 32, g, b, 1e-5, s_inv, zp, silu=True, want_f16=True)
+    assert torch.equal(C.quantize_per_tensor_to_int8(h, s_inv, zp), q)
+
+
+def test_groupnorm_unsupported_shapes_raise(C):
+    x = torch.zeros(1, 36, 4, 4, dtype=torch.float16, device=DEV).contiguous(
+        memory_format=torch.channels_last)
+    w = torch.ones(36, dtype=torch.float16, device=DEV)
+    assert not C.groupnorm_supported(1, 16, 36, 6)
+    with pytest.raises(RuntimeError, match="unsupported"):
+        C.groupnorm_silu_quantize(x, 6, w, w, 1e-5, scal(1), scal(0))
+
+
+LN_CASES = [(1024, 1280, 3), (4096, 640, 1), (77, 640, 2), (5, 64, 3), (3, 2048, 1), (1, 128, 0)]
+
+
+@pytest.mark.parametrize("M,Cc,nq", LN_CASES)
+def test_layernorm_quantize(C, oracle, M, Cc, nq):
+    x = (dd.normal_f16(31, (M, Cc), 1.2).astype(np.float32) + 0.4).astype(np.float16)
+    gamma = (dd.normal_f16(32, (Cc,), 0.3).astype(np.float32) + 1).astype(np.float16)
+    beta = dd.normal_f16(33, (Cc,), 0.2)
+    qp = [(float(np.float32(1) / np.float32(0.02 + 0.01 * i)), float(-7 + 11 * i)) for i in range(nq)]
+    outs, h = C.layernorm_quantize(t(x), t(gamma), t(beta), 1e-5,
+                                   [(scal(a), scal(b)) for a, b in qp], want_f16=True)
+    o_ref, h_ref = oracle.layernorm_quantize(x, gamma, beta, 1e-5, qp, C.FLAGS & 1)
+    assert np.array_equal(h.cpu().numpy().view(np.uint16), h_ref.view(np.uint16))
+    assert len(outs) == nq
+    for a, b in zip(outs, o_ref):
+        assert np.array_equal(a.cpu().numpy(), b)
+    ref = F.layer_norm(t(x).float(), (Cc,), t(gamma).float(), t(beta).float(), 1e-5).half()
+    assert ((h.float() - ref.float()).abs() <= 1.001 * ulp_f16(ref) + 2e-6).all()
+
+
+@pytest.mark.parametrize("M,D", [(1024, 5120), (4096, 2560), (7, 64), (1, 8)])
+def test_geglu_quantize(C, oracle, M, D):
+    hin = dd.normal_f16(41, (M, 2 * D), 2.0)
+    s_inv, zp = float(np.float32(1) / np.float32(0.05)), -100.0
+    q, o = C.geglu_quantize(t(hin), scal(s_inv), scal(zp), want_f16=True)
+    q_ref, o_ref = oracle.geglu_quantize(hin, s_inv, zp, C.FLAGS & 1)
+    assert np.array_equal(o.cpu().numpy().view(np.uint16), o_ref.view(np.uint16))
+    assert np.array_equal(q.cpu().numpy(), q_ref)
+    hd = t(hin)
+    ref = (hd[:, :D].float() * F.gelu(hd[:, D:].float()).half().float()).half()
+    # a 1-ulp difference of the FP16 GELU value, times x, then rounded again: up to 2 ulp
+    assert ((o.float() - ref.float()).abs() <= 2.001 * ulp_f16(ref)).all()
+
+
+def test_shared_math_spec_matches_on_device(C, oracle):
+    """include/mixdq_math.h evaluates identically under hipcc and gcc: drive SiLU / GELU through
+    the fused kernels with identity normalisation and compare with the host evaluation."""
+    L = oracle.lib()
+    vals = np.concatenate([np.linspace(-12, 12, 4001), [0.0, -0.0, 65504, -65504, 1e-4, -1e-4]]
+                          ).astype(np.float16)
+    n = (vals.size + 7) // 8 * 8
+    v = np.zeros(n, np.float16)
+    v[:vals.size] = vals
+    hin = np.concatenate([np.ones_like(v), v]).reshape(1, 2 * n)     # x = 1, gate = v
+    _, o = C.geglu_quantize(t(hin), want_f16=True)
+    with np.errstate(over="ignore"):
+        want = np.array([np.float16(L.mixdq_oracle_geluf(float(a))) for a in v], np.float16)
+    assert np.array_equal(o.cpu().numpy().reshape(-1).view(np.uint16), want.view(np.uint16))
