@@ -46,6 +46,8 @@ def parse_args():
     ap.add_argument("--a-config", default="act/act_8.00")
     ap.add_argument("--no-bos", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="eager launches (host-bound)")
+    ap.add_argument("--no-fuse", action="store_true",
+                    help="run the unfused drop-in graph (torch GroupNorm/LayerNorm/GELU + quantize)")
     ap.add_argument("--no-fp16", action="store_true", help="skip the FP16 comparison")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -261,6 +263,7 @@ def main():
 
     quantize_unet(unet, Cfg(cfgs.load(args.w_config), cfgs.load(args.a_config)), ckpt,
                   bos=not args.no_bos, bos_dict=bos_dict)
+    unet.set_fused(not args.no_fuse)
     bcast_bytes = shard.broadcast_module_state(unet, src=0)
     qmods = [m for m in unet.modules() if isinstance(m, (QuantizedLinear, QuantizedConv2d))]
     n_accel = sum(m.valid_for_acceleration for m in qmods)
@@ -292,7 +295,7 @@ def main():
             "global_batch": world * B, "per_gpu_batch": B, "px": args.px, "latent": L,
             "w_config": args.w_config, "a_config": args.a_config, "bos": not args.no_bos,
             "parallelism": f"dp{world} (batch-sharded replicas, no step-loop collective)",
-            "hip_graph": not args.no_graph,
+            "hip_graph": not args.no_graph, "producer_fusions": not args.no_fuse,
             "accelerated_layers": n_accel, "quantizable_layers": len(qmods),
             "epilogue_variant": "B" if C.FLAGS & 1 else "A",
         },

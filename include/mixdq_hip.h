@@ -86,16 +86,23 @@ int mixdq_qlinear_w8a8(const int8_t* A, const int8_t* W,
                        int64_t M, int N, int K,
                        int flags, mixdq_stream_t stream);
 
-/* Same GEMM with an output row map, used by QuantizedLinear's BOS path (nn/Linear.py:178-194)
- * to write rows straight into the [B, T, N] result instead of torch.cat:
- *   D_row(m) = (m / group_rows) * group_stride + group_offset + (m % group_rows)
- * (group_rows = T-1 = 76, group_stride = T = 77, group_offset = 1).  group_rows <= 0 = identity.
+/* Same GEMM with two extensions (no reference counterpart; both keep results bit-identical to the
+ * unfused sequence of reference ops + torch ops):
+ *  - an output row map, used by QuantizedLinear's BOS path (nn/Linear.py:178-194) to write rows
+ *    straight into the [B, T, N] result instead of torch.cat:
+ *      D_row(m) = (m / group_rows) * group_stride + group_offset + (m % group_rows)
+ *    (group_rows = T-1 = 76, group_stride = T = 77, group_offset = 1).  group_rows <= 0 = identity;
+ *  - a residual added after the epilogue's FP16 rounding, exactly as a following torch half add:
+ *      D[m,n] = f16( f32(f16(epilogue)) + f32(residual[(m / residual_row_div) * N + n]) )
+ *    residual_row_div = 1: a full [M,N] residual (x + attn(x), x + ff(x)); = P*Q: one row per
+ *    image (h + time_emb[:, :, None, None] after a conv).  Not combinable with a row map.
  */
 int mixdq_qlinear_w8a8_rows(const int8_t* A, const int8_t* W,
                             const float* bias0, const float* scale,
                             const void* bias_f16_or_null, void* D_f16,
                             int64_t M, int N, int K,
                             int group_rows, int group_stride, int group_offset,
+                            const void* residual_f16_or_null, int64_t residual_row_div,
                             int flags, mixdq_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -140,6 +147,7 @@ int mixdq_qconv2d_w8a8_table(const int8_t* X_nhwc, const int8_t* Wt_krsc,
                              const void* bias_f16_or_null, void* D_nhwc_f16,
                              int N, int H, int W, int C, int K, int R, int S,
                              int stride, int pad,
+                             const void* residual_f16_or_null, int64_t residual_row_div,
                              int flags, mixdq_stream_t stream);
 
 /* Stand-alone restatement of the reference's materialised zero-point propagation

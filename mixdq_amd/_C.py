@@ -39,12 +39,12 @@ _lib.mixdq_abi_version.restype = _i32
 _lib.mixdq_quantize_f16_i8.argtypes = [_vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp]
 _lib.mixdq_qlinear_w8a8.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]
 _lib.mixdq_qlinear_w8a8_rows.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32,
-                                         _i32, _i32, _i32, _i32, _vp]
+                                         _i32, _i32, _i32, _vp, _i64, _i32, _vp]
 _lib.mixdq_qconv2d_workspace_bytes.restype = _sz
 _lib.mixdq_qconv2d_workspace_bytes.argtypes = [_i32] * 4
 _lib.mixdq_qconv2d_w8a8.argtypes = [_vp] * 9 + [_i32] * 11 + [_vp]
 _lib.mixdq_conv_border_table.argtypes = [_vp, _vp, _i32, _i32, _i32, _vp]
-_lib.mixdq_qconv2d_w8a8_table.argtypes = [_vp] * 8 + [_i32] * 10 + [_vp]
+_lib.mixdq_qconv2d_w8a8_table.argtypes = [_vp] * 8 + [_i32] * 9 + [_vp, _i64, _i32, _vp]
 _lib.mixdq_conv_zero_point_propagate.argtypes = [_vp, _vp, _vp] + [_i32] * 8 + [_vp]
 _lib.mixdq_gemm_f16.argtypes = [_vp, _vp, _vp, _i64, _i32, _i32, _vp]
 for _n in ("mixdq_quantize_f16_i8", "mixdq_qlinear_w8a8", "mixdq_qlinear_w8a8_rows",
@@ -144,7 +144,7 @@ def quantize_per_tensor_to_int8_vectorized(input, scale_inv, zero_point):
 
 def qlinear_w8_a8_ohalf(input_int8, weight_int8, weight_scale, input_scale, input_zero_point,
                         weight_sum_by_input_channels, scale, bias0, bias=None, *,
-                        _out=None, _row_map=None, _cfg=0):
+                        _out=None, _row_map=None, _cfg=0, _residual=None, _residual_div=1):
     _check(input_int8.is_cuda, "Input should be on GPU.")
     dev = input_int8.device
     _check(dev == weight_int8.device, "input and weight_int8 should be on the same device.")
@@ -191,10 +191,15 @@ def qlinear_w8_a8_ohalf(input_int8, weight_int8, weight_scale, input_scale, inpu
     rm = _row_map or (0, 0, 0)
     sc, b0 = _f32vec(scale), _f32vec(bias0)
     bs = None if bias is None else bias.contiguous()
+    if _residual is not None:
+        _check(_residual.dtype == torch.float16 and _residual.is_contiguous()
+               and _residual.numel() == (M // _residual_div) * N,
+               "residual should be contiguous fp16 of M / residual_div rows")
     with torch.cuda.device(dev):
         code = _lib.mixdq_qlinear_w8a8_rows(a.data_ptr(), w.data_ptr(), b0.data_ptr(),
                                             sc.data_ptr(), _ptr(bs), D.data_ptr(), M, N, K,
-                                            rm[0], rm[1], rm[2], FLAGS | (_cfg << 8), _stream())
+                                            rm[0], rm[1], rm[2], _ptr(_residual), _residual_div,
+                                            FLAGS | (_cfg << 8), _stream())
     _status(code, "qlinear_w8_a8_ohalf")
     return D
 
@@ -209,7 +214,8 @@ def _conv_geometry(input_int8, weight_int8, stride, padding, dilation):
 
 def qconv2d_w8_a8_ohalf(input_int8, weight_int8, weight_scale, input_scale, input_zero_point,
                         scale, weight_sum_by_input_channels, bias0, bias=None, stride=1,
-                        padding=0, dilation=1, *, _table=None, _cfg=0):
+                        padding=0, dilation=1, *, _table=None, _cfg=0, _residual=None,
+                        _residual_per_image=False):
     stride = 1 if stride is None else int(stride)
     padding = 0 if padding is None else int(padding)
     dilation = 1 if dilation is None else int(dilation)
@@ -265,7 +271,18 @@ def qconv2d_w8_a8_ohalf(input_int8, weight_int8, weight_scale, input_scale, inpu
     sc = _f32vec(scale)
     bs = None if bias is None else bias.contiguous()
     with torch.cuda.device(dev):
-        if padding > 0 and _table is None:
+        res_ptr, res_div = None, 1
+        if _residual is not None:
+            _check(_residual.dtype == torch.float16, "residual should be fp16")
+            if _residual_per_image:       # [N, K] (or [N, K, 1, 1]) row per image
+                _check(_residual.is_contiguous() and _residual.numel() == N * K,
+                       "per-image residual should be contiguous [N, K]")
+                res_div = P * Q
+            else:                         # [N, K, P, Q] channels-last
+                _check(tuple(_residual.shape) == (N, K, P, Q) and _residual.is_contiguous(
+                    memory_format=torch.channels_last), "residual should be channels-last [N,K,P,Q]")
+            res_ptr = _residual.data_ptr()
+        if padding > 0 and _table is None and _residual is None:
             ws_bytes = _lib.mixdq_qconv2d_workspace_bytes(K, R, S, padding)
             workspace = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)
             code = _lib.mixdq_qconv2d_w8a8(
@@ -275,11 +292,14 @@ def qconv2d_w8_a8_ohalf(input_int8, weight_int8, weight_scale, input_scale, inpu
         else:
             _check(dilation == 1, "qconv2d_w8_a8_ohalf: unsupported configuration "
                                   "(dilation must be 1)")
+            if padding > 0 and _table is None:
+                _table = conv_border_table(wsum)
             b0 = None if padding > 0 else _f32vec(bias0)
             code = _lib.mixdq_qconv2d_w8a8_table(
                 x.data_ptr(), w.data_ptr(), sc.data_ptr(), _ptr(_table),
                 input_zero_point.data_ptr(), _ptr(b0), _ptr(bs), D.data_ptr(),
-                N, H, W, C, K, R, S, stride, padding, FLAGS | (_cfg << 8), _stream())
+                N, H, W, C, K, R, S, stride, padding, res_ptr, res_div, FLAGS | (_cfg << 8),
+                _stream())
     _status(code, "qconv2d_w8_a8_ohalf")
     return D
 

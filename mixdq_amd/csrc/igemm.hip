@@ -40,6 +40,8 @@ struct IgemmParams {
   int N, Ktot;
   int H, W, C, R, S, P, Q, stride, pad;   // conv geometry
   int grp_rows, grp_stride, grp_off;      // output row map (grp_rows <= 0: identity)
+  const __half* res;     // optional residual added AFTER the fp16 rounding of the epilogue:
+  int64_t res_div;       //   D = f16(f32(f16(epilogue)) + f32(res[(m / res_div) * N + n]))
   int tiles_m, tiles_n;
   int unfused;
 };
@@ -55,6 +57,16 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds(
       (const __attribute__((address_space(1))) void*)gsrc,
       (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// two packed fp16 + two packed fp16, each lane as torch's half add: f32 add, one rounding
+__device__ __forceinline__ uint32_t add_f16x2(uint32_t a, uint32_t b) {
+  __half_raw al, ah, bl, bh;
+  al.x = (unsigned short)(a & 0xffffu); ah.x = (unsigned short)(a >> 16);
+  bl.x = (unsigned short)(b & 0xffffu); bh.x = (unsigned short)(b >> 16);
+  const __half lo = f32_to_f16_rn(__fadd_rn(__half2float(__half(al)), __half2float(__half(bl))));
+  const __half hi = f32_to_f16_rn(__fadd_rn(__half2float(__half(ah)), __half2float(__half(bh))));
+  return (uint32_t)__half_as_ushort(lo) | ((uint32_t)__half_as_ushort(hi) << 16);
 }
 
 template <int BM, int BN, int BK, int STAGES, bool CONV>
@@ -299,7 +311,25 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         const int64_t gq = m / p.grp_rows;
         drow = gq * p.grp_stride + p.grp_off + (m - gq * p.grp_rows);
       }
-      const uint4 v = *reinterpret_cast<const uint4*>(Cs + row * CS_STRIDE + cc * 16);
+      uint4 v = *reinterpret_cast<const uint4*>(Cs + row * CS_STRIDE + cc * 16);
+      if (p.res != nullptr) {
+        const __half* rp = p.res + (m / p.res_div) * p.N + n;
+        uint32_t rw[4];
+        if (n8) {
+          const uint4 r = *reinterpret_cast<const uint4*>(rp);
+          rw[0] = r.x; rw[1] = r.y; rw[2] = r.z; rw[3] = r.w;
+        } else {
+          const uint2 r0 = *reinterpret_cast<const uint2*>(rp);
+          rw[0] = r0.x; rw[1] = r0.y; rw[2] = 0; rw[3] = 0;
+          if (n + 8 <= p.N) {
+            const uint2 r1 = *reinterpret_cast<const uint2*>(rp + 4);
+            rw[2] = r1.x; rw[3] = r1.y;
+          }
+        }
+        uint32_t* vw = reinterpret_cast<uint32_t*>(&v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vw[e] = add_f16x2(vw[e], rw[e]);
+      }
       __half* dst = p.D + drow * p.N + n;
       if (n8) {
         *reinterpret_cast<uint4*>(dst) = v;
@@ -357,8 +387,11 @@ __global__ __launch_bounds__(256) void igemm_generic_kernel(const IgemmParams p)
       drow = gq * p.grp_stride + p.grp_off + (m - gq * p.grp_rows);
     }
     const bool hb_ = p.bias != nullptr;
-    p.D[drow * p.N + n] = epilogue_one(acc, b0, p.scale[n], hb_ ? __half2float(p.bias[n]) : 0.f,
-                                       hb_, p.unfused != 0);
+    __half o = epilogue_one(acc, b0, p.scale[n], hb_ ? __half2float(p.bias[n]) : 0.f, hb_,
+                            p.unfused != 0);
+    if (p.res != nullptr)
+      o = f32_to_f16_rn(__fadd_rn(__half2float(o), __half2float(p.res[(m / p.res_div) * p.N + n])));
+    p.D[drow * p.N + n] = o;
   }
 }
 
@@ -492,7 +525,7 @@ int dispatch(IgemmParams& p, hipStream_t stream, int forced_cfg) {
   const bool ptr_ok = ((uintptr_t)p.A % 16 == 0) && ((uintptr_t)p.Wt % 16 == 0) &&
                       ((uintptr_t)p.D % 16 == 0) && ((uintptr_t)p.scale % 16 == 0) &&
                       ((uintptr_t)p.bias0 % 16 == 0) && ((uintptr_t)p.table % 16 == 0) &&
-                      ((uintptr_t)p.bias % 8 == 0);
+                      ((uintptr_t)p.bias % 8 == 0) && ((uintptr_t)p.res % 16 == 0);
   if (align_k % 16 != 0 || !ptr_ok) {
     int64_t blocks = (p.M * p.N + 255) / 256;
     if (blocks > kNumCU * 16) blocks = kNumCU * 16;
@@ -517,8 +550,9 @@ using namespace mixdq;
 extern "C" int mixdq_qlinear_w8a8_rows(const int8_t* A, const int8_t* W, const float* bias0,
                                        const float* scale, const void* bias_f16_or_null,
                                        void* D_f16, int64_t M, int N, int K, int group_rows,
-                                       int group_stride, int group_offset, int flags,
-                                       mixdq_stream_t stream) {
+                                       int group_stride, int group_offset,
+                                       const void* residual_f16_or_null, int64_t residual_row_div,
+                                       int flags, mixdq_stream_t stream) {
   if (M < 0 || N < 0 || K < 0) return MIXDQ_ERR_INVALID_ARG;
   if (M == 0 || N == 0) return MIXDQ_OK;
   if (!A || !W || !bias0 || !scale || !D_f16) return MIXDQ_ERR_INVALID_ARG;
@@ -528,6 +562,9 @@ extern "C" int mixdq_qlinear_w8a8_rows(const int8_t* A, const int8_t* W, const f
   p.M = M; p.N = N; p.Ktot = K;
   p.H = p.W = p.P = p.Q = 1; p.C = K; p.R = p.S = 1; p.stride = 1; p.pad = 0;
   p.grp_rows = group_rows; p.grp_stride = group_stride; p.grp_off = group_offset;
+  p.res = (const __half*)residual_f16_or_null;
+  p.res_div = residual_row_div > 0 ? residual_row_div : 1;
+  if (p.res && group_rows > 0) return MIXDQ_ERR_UNSUPPORTED;   // residual rows follow m, not D_row
   p.unfused = (flags & MIXDQ_FLAG_UNFUSED) ? 1 : 0;
   return dispatch<false>(p, (hipStream_t)stream, (flags >> 8) & 0xff);
 }
@@ -536,7 +573,7 @@ extern "C" int mixdq_qlinear_w8a8(const int8_t* A, const int8_t* W, const float*
                                   const float* scale, const void* bias_f16_or_null, void* D_f16,
                                   int64_t M, int N, int K, int flags, mixdq_stream_t stream) {
   return mixdq_qlinear_w8a8_rows(A, W, bias0, scale, bias_f16_or_null, D_f16, M, N, K, 0, 0, 0,
-                                 flags, stream);
+                                 nullptr, 1, flags, stream);
 }
 
 extern "C" size_t mixdq_qconv2d_workspace_bytes(int K, int R, int S, int pad) {
@@ -558,7 +595,9 @@ extern "C" int mixdq_qconv2d_w8a8_table(const int8_t* X, const int8_t* Wt, const
                                         const float* table_or_null, const float* zero_point,
                                         const float* bias0_or_null, const void* bias_f16_or_null,
                                         void* D, int N, int H, int W, int C, int K, int R, int S,
-                                        int stride, int pad, int flags, mixdq_stream_t stream) {
+                                        int stride, int pad, const void* residual_f16_or_null,
+                                        int64_t residual_row_div, int flags,
+                                        mixdq_stream_t stream) {
   if (N < 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || R <= 0 || S <= 0 || stride <= 0 || pad < 0)
     return MIXDQ_ERR_INVALID_ARG;
   if (!X || !Wt || !scale || !D) return MIXDQ_ERR_INVALID_ARG;
@@ -576,6 +615,8 @@ extern "C" int mixdq_qconv2d_w8a8_table(const int8_t* X, const int8_t* Wt, const
   p.M = (int64_t)N * P * Q; p.N = K; p.Ktot = R * S * C;
   p.H = H; p.W = W; p.C = C; p.R = R; p.S = S; p.P = P; p.Q = Q; p.stride = stride; p.pad = pad;
   p.grp_rows = 0; p.grp_stride = 0; p.grp_off = 0;
+  p.res = (const __half*)residual_f16_or_null;
+  p.res_div = residual_row_div > 0 ? residual_row_div : 1;
   p.unfused = (flags & MIXDQ_FLAG_UNFUSED) ? 1 : 0;
   return dispatch<true>(p, (hipStream_t)stream, (flags >> 8) & 0xff);
 }
@@ -595,8 +636,8 @@ extern "C" int mixdq_qconv2d_w8a8(const int8_t* X, const int8_t* Wt, const float
     table = (const float*)workspace;
   }
   return mixdq_qconv2d_w8a8_table(X, Wt, scale, table, zero_point, bias0_or_null,
-                                  bias_f16_or_null, D, N, H, W, C, K, R, S, stride, pad, flags,
-                                  stream);
+                                  bias_f16_or_null, D, N, H, W, C, K, R, S, stride, pad, nullptr, 1,
+                                  flags, stream);
 }
 
 extern "C" int mixdq_conv_zero_point_propagate(const float* wsum_krs, const float* zero_point,

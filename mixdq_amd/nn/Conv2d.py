@@ -160,13 +160,21 @@ class QuantizedConv2d(nn.Module):
             cache[key] = _C.conv_border_table(wsum)
         return cache[key]
 
-    def _conv(self, x_int, sfx, bias):
+    def forward_quantized(self, x_int, residual=None, residual_per_image=False):
+        """The conv half of forward() for an input already quantized with this layer's activation
+        qparams (not for split shortcuts).  `residual`: fp16 [N,K,P,Q] channels-last, or [N,K] with
+        residual_per_image (the time-embedding add), added after the epilogue's FP16 rounding."""
+        assert self.valid_for_acceleration and self.split == 0
+        return self._conv(x_int, "", self.bias, residual, residual_per_image)
+
+    def _conv(self, x_int, sfx, bias, residual=None, residual_per_image=False):
         return _C.qconv2d_w8_a8_ohalf(
             x_int, getattr(self, "weight_int" + sfx), getattr(self, "weight_scales" + sfx),
             getattr(self, "act_scales" + sfx), getattr(self, "act_zero_points" + sfx),
             getattr(self, "scale" + sfx), getattr(self, "weight_sum_by_input_channels" + sfx),
             getattr(self, "bias0" + sfx), bias, self.stride[0], self.padding[0], 1,
-            _table=self._border_table(sfx))
+            _table=self._border_table(sfx), _residual=residual,
+            _residual_per_image=residual_per_image)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if not self.valid_for_acceleration:

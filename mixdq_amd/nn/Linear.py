@@ -112,10 +112,17 @@ class QuantizedLinear(nn.Module):
         w = (self.weight_int.float() * self.weight_scales[:, None]).to(x.dtype)
         return F.linear(x, w, self.bias.to(x.dtype) if self.bias is not None else None)
 
-    def _gemm(self, x_int, out=None, row_map=None):
+    def _gemm(self, x_int, out=None, row_map=None, residual=None):
         return qlinear(x_int, self.weight_int, self.weight_scales, self.act_scales,
                        self.act_zero_points, self.weight_sum_by_input_channels, self.scale,
-                       self.bias0, self.bias, _out=out, _row_map=row_map)
+                       self.bias0, self.bias, _out=out, _row_map=row_map, _residual=residual)
+
+    def forward_quantized(self, x_int: torch.Tensor, residual=None) -> torch.Tensor:
+        """The GEMM half of forward() for an input that a fused producer already quantized with
+        this layer's (act_scales_inv, act_zero_points).  `residual` (fp16, same shape as the
+        output) is added after the epilogue's FP16 rounding, as a following `+` would."""
+        assert self.valid_for_acceleration and not getattr(self, "bos", False)
+        return self._gemm(x_int, residual=residual)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if not self.valid_for_acceleration:

@@ -24,6 +24,100 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+# ---------------------------------------------------------------------------------------------
+# Fused forward.  With `unet.fused = True` (set_fused) the glue that
+# feeds a W8A8 layer is replaced by the producer-fusion kernels of mixdq_amd/csrc/fused_norm.hip
+# and the residual adds move into the GEMM / conv epilogues.  Rounding points are those of the
+# unfused graph; the only numerical difference is this repo's GroupNorm / LayerNorm / SiLU / GELU
+# arithmetic (include/mixdq_math.h, fixed reduction order) instead of PyTorch's, i.e. at most
+# one FP16 ulp before quantization.  Off by default: the unfused graph is the drop-in path.
+# ---------------------------------------------------------------------------------------------
+def _accel(m) -> bool:
+    return bool(getattr(m, "valid_for_acceleration", False)) and not getattr(m, "bos", False) \
+        and getattr(m, "split", 0) == 0
+
+
+def _qp(m):
+    return (m.act_scales_inv, m.act_zero_points)
+
+
+def _same_qparams(a, b) -> bool:
+    """Host comparison of two layers' activation qparams (a device sync: cached by callers, and
+    only ever evaluated in the eager warm-up that precedes graph capture)."""
+    return bool(torch.equal(a.act_scales_inv, b.act_scales_inv)
+                and torch.equal(a.act_zero_points, b.act_zero_points))
+
+
+def _fusable_f16(x) -> bool:
+    return x.is_cuda and x.dtype == torch.float16
+
+
+def _gn_feed(norm: nn.GroupNorm, x, consumer, silu: bool):
+    """GroupNorm(+SiLU) of a channels-last fp16 x for `consumer`: returns (tensor, quantized?)."""
+    from mixdq_amd import _C
+    N, C, H, W = x.shape
+    if (_fusable_f16(x) and x.is_contiguous(memory_format=torch.channels_last)
+            and _C.groupnorm_supported(N, H * W, C, norm.num_groups)):
+        if _accel(consumer):
+            q, _ = _C.groupnorm_silu_quantize(x, norm.num_groups, norm.weight, norm.bias, norm.eps,
+                                              *_qp(consumer), silu=silu)
+            return q, True
+        _, h = _C.groupnorm_silu_quantize(x, norm.num_groups, norm.weight, norm.bias, norm.eps,
+                                          silu=silu, want_f16=True)
+        return h, False
+    h = norm(x)
+    return (F.silu(h) if silu else h), False
+
+
+def _ln_feed(norm: nn.LayerNorm, x, consumers):
+    """LayerNorm of x [B, T, C] for several consumer layers: one fused kernel produces an int8
+    tensor per distinct activation quantizer (and the fp16 tensor if some consumer needs it).
+    Returns a list of (tensor, quantized?) aligned with `consumers`."""
+    from mixdq_amd import _C
+    C = x.shape[-1]
+    if not (_fusable_f16(x) and x.is_contiguous() and C % 8 == 0 and C <= 2048):
+        h = norm(x)
+        return [(h, False)] * len(consumers)
+    plan = getattr(norm, "_mixdq_plan", None)
+    if plan is None or plan[0] != tuple(id(c) for c in consumers):
+        groups, slot = [], []          # distinct quantizers among the accelerated consumers
+        for c in consumers:
+            if not _accel(c):
+                slot.append(-1)
+                continue
+            for gi, rep in enumerate(groups):
+                if _same_qparams(rep, c):
+                    slot.append(gi)
+                    break
+            else:
+                groups.append(c)
+                slot.append(len(groups) - 1)
+        plan = (tuple(id(c) for c in consumers), groups, slot)
+        norm._mixdq_plan = plan
+    _, groups, slot = plan
+    want_f16 = any(s < 0 for s in slot)
+    outs, h = _C.layernorm_quantize(x, norm.weight, norm.bias, norm.eps, [_qp(g) for g in groups],
+                                    want_f16=want_f16)
+    return [((outs[s], True) if s >= 0 else (h, False)) for s in slot]
+
+
+def _run(layer, feed, residual=None):
+    """Run a Linear on a (tensor, quantized?) feed; fold `residual` into the epilogue if possible."""
+    t, quantized = feed
+    if quantized:
+        return layer.forward_quantized(t, residual=residual)
+    y = layer(t)
+    return y if residual is None else y + residual
+
+
+def _linear_res(layer, x, residual):
+    """layer(x) + residual with the add folded into the GEMM epilogue when the layer is W8A8."""
+    if _accel(layer) and _fusable_f16(x) and residual.is_contiguous():
+        from mixdq_amd.nn.Linear import quant_op
+        return layer.forward_quantized(quant_op(x, *_qp(layer)), residual=residual)
+    return layer(x) + residual
+
+
 SDXL_CONFIG = dict(
     in_channels=4, out_channels=4,
     block_out_channels=(320, 640, 1280),
@@ -71,13 +165,31 @@ class ResnetBlock2D(nn.Module):
             # activation scales for the two halves (quant_block_forward_func.py:153-157)
             self.conv_shortcut.split = split
 
+    fused = False
+
     def forward(self, x, temb):
+        if self.fused and _fusable_f16(x):
+            return self.forward_fused(x, temb)
         h = self.conv1(F.silu(self.norm1(x)))
         h = h + self.time_emb_proj(F.silu(temb))[:, :, None, None]
         h = self.conv2(F.silu(self.norm2(h)))
         if self.conv_shortcut is not None:
             x = self.conv_shortcut(x)
         return x + h
+
+    def forward_fused(self, x, temb):
+        t = self.time_emb_proj(F.silu(temb))                       # [N, Cout]
+        feed, q = _gn_feed(self.norm1, x, self.conv1, silu=True)
+        if q:   # h = conv1(..) + t[:, :, None, None], the add folded into the conv epilogue
+            h = self.conv1.forward_quantized(feed, residual=t.contiguous(), residual_per_image=True)
+        else:
+            h = self.conv1(feed) + t[:, :, None, None]
+        if self.conv_shortcut is not None:
+            x = self.conv_shortcut(x)
+        feed, q = _gn_feed(self.norm2, h, self.conv2, silu=True)
+        if q and x.is_contiguous(memory_format=torch.channels_last):
+            return self.conv2.forward_quantized(feed, residual=x)  # x + conv2(..)
+        return x + self.conv2(feed)
 
 
 class Attention(nn.Module):
@@ -92,13 +204,16 @@ class Attention(nn.Module):
 
     def forward(self, x, context=None):
         context = x if context is None else context
-        B, T, C = x.shape
+        return self.to_out[0](self.attend(self.to_q(x), self.to_k(context), self.to_v(context)))
+
+    def attend(self, q, k, v):
+        B, T, C = q.shape
         h = self.heads
-        q = self.to_q(x).view(B, T, h, C // h).transpose(1, 2)
-        k = self.to_k(context).view(B, -1, h, C // h).transpose(1, 2)
-        v = self.to_v(context).view(B, -1, h, C // h).transpose(1, 2)
+        q = q.view(B, T, h, C // h).transpose(1, 2)
+        k = k.view(B, -1, h, C // h).transpose(1, 2)
+        v = v.view(B, -1, h, C // h).transpose(1, 2)
         o = F.scaled_dot_product_attention(q, k, v)   # FP16, as in the reference
-        return self.to_out[0](o.transpose(1, 2).reshape(B, T, C))
+        return o.transpose(1, 2).reshape(B, T, C)
 
 
 class GEGLU(nn.Module):
@@ -119,6 +234,22 @@ class FeedForward(nn.Module):
     def forward(self, x):
         return self.net[2](self.net[0](x))
 
+    def forward_fused(self, feed, residual):
+        """residual + net2(geglu(proj(feed))): GEGLU fused with net.2's quantizer, the residual add
+        folded into net.2's epilogue."""
+        from mixdq_amd import _C
+        h = _run(self.net[0].proj, feed)
+        out_layer = self.net[2]
+        D = h.shape[-1] // 2
+        if _fusable_f16(h) and h.is_contiguous() and D % 8 == 0:
+            if _accel(out_layer):
+                q, _ = _C.geglu_quantize(h, *_qp(out_layer))
+                return out_layer.forward_quantized(q, residual=residual)
+            _, g = _C.geglu_quantize(h, want_f16=True)
+            return out_layer(g) + residual
+        a, gate = h.chunk(2, dim=-1)
+        return out_layer(a * F.gelu(gate)) + residual
+
 
 class BasicTransformerBlock(nn.Module):
     def __init__(self, dim, cross_dim, head_dim):
@@ -130,10 +261,27 @@ class BasicTransformerBlock(nn.Module):
         self.norm3 = nn.LayerNorm(dim)
         self.ff = FeedForward(dim)
 
+    fused = False
+
     def forward(self, x, context):
+        if self.fused and _fusable_f16(x):
+            return self.forward_fused(x, context)
         x = x + self.attn1(self.norm1(x))
         x = x + self.attn2(self.norm2(x), context)
         return x + self.ff(self.norm3(x))
+
+    def forward_fused(self, x, context):
+        x = x.contiguous()
+        a = self.attn1
+        fq, fk, fv = _ln_feed(self.norm1, x, [a.to_q, a.to_k, a.to_v])
+        o = a.attend(_run(a.to_q, fq), _run(a.to_k, fk), _run(a.to_v, fv))
+        x = _linear_res(a.to_out[0], o, x)                          # x + attn1(norm1(x))
+        a = self.attn2
+        (fq,) = _ln_feed(self.norm2, x, [a.to_q])
+        o = a.attend(_run(a.to_q, fq), a.to_k(context), a.to_v(context))   # K/V: BOS path
+        x = _linear_res(a.to_out[0], o, x)                          # x + attn2(norm2(x), ctx)
+        (ff,) = _ln_feed(self.norm3, x, [self.ff.net[0].proj])
+        return self.ff.forward_fused(ff, x)                         # x + ff(norm3(x))
 
 
 class Transformer2DModel(nn.Module):
@@ -145,9 +293,20 @@ class Transformer2DModel(nn.Module):
             [BasicTransformerBlock(dim, cross_dim, head_dim) for _ in range(depth)])
         self.proj_out = nn.Linear(dim, dim)
 
+    fused = False
+
     def forward(self, x, context):
         B, C, H, W = x.shape
         res = x
+        if self.fused and _fusable_f16(x) and x.is_contiguous(memory_format=torch.channels_last):
+            feed, q = _gn_feed(self.norm, x, self.proj_in, silu=False)
+            feed = feed.permute(0, 2, 3, 1).reshape(B, H * W, C)    # NHWC memory == [B, HW, C]
+            h = _run(self.proj_in, (feed, q))
+            for blk in self.transformer_blocks:
+                h = blk(h, context)
+            res_rows = res.permute(0, 2, 3, 1).reshape(B, H * W, C)
+            h = _linear_res(self.proj_out, h, res_rows)             # proj_out(h) + res
+            return h.reshape(B, H, W, C).permute(0, 3, 1, 2)
         h = self.norm(x).permute(0, 2, 3, 1).reshape(B, H * W, C)   # free when channels-last
         h = self.proj_in(h)
         for blk in self.transformer_blocks:
@@ -282,9 +441,14 @@ class SDXLUNet(nn.Module):
         self.conv_norm_out = nn.GroupNorm(cfg["norm_num_groups"], boc[0], eps=1e-5)
         self.conv_out = nn.Conv2d(boc[0], cfg["out_channels"], 3, 1, 1)
 
-    @property
-    def sample_size_for(self):
-        return {512: 64, 1024: 128}
+    fused = False
+
+    def set_fused(self, enabled: bool = True):
+        """Switch the producer fusions on or off for the whole graph (see the top of this file)."""
+        for m in self.modules():
+            if hasattr(type(m), "fused"):
+                m.fused = bool(enabled)
+        return self
 
     def forward(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None,
                 return_dict=False):
@@ -311,7 +475,11 @@ class SDXLUNet(nn.Module):
         x = self.mid_block(x, emb, encoder_hidden_states)
         for blk in self.up_blocks:
             x = blk(x, skips, emb, encoder_hidden_states)
-        x = self.conv_out(F.silu(self.conv_norm_out(x)))
+        if self.fused and _fusable_f16(x):
+            feed, q = _gn_feed(self.conv_norm_out, x, self.conv_out, silu=True)
+            x = self.conv_out.forward_quantized(feed) if q else self.conv_out(feed)
+        else:
+            x = self.conv_out(F.silu(self.conv_norm_out(x)))
         return (x,)
 
 

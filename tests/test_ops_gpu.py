@@ -408,3 +408,58 @@ def test_ops_are_graph_capturable(C, oracle):
     want = oracle.qlinear(oracle.quantize(x2, 20.0, 4.0, C.FLAGS & 1), w, b0, sc, None,
                           C.FLAGS & 1)
     assert_bits_equal(y_static.cpu().numpy(), want, "graph replay")
+
+
+# -------------------------------------------------------------- residual folded into the epilogue
+def test_qlinear_residual_epilogue(C, oracle):
+    """D = f16(f16(epilogue) + residual): identical to the op followed by torch's half add."""
+    M, K, N = 150, 128, 72
+    a, w = dd.int8(61, (M, K)), dd.int8(62, (N, K))
+    b0, sc = dd.f32(63, (N,), -50, 50), dd.f32(64, (N,), 0.001, 0.01)
+    bias, res = dd.f16(65, (N,), -1, 1), dd.normal_f16(66, (M, N), 3.0)
+    args = (t(a), t(w), t(sc), scal(1), scal(0), t(b0), t(sc), t(b0), t(bias))
+    plain = C.qlinear_w8_a8_ohalf(*args)
+    fused = C.qlinear_w8_a8_ohalf(*args, _residual=t(res))
+    assert torch.equal(fused, plain + t(res))
+    want = oracle.add_f16(oracle.qlinear(a, w, b0, sc, bias, C.FLAGS & 1), res)
+    assert_bits_equal(fused.cpu().numpy(), want, "residual epilogue")
+    for cfg in (1, 4, 7):
+        assert torch.equal(C.qlinear_w8_a8_ohalf(*args, _residual=t(res), _cfg=cfg), fused)
+
+
+def test_qconv2d_residual_epilogue(C, oracle):
+    case = next(c for c in CONV_CASES if c[0] == "conv_res_320")
+    name, n, h, w_, c, k, r, s, pad, stride, has_bias, rng, seed = case
+    x, wt, wscale, in_scale, in_zp, bias, scale, wsum, bias0 = conv_inputs(case)
+    xin, win = t(x).permute(0, 3, 1, 2), t(wt).permute(0, 3, 1, 2)
+    args = (xin, win, t(wscale), scal(in_scale), scal(in_zp), t(scale),
+            t(wsum.reshape(k, 1, r, s)), None, t(bias), stride, pad)
+    plain = C.qconv2d_w8_a8_ohalf(*args)
+    res = t(dd.normal_f16(71, (n, h, w_, k), 2.0)).permute(0, 3, 1, 2)     # channels-last
+    assert torch.equal(C.qconv2d_w8_a8_ohalf(*args, _residual=res), plain + res)
+    per_img = t(dd.normal_f16(72, (n, k), 2.0))                            # time-embedding add
+    assert torch.equal(C.qconv2d_w8_a8_ohalf(*args, _residual=per_img, _residual_per_image=True),
+                       plain + per_img[:, :, None, None])
+
+
+@pytest.mark.parametrize("cfg", sorted(__import__("mixdq_amd._C", fromlist=["x"]).IGEMM_CONFIGS)
+                         if torch.cuda.is_available() else [])
+def test_every_kernel_configuration_is_bit_exact(C, oracle, cfg):
+    """All tile / stage configurations of the igemm family give the oracle's bits (linear with a
+    ragged M, K tail for BK = 128; padded conv with odd spatial size)."""
+    M, K, N = 203, 1232, 136          # K % 128 != 0, N % 64 != 0
+    a, w = dd.int8(81, (M, K)), dd.int8(82, (N, K))
+    b0, sc = dd.f32(83, (N,), -500, 500), dd.f32(84, (N,), 1e-4, 1e-3)
+    bias = dd.f16(85, (N,), -1, 1)
+    out = C.qlinear_w8_a8_ohalf(t(a), t(w), t(sc), scal(1), scal(0), t(b0), t(sc), t(b0), t(bias),
+                                _cfg=cfg)
+    assert_bits_equal(out.cpu().numpy(), oracle.qlinear(a, w, b0, sc, bias, C.FLAGS & 1),
+                      f"linear cfg {cfg}")
+    case = next(c for c in CONV_CASES if c[0] == "conv_s2_odd")
+    name, n, h, w_, c, k, r, s, pad, stride, has_bias, rng, seed = case
+    x, wt, wscale, in_scale, in_zp, bias, scale, wsum, bias0 = conv_inputs(case)
+    out = C.qconv2d_w8_a8_ohalf(t(x).permute(0, 3, 1, 2), t(wt).permute(0, 3, 1, 2), t(wscale),
+                                scal(in_scale), scal(in_zp), t(scale), t(wsum.reshape(k, 1, r, s)),
+                                None, t(bias), stride, pad, _cfg=cfg)
+    want = oracle.qconv2d(x, wt, scale, wsum, in_zp, None, bias, stride, pad, C.FLAGS & 1)
+    assert_bits_equal(out.permute(0, 2, 3, 1).contiguous().cpu().numpy(), want, f"conv cfg {cfg}")
