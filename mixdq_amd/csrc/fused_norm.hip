@@ -94,22 +94,34 @@ __global__ void gn_stats_kernel(const __half* __restrict__ x, float2* __restrict
   }
 }
 
-__global__ void gn_finalize_kernel(const float2* __restrict__ partial, float2* __restrict__ stats,
-                                   GnGeom g, float eps) {
-  const int n = blockIdx.x, t = threadIdx.x;
-  if (t >= g.G) return;
+// One 64-lane wave per (group, image): lane l sums the chunk partials l, l + 64, ... in order,
+// then a 6-step xor butterfly (every lane ends with the same bits).  Fixed order.
+__device__ __forceinline__ float wave_sum_gn(float v) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) v = __fadd_rn(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float2* __restrict__ partial,
+                                                         float2* __restrict__ stats, GnGeom g,
+                                                         float eps) {
+  const int grp = blockIdx.x, n = blockIdx.y, lane = threadIdx.x;
   float s = 0.f, q = 0.f;
-  for (int c = 0; c < g.nchunk; ++c) {
-    const float2 v = partial[((int64_t)n * g.nchunk + c) * g.G + t];
+  for (int c = lane; c < g.nchunk; c += 64) {
+    const float2 v = partial[((int64_t)n * g.nchunk + c) * g.G + grp];
     s = __fadd_rn(s, v.x);
     q = __fadd_rn(q, v.y);
   }
-  const float cnt = (float)((double)g.HW * g.cg);
-  const float mean = s / cnt;
-  float var = __builtin_fmaf(-mean, mean, q / cnt);
-  var = fmaxf(var, 0.f);
-  const float rstd = 1.0f / sqrtf(__fadd_rn(var, eps));
-  stats[(int64_t)n * g.G + t] = make_float2(mean, rstd);
+  s = wave_sum_gn(s);
+  q = wave_sum_gn(q);
+  if (lane == 0) {
+    const float cnt = (float)((double)g.HW * g.cg);
+    const float mean = s / cnt;
+    float var = __builtin_fmaf(-mean, mean, q / cnt);
+    var = fmaxf(var, 0.f);
+    const float rstd = 1.0f / sqrtf(__fadd_rn(var, eps));
+    stats[(int64_t)n * g.G + grp] = make_float2(mean, rstd);
+  }
 }
 
 template <bool SILU, bool UNFUSED>
@@ -317,7 +329,7 @@ extern "C" int mixdq_groupnorm_silu_quantize(const void* x_nhwc, const void* gam
   const dim3 grid(g.nchunk, N);
   gn_stats_kernel<<<grid, threads, threads * 4 * sizeof(float), stream>>>((const __half*)x_nhwc,
                                                                            partial, g);
-  gn_finalize_kernel<<<N, 64, 0, stream>>>(partial, stats, g, eps);
+  gn_finalize_kernel<<<dim3(G, N), 64, 0, stream>>>(partial, stats, g, eps);
   const bool unfused = flags & MIXDQ_FLAG_UNFUSED;
 #define GN_APPLY(S, U)                                                                          \
   gn_apply_kernel<S, U><<<grid, threads, 0, stream>>>(                                          \

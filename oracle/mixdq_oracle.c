@@ -255,6 +255,16 @@ void mixdq_oracle_gemm_f16(const uint16_t* A, const uint16_t* B, uint16_t* D, in
 
 static float rh(float v) { return h2f(f2h(v)); } /* round to fp16 and back */
 
+/* 64-lane xor butterfly: all lanes end with the same bits; returns lane 0. */
+static float wave_sum64(float* v) {
+  for (int off = 32; off >= 1; off >>= 1) {
+    float t[64];
+    for (int l = 0; l < 64; l++) t[l] = v[l] + v[l ^ off];
+    for (int l = 0; l < 64; l++) v[l] = t[l];
+  }
+  return v[0];
+}
+
 /* Geometry rule of make_gn_geom() (fused_norm.hip): returns 0 if unsupported. */
 static int gn_geom(int N, int64_t HW, int C, int G, int* cg, int* OC, int* PP, int* ppb,
                    int* nchunk) {
@@ -312,9 +322,14 @@ int mixdq_oracle_groupnorm_stats(const uint16_t* x, float eps, float* mean, floa
         pq[(size_t)chunk * G + g] = q;
       }
     }
-    for (int g = 0; g < G; g++) { /* gn_finalize_kernel */
-      float s = 0, q = 0;
-      for (int c = 0; c < nchunk; c++) { s = s + ps[(size_t)c * G + g]; q = q + pq[(size_t)c * G + g]; }
+    for (int g = 0; g < G; g++) { /* gn_finalize_kernel: lane partials + xor butterfly */
+      float ls[64], lq[64];
+      for (int l = 0; l < 64; l++) {
+        float a = 0, b = 0;
+        for (int c = l; c < nchunk; c += 64) { a = a + ps[(size_t)c * G + g]; b = b + pq[(size_t)c * G + g]; }
+        ls[l] = a; lq[l] = b;
+      }
+      float s = wave_sum64(ls), q = wave_sum64(lq);
       float cnt = (float)((double)HW * cg);
       float m = s / cnt;
       float var = fmaf(-m, m, q / cnt);
@@ -356,14 +371,6 @@ int mixdq_oracle_groupnorm_silu_quantize(const uint16_t* x, const uint16_t* gamm
 }
 
 /* ln_quant_kernel: one 64-lane wave per row, lane l owns chunks l, l+64, ...; xor butterfly. */
-static float wave_sum64(float* v) {
-  for (int off = 32; off >= 1; off >>= 1) {
-    float t[64];
-    for (int l = 0; l < 64; l++) t[l] = v[l] + v[l ^ off];
-    for (int l = 0; l < 64; l++) v[l] = t[l];
-  }
-  return v[0];
-}
 
 void mixdq_oracle_layernorm_quantize(const uint16_t* x, const uint16_t* gamma, const uint16_t* beta,
                                      float eps, int64_t M, int C, int n_out, const float* s_inv,

@@ -120,8 +120,11 @@ def test_geglu_quantize(C, oracle, M, D):
     assert np.array_equal(q.cpu().numpy(), q_ref)
     hd = t(hin)
     ref = (hd[:, :D].float() * F.gelu(hd[:, D:].float()).half().float()).half()
-    # a 1-ulp difference of the FP16 GELU value, times x, then rounded again: up to 2 ulp
-    assert ((o.float() - ref.float()).abs() <= 2.001 * ulp_f16(ref)).all()
+    # a 1-ulp difference of the FP16 GELU value, times x, then rounded again: up to 2 ulp; plus,
+    # for gate << 0, 1 + erf(gate / sqrt 2) cancels, so ANY FP32 erf (PyTorch's included) carries an
+    # absolute error ~1e-7 * |gate| that is several ulps of the tiny result
+    atol = 4e-7 * hd[:, :D].float().abs() * hd[:, D:].float().abs().clamp(min=1.0)
+    assert ((o.float() - ref.float()).abs() <= 2.001 * ulp_f16(ref) + atol).all()
 
 
 def test_shared_math_spec_matches_on_device(C, oracle):
