@@ -139,7 +139,7 @@ def roofline_sweep(unet, shapes, device, reps):
                 P = (shp[2] + 2 * mod.padding[0] - R) // mod.stride[0] + 1
                 Q = (shp[3] + 2 * mod.padding[0] - S) // mod.stride[0] + 1
                 M, N, K = shp[0] * P * Q, mod.out_channels, R * S * cin
-                bm, bn, bk, st = C.igemm_select(M, N, cin)
+                bm, bn, bk, st = C.igemm_select(M, N, cin, K)
                 calls.append((f"igemm_kernel<{bm},{bn},{bk},{st},conv>", 2.0 * M * N * K,
                               lambda mod=mod, x=x, sfx=sfx: mod._conv(x, sfx, None)))
     # Group the launches by kernel instantiation, capture each group (model order) in a hipGraph so

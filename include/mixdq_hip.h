@@ -202,11 +202,12 @@ int mixdq_geglu_quantize(const void* h_f16, int64_t M, int D,
                          mixdq_stream_t stream);
 
 /* Which kernel instantiation mixdq_qlinear_w8a8 / mixdq_qconv2d_w8a8 will launch for a problem of
- * M rows x N output channels (k_align = K for Linear, C for Conv2d): the block tile BM x BN x BK
+ * M rows x N output channels (k_align = K for Linear, C for Conv2d; k_total = K or R*S*C): the block tile BM x BN x BK
  * and LDS stage count of `igemm_kernel<BM,BN,BK,STAGES,CONV>`, or zeros for the small-alignment
  * generic kernel.  Host-only
  * query, used by bench.py to attribute measured time to kernel names.  No reference counterpart. */
-int mixdq_igemm_select(int64_t M, int N, int k_align, int* bm, int* bn, int* bk, int* stages);
+int mixdq_igemm_select(int64_t M, int N, int k_align, int k_total, int* bm, int* bn, int* bk,
+                       int* stages);
 
 #ifdef __cplusplus
 }

@@ -52,17 +52,18 @@ for _n in ("mixdq_quantize_f16_i8", "mixdq_qlinear_w8a8", "mixdq_qlinear_w8a8_ro
            "mixdq_conv_zero_point_propagate", "mixdq_gemm_f16"):
     getattr(_lib, _n).restype = _i32
 
-_lib.mixdq_igemm_select.argtypes = [_i64, _i32, _i32, _vp, _vp, _vp, _vp]
+_lib.mixdq_igemm_select.argtypes = [_i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp]
 _lib.mixdq_igemm_select.restype = _i32
 
 ABI_VERSION = _lib.mixdq_abi_version()
 
 
-def igemm_select(M: int, N: int, k_align: int):
+def igemm_select(M: int, N: int, k_align: int, k_total: int = 0):
     """(BM, BN, BK, STAGES) of the igemm_kernel instantiation used for this problem; zeros =
     the generic small-alignment kernel."""
     bm, bn, bk, st = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
-    _status(_lib.mixdq_igemm_select(M, N, k_align, ctypes.byref(bm), ctypes.byref(bn),
+    _status(_lib.mixdq_igemm_select(M, N, k_align, k_total or k_align, ctypes.byref(bm),
+                                    ctypes.byref(bn),
                                     ctypes.byref(bk), ctypes.byref(st)), "igemm_select")
     return bm.value, bn.value, bk.value, st.value
 
@@ -71,7 +72,10 @@ def igemm_select(M: int, N: int, k_align: int):
 IGEMM_CONFIGS = {1: (64, 64, 64, 2), 2: (64, 128, 64, 2), 3: (128, 128, 64, 2),
                  4: (64, 64, 128, 3), 5: (64, 64, 128, 4), 6: (64, 128, 128, 3),
                  7: (128, 128, 128, 3), 8: (128, 128, 64, 4), 9: (64, 64, 64, 4),
-                 10: (128, 64, 128, 3), 11: (64, 128, 128, 4), 12: (128, 128, 128, 4)}
+                 10: (128, 64, 128, 3), 11: (64, 128, 128, 4), 12: (128, 128, 128, 4),
+                 13: (256, 128, 64, 3), 14: (256, 256, 64, 3), 15: (128, 256, 64, 3),
+                 16: (256, 128, 64, 2), 17: (256, 256, 64, 2), 18: (256, 128, 128, 2),
+                 19: (128, 128, 64, 3), 20: (256, 256, 128, 2)}
 
 # Rounding variant of the fused multiply-adds: "A" (default) = FMA,
 # "B" = separate multiply and add.  Read once at import; no other global state.

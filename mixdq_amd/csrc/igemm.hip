@@ -59,27 +59,45 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
       (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-// two packed fp16 + two packed fp16, each lane as torch's half add: f32 add, one rounding
-__device__ __forceinline__ uint32_t add_f16x2(uint32_t a, uint32_t b) {
-  __half_raw al, ah, bl, bh;
-  al.x = (unsigned short)(a & 0xffffu); ah.x = (unsigned short)(a >> 16);
-  bl.x = (unsigned short)(b & 0xffffu); bh.x = (unsigned short)(b >> 16);
-  const __half lo = f32_to_f16_rn(__fadd_rn(__half2float(__half(al)), __half2float(__half(bl))));
-  const __half hi = f32_to_f16_rn(__fadd_rn(__half2float(__half(ah)), __half2float(__half(bh))));
-  return (uint32_t)__half_as_ushort(lo) | ((uint32_t)__half_as_ushort(hi) << 16);
+template <int BM, int BN, int BK, int STAGES>
+constexpr int igemm_main_bytes() {   // K-tile stages, overlaid by the epilogue's fp16 tile
+  return (STAGES * (BM + BN) * BK > BM * (BN * 2 + 16)) ? STAGES * (BM + BN) * BK
+                                                        : BM * (BN * 2 + 16);
+}
+template <int BM, int BN, int BK, int STAGES>
+constexpr int igemm_smem_bytes() {   // + the per-channel epilogue vectors: bias0, scale, bias
+  return igemm_main_bytes<BM, BN, BK, STAGES>() + BN * 12;
 }
 
-template <int BM, int BN, int BK, int STAGES, bool CONV>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
-  constexpr int WTM = BM / 2, WTN = BN / 2;       // wave tile (2 x 2 waves)
+// two packed fp16 + two packed fp16, each lane as torch's half add: f32 add, one rounding
+__device__ __forceinline__ uint32_t add_f16x2(uint32_t a, uint32_t b) {
+  const v2h ah = *reinterpret_cast<const v2h*>(&a), bh = *reinterpret_cast<const v2h*>(&b);
+  v2f r = __builtin_convertvector(ah, v2f) + __builtin_convertvector(bh, v2f);
+  asm("" : "+v"(r));
+  const v2h h = __builtin_convertvector(r, v2h);
+  return *reinterpret_cast<const uint32_t*>(&h);
+}
+
+// FAST (Linear only): K % BK == 0 and every operand offset fits 32 bits.  Then the staging needs
+// no per-K-tile vector arithmetic at all: each lane keeps one constant 32-bit byte offset per
+// DMA piece and the K-tile advance is a scalar add on the uniform base pointer (saddr form of
+// global_load_lds).  Rows past M / N are clamped to the last valid row instead of reading the
+// zero page: their accumulators are never stored.
+template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool CONV, bool FAST>
+__global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p) {
+  static_assert(!(CONV && FAST), "the fast staging path is for Linear");
+  constexpr int NWAVES = WM * WN, NTHREADS = 64 * NWAVES;
+  constexpr int WTM = BM / WM, WTN = BN / WN;     // wave tile (WM x WN waves)
   constexpr int TM = WTM / 32, TN = WTN / 32;     // 32x32 MFMA tiles per wave
   constexpr int A_STAGE = BM * BK, B_STAGE = BN * BK, STAGE = A_STAGE + B_STAGE;
-  constexpr int A_NI = A_STAGE / 1024 / 4;        // LDS-DMA instructions per wave per stage
-  constexpr int B_NI = B_STAGE / 1024 / 4;
+  constexpr int A_NI = A_STAGE / 1024 / NWAVES;   // LDS-DMA instructions per wave per stage
+  constexpr int B_NI = B_STAGE / 1024 / NWAVES;
   constexpr int CS_STRIDE = BN * 2 + 16;          // epilogue tile row stride (bytes)
   constexpr int NI = A_NI + B_NI;                 // ... in total: the unit of the vmcnt count
   constexpr int PRE = STAGES - 1;                 // K-tiles in flight ahead of the one computed
-  static_assert(A_NI >= 1 && B_NI >= 1, "tile too small for 4 waves of 1-KiB DMA pieces");
+  static_assert(A_NI >= 1 && B_NI >= 1 && A_NI * 1024 * NWAVES == A_STAGE &&
+                    B_NI * 1024 * NWAVES == B_STAGE,
+                "each wave must stage a whole number of 1-KiB DMA pieces per operand");
   static_assert(TM >= 1 && TN >= 1, "wave tile must hold a 32x32 MFMA tile");
   static_assert(STAGES >= 2 && (PRE - 1) * NI <= 63, "vmcnt is a 6-bit counter");
   extern __shared__ __attribute__((aligned(16))) char smem[];   // igemm_smem_bytes<...>()
@@ -87,15 +105,25 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid >> 1, wn = wid & 1;
+  const int wm = wid / WN, wn = wid % WN;
 
-  // ---- XCD-aware tile map: the blocks of one XCD (bid % 8) get a contiguous run of tiles,
-  //      m fastest, so neighbours share the weight panel in that XCD's L2 (bijective form).
+  // ---- XCD- and L2-aware tile map.  Blocks are dealt round-robin over the 8 XCDs (bid % 8), each
+  //      with its own 4 MiB L2: give every XCD a contiguous run of the tile sequence (bijective
+  //      remap), and order that sequence in super-rows of GM m-tiles (m fastest inside, then n),
+  //      so the ~100 blocks an XCD runs at once cover a near-square patch of the output and share
+  //      both their activation rows and their weight panels in that L2 instead of streaming all
+  //      of A for every column of tiles.
   const int nwg = gridDim.x;
   const int bid = blockIdx.x;
   const int xcd = bid % kNumXCD, q8 = nwg / kNumXCD, r8 = nwg % kNumXCD;
   const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / kNumXCD;
-  const int tile_n = wg / p.tiles_m, tile_m = wg - tile_n * p.tiles_m;
+  constexpr int GM = 8;
+  const int per_group = GM * p.tiles_n;
+  const int group = wg / per_group;
+  const int first_m = group * GM;
+  const int gsz = min(GM, p.tiles_m - first_m);
+  const int rem = wg - group * per_group;
+  const int tile_n = rem / gsz, tile_m = first_m + (rem - tile_n * gsz);
   const int64_t m0 = (int64_t)tile_m * BM;
   const int n0 = tile_n * BN;
 
@@ -138,6 +166,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   const int8_t* b_base[B_NI];
   int b_k[B_NI];
   bool b_ok[B_NI];
+  uint32_t a_off32[A_NI], b_off32[B_NI];   // FAST: constant per-lane byte offsets
 #pragma unroll
   for (int j = 0; j < B_NI; ++j) {
     const int byte = (wid * B_NI + j) * 1024 + lane * 16;
@@ -147,11 +176,31 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     b_ok[j] = n < p.N;
     b_base[j] = p.Wt + (int64_t)n * Ktot + lc * 16;
     b_k[j] = lc * 16;
+    b_off32[j] = (uint32_t)min(n, p.N - 1) * (uint32_t)Ktot + lc * 16;
+  }
+#pragma unroll
+  for (int j = 0; j < A_NI; ++j) {
+    const int byte = (wid * A_NI + j) * 1024 + lane * 16;
+    const int row = byte / BK;
+    const int lc = ((byte % BK) >> 4) ^ swz<BK>(row);
+    const int64_t m = m0 + row;
+    a_off32[j] = (uint32_t)(m < p.M ? m : p.M - 1) * (uint32_t)Ktot + lc * 16;
   }
 
   auto stage = [&](int buf, int kk) {
     char* As = smem + buf * STAGE;
     char* Bs = As + A_STAGE;
+    if constexpr (FAST) {
+      // tiles past the end of K (staged only to keep the vmcnt count uniform) re-read tile 0
+      const int kk_u = __builtin_amdgcn_readfirstlane(kk < Ktot ? kk : 0);
+      const int8_t* a_u = p.A + kk_u;
+      const int8_t* b_u = p.Wt + kk_u;
+#pragma unroll
+      for (int j = 0; j < A_NI; ++j) glds16(a_u + a_off32[j], As + (wid * A_NI + j) * 1024);
+#pragma unroll
+      for (int j = 0; j < B_NI; ++j) glds16(b_u + b_off32[j], Bs + (wid * B_NI + j) * 1024);
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < A_NI; ++j) {
       const void* src;
@@ -180,20 +229,23 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     }
   };
 
-  // ---- fragment read addressing (loop invariant) ---------------------------------------------
+  // ---- fragment read offsets (loop invariant; the LDS buffer base is a compile-time constant
+  //      after the K loop is unrolled by STAGES, so each ds_read_b128 needs no address arithmetic)
   const int lrow = lane & 31, lhalf = lane >> 5;
-  int a_rd[TM], a_sw[TM], b_rd[TN], b_sw[TN];
+  constexpr int KS = BK / 32;
+  int a_rd[TM][KS], b_rd[TN][KS];
 #pragma unroll
   for (int t = 0; t < TM; ++t) {
     const int row = wm * WTM + t * 32 + lrow;
-    a_rd[t] = row * BK;
-    a_sw[t] = swz<BK>(row);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) a_rd[t][ks] = row * BK + (((ks * 2 + lhalf) ^ swz<BK>(row)) << 4);
   }
 #pragma unroll
   for (int t = 0; t < TN; ++t) {
     const int row = wn * WTN + t * 32 + lrow;
-    b_rd[t] = A_STAGE + row * BK;
-    b_sw[t] = swz<BK>(row);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      b_rd[t][ks] = A_STAGE + row * BK + (((ks * 2 + lhalf) ^ swz<BK>(row)) << 4);
   }
 
   v16i acc[TN][TM];
@@ -212,28 +264,55 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   const int nk = (Ktot + BK - 1) / BK;
 #pragma unroll
   for (int s = 0; s < PRE; ++s) stage(s, s * BK);
-  int buf_c = 0, buf_s = PRE;   // buffer computed / buffer staged next
-  for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((PRE - 1) * NI) : "memory");
-    stage(buf_s, (kt + PRE) * BK);
-    const char* S0 = smem + buf_c * STAGE;
-#pragma unroll
-    for (int ks = 0; ks < BK / 32; ++ks) {
-      v4i af[TM], bf[TN];
-#pragma unroll
-      for (int t = 0; t < TM; ++t)
-        af[t] = *reinterpret_cast<const v4i*>(S0 + a_rd[t] + (((ks * 2 + lhalf) ^ a_sw[t]) << 4));
-#pragma unroll
-      for (int t = 0; t < TN; ++t)
-        bf[t] = *reinterpret_cast<const v4i*>(S0 + b_rd[t] + (((ks * 2 + lhalf) ^ b_sw[t]) << 4));
-#pragma unroll
-      for (int a = 0; a < TN; ++a)
-#pragma unroll
-        for (int b = 0; b < TM; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[a], af[b], acc[a][b], 0, 0, 0);
+
+  // ---- per-channel epilogue vectors -> LDS, issued now so their latency hides under the main
+  //      loop (read back ~100 cycles away instead of ~1 us away per quad at the end).
+  //      P_B0: bias0[n] (table mode: the full-window class row), P_SC: scale[n], P_BS: bias[n].
+  constexpr int PARAM_OFF = igemm_main_bytes<BM, BN, BK, STAGES>();
+  float* P_B0 = reinterpret_cast<float*>(smem + PARAM_OFF);
+  float* P_SC = P_B0 + BN;
+  __half* P_BS = reinterpret_cast<__half*>(P_SC + BN);
+  const bool has_bias = p.bias != nullptr;
+  const bool use_table = p.table != nullptr;
+  const int full_cls = (((p.R - 1)) * p.S) * p.S + (p.S - 1);   // rlo=0, rhi=R-1, slo=0, shi=S-1
+  if (tid < BN / 4) {
+    const int n = n0 + tid * 4;
+    v4f b0 = {0.f, 0.f, 0.f, 0.f}, sc = {0.f, 0.f, 0.f, 0.f};
+    uint2 bs = make_uint2(0u, 0u);
+    if (n < p.N) {
+      const float* b0src = use_table ? p.table + (int64_t)full_cls * p.N : p.bias0;
+      b0 = *reinterpret_cast<const v4f*>(b0src + n);
+      sc = *reinterpret_cast<const v4f*>(p.scale + n);
+      if (has_bias) bs = *reinterpret_cast<const uint2*>(p.bias + n);
     }
-    buf_c = (buf_c + 1 == STAGES) ? 0 : buf_c + 1;
-    buf_s = (buf_s + 1 == STAGES) ? 0 : buf_s + 1;
+    *reinterpret_cast<v4f*>(P_B0 + tid * 4) = b0;
+    *reinterpret_cast<v4f*>(P_SC + tid * 4) = sc;
+    *reinterpret_cast<uint2*>(P_BS + tid * 4) = bs;
+  }
+
+  for (int kt0 = 0; kt0 < nk; kt0 += STAGES) {
+#pragma unroll
+    for (int s = 0; s < STAGES; ++s) {      // tile kt0 + s lives in buffer s (compile-time)
+      const int kt = kt0 + s;
+      if (kt < nk) {
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((PRE - 1) * NI) : "memory");
+        stage((s + PRE) % STAGES, (kt + PRE) * BK);
+        const char* S0 = smem + s * STAGE;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          v4i af[TM], bf[TN];
+#pragma unroll
+          for (int t = 0; t < TM; ++t) af[t] = *reinterpret_cast<const v4i*>(S0 + a_rd[t][ks]);
+#pragma unroll
+          for (int t = 0; t < TN; ++t) bf[t] = *reinterpret_cast<const v4i*>(S0 + b_rd[t][ks]);
+#pragma unroll
+          for (int a = 0; a < TN; ++a)
+#pragma unroll
+            for (int b = 0; b < TM; ++b)
+              acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[a], af[b], acc[a][b], 0, 0, 0);
+        }
+      }
+    }
   }
   // the zero-page DMAs staged for tiles >= nk are still in flight: drain before LDS is reused
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -241,28 +320,25 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   // ---- epilogue: registers -> f16 tile in LDS -> whole-row 16-byte stores --------------------
   __syncthreads();   // every wave is done reading the stage buffers
   char* Cs = smem;
-  const bool has_bias = p.bias != nullptr;
-  const bool use_table = p.table != nullptr;
   const bool unfused = p.unfused != 0;
   const float zpv = use_table ? *p.zp : 0.f;
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     const int ml = wm * WTM + tm * 32 + lrow;
-    const float* b0row = p.bias0;
+    // table mode: border class of this output pixel = its valid tap rectangle [rlo,rhi]x[slo,shi];
+    // interior pixels (the full window) use the row staged in LDS, border pixels read theirs.
+    const float* b0row = nullptr;
     if (use_table) {
-      // border class of this output pixel: valid tap rectangle [rlo,rhi] x [slo,shi]
       int64_t m = m0 + ml;
       if (m >= p.M) m = 0;
       const int pq = p.P * p.Q;
       const int rem = (int)(m % pq);
       const int pp = rem / p.Q, qq = rem - pp * p.Q;
       const int hb = pp * p.stride - p.pad, wb = qq * p.stride - p.pad;
-      const int rlo = max(0, -hb), rhi = min(p.R - 1, p.H - 1 - hb);
-      const int slo = max(0, -wb), shi = min(p.S - 1, p.W - 1 - wb);
-      int cls = 0;   // empty rectangle -> class 0 holds... (rlo>rhi cannot index: clamp)
-      const int rh = max(rhi, 0), sh = max(shi, 0);
-      cls = ((min(rlo, p.R - 1) * p.R + rh) * p.S + min(slo, p.S - 1)) * p.S + sh;
-      b0row = p.table + (int64_t)cls * p.N;
+      const int rlo = max(0, -hb), rhi = max(min(p.R - 1, p.H - 1 - hb), 0);
+      const int slo = max(0, -wb), shi = max(min(p.S - 1, p.W - 1 - wb), 0);
+      const int cls = ((min(rlo, p.R - 1) * p.R + rhi) * p.S + min(slo, p.S - 1)) * p.S + shi;
+      if (cls != full_cls) b0row = p.table + (int64_t)cls * p.N;
     }
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
@@ -271,27 +347,28 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         const int nl = wn * WTN + tn * 32 + 8 * g + 4 * lhalf;
         const int n = n0 + nl;
         if (n < p.N) {   // N % 4 == 0: the quad is all-valid or all-invalid
-          const v4f b0 = *reinterpret_cast<const v4f*>(b0row + n);
-          const v4f sc = *reinterpret_cast<const v4f*>(p.scale + n);
-          uint2 hb2 = make_uint2(0u, 0u);
-          if (has_bias) hb2 = *reinterpret_cast<const uint2*>(p.bias + n);
+          v4f b0 = *reinterpret_cast<const v4f*>(P_B0 + nl);
+          if (b0row != nullptr) b0 = *reinterpret_cast<const v4f*>(b0row + n);
+          if (use_table) b0 = b0 * zpv;                      // f32(sum of taps) * zp, one rounding
+          const v4f sc = *reinterpret_cast<const v4f*>(P_SC + nl);
+          const v4h hb4 = *reinterpret_cast<const v4h*>(P_BS + nl);
+          const v4f bs = __builtin_convertvector(hb4, v4f);  // exact
           uint32_t packed[2];
 #pragma unroll
           for (int e2 = 0; e2 < 2; ++e2) {
-            uint32_t w = 0;
-#pragma unroll
-            for (int e1 = 0; e1 < 2; ++e1) {
-              const int e = e2 * 2 + e1;
-              const uint32_t hw = e2 ? hb2.y : hb2.x;
-              __half_raw br;
-              br.x = (unsigned short)(e1 ? (hw >> 16) : (hw & 0xffffu));
-              float b0v = b0[e];
-              if (use_table) b0v = __fmul_rn(b0v, zpv);
-              __half h = epilogue_one(acc[tn][tm][4 * g + e], b0v, sc[e],
-                                      __half2float(__half(br)), has_bias, unfused);
-              w |= (uint32_t)__half_as_ushort(h) << (16 * e1);
-            }
-            packed[e2] = w;
+            // two outputs at a time on the packed-FP32 VALU: (f32(acc) - bias0) * scale [+ bias]
+            v2f x = {(float)acc[tn][tm][4 * g + 2 * e2], (float)acc[tn][tm][4 * g + 2 * e2 + 1]};
+            const v2f b0e = {b0[2 * e2], b0[2 * e2 + 1]};
+            const v2f sce = {sc[2 * e2], sc[2 * e2 + 1]};
+            const v2f bse = {bs[2 * e2], bs[2 * e2 + 1]};
+            x = x - b0e;
+            v2f r;
+            if (!has_bias) r = x * sce;
+            else if (unfused) r = x * sce + bse;             // -ffp-contract=off: mul, then add
+            else r = __builtin_elementwise_fma(x, sce, bse);
+            asm("" : "+v"(r));   // keep the FP32 rounding: no fold into a single-rounding fma_mix
+            const v2h h = __builtin_convertvector(r, v2h);    // v_cvt_pk_f16_f32, RNE
+            packed[e2] = *reinterpret_cast<const uint32_t*>(&h);
           }
           *reinterpret_cast<uint2*>(Cs + ml * CS_STRIDE + nl * 2) = make_uint2(packed[0], packed[1]);
         }
@@ -300,20 +377,27 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   }
   __syncthreads();
   constexpr int CPRO = BN / 8;   // 16-byte chunks per output row of the tile
+  constexpr int ROWS_PER_IT = NTHREADS / CPRO;
+  static_assert(NTHREADS % CPRO == 0 && BM % ROWS_PER_IT == 0, "copy-out geometry");
   const bool n8 = (p.N & 7) == 0;
-  for (int t = tid; t < BM * CPRO; t += 256) {
-    const int row = t / CPRO, cc = t - row * CPRO;
-    const int64_t m = m0 + row;
-    const int n = n0 + cc * 8;
-    if (m < p.M && n < p.N) {
+  const int cc = tid % CPRO;
+  const int n = n0 + cc * 8;
+  const bool identity_rows = p.grp_rows <= 0;
+  const bool res_full = p.res != nullptr && p.res_div == 1;
+  if (n < p.N) {
+
+    for (int row = tid / CPRO; row < BM; row += ROWS_PER_IT) {
+      const int64_t m = m0 + row;
+      if (m >= p.M) break;
       int64_t drow = m;
-      if (p.grp_rows > 0) {
+      if (!identity_rows) {
         const int64_t gq = m / p.grp_rows;
         drow = gq * p.grp_stride + p.grp_off + (m - gq * p.grp_rows);
       }
       uint4 v = *reinterpret_cast<const uint4*>(Cs + row * CS_STRIDE + cc * 16);
       if (p.res != nullptr) {
-        const __half* rp = p.res + (m / p.res_div) * p.N + n;
+        const int64_t rrow = res_full ? m : m / p.res_div;
+        const __half* rp = p.res + rrow * p.N + n;
         uint32_t rw[4];
         if (n8) {
           const uint4 r = *reinterpret_cast<const uint4*>(rp);
@@ -460,19 +544,13 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const __half* __restrict_
   }
 }
 
-template <int BM, int BN, int BK, int STAGES>
-constexpr int igemm_smem_bytes() {
-  return (STAGES * (BM + BN) * BK > BM * (BN * 2 + 16)) ? STAGES * (BM + BN) * BK
-                                                        : BM * (BN * 2 + 16);
-}
-
-template <int BM, int BN, int BK, int STAGES, bool CONV>
-int launch_tile(IgemmParams& p, hipStream_t stream) {
+template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool CONV, bool FAST>
+int launch_kernel(IgemmParams& p, hipStream_t stream) {
   constexpr int SMEM = igemm_smem_bytes<BM, BN, BK, STAGES>();
   static_assert(SMEM <= 160 * 1024, "LDS is 160 KiB per CU");
   if constexpr (SMEM > 64 * 1024) {   // opt in to > 64 KiB of dynamic LDS, once per instantiation
     static const hipError_t attr = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&igemm_kernel<BM, BN, BK, STAGES, CONV>),
+        reinterpret_cast<const void*>(&igemm_kernel<BM, BN, BK, STAGES, WM, WN, CONV, FAST>),
         hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (attr != hipSuccess) return MIXDQ_ERR_LAUNCH;
   }
@@ -480,38 +558,63 @@ int launch_tile(IgemmParams& p, hipStream_t stream) {
   p.tiles_n = (p.N + BN - 1) / BN;
   const int64_t grid = (int64_t)p.tiles_m * p.tiles_n;
   if (grid <= 0 || grid > 0x7fffffff) return MIXDQ_ERR_INVALID_ARG;
-  igemm_kernel<BM, BN, BK, STAGES, CONV><<<(int)grid, 256, SMEM, stream>>>(p);
+  igemm_kernel<BM, BN, BK, STAGES, WM, WN, CONV, FAST>
+      <<<(int)grid, 64 * WM * WN, SMEM, stream>>>(p);
   return launch_status();
+}
+
+template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool CONV>
+int launch_tile(IgemmParams& p, hipStream_t stream) {
+  if constexpr (!CONV) {
+    const bool fits32 = (uint64_t)p.M * (uint64_t)p.Ktot < (1ull << 32) &&
+                        (uint64_t)p.N * (uint64_t)p.Ktot < (1ull << 32);
+    if (p.Ktot % BK == 0 && fits32)
+      return launch_kernel<BM, BN, BK, STAGES, WM, WN, false, true>(p, stream);
+  }
+  return launch_kernel<BM, BN, BK, STAGES, WM, WN, CONV, false>(p, stream);
 }
 
 // Kernel configurations.  id 0 = automatic choice; ids 1.. can be forced through bits 8..15 of
 // the `flags` argument of the C entry points (tuning / tests only).
-#define MIXDQ_IGEMM_CONFIGS(X) \
-  X(1, 64, 64, 64, 2)          \
-  X(2, 64, 128, 64, 2)         \
-  X(3, 128, 128, 64, 2)        \
-  X(4, 64, 64, 128, 3)         \
-  X(5, 64, 64, 128, 4)         \
-  X(6, 64, 128, 128, 3)        \
-  X(7, 128, 128, 128, 3)       \
-  X(8, 128, 128, 64, 4)        \
-  X(9, 64, 64, 64, 4)          \
-  X(10, 128, 64, 128, 3)       \
-  X(11, 64, 128, 128, 4)       \
-  X(12, 128, 128, 128, 4)
+// X(id, BM, BN, BK, STAGES, WM, WN): block tile, K-tile bytes, LDS stages, wave grid (m x n)
+#define MIXDQ_IGEMM_CONFIGS(X)     \
+  X(1, 64, 64, 64, 2, 2, 2)        \
+  X(2, 64, 128, 64, 2, 2, 2)       \
+  X(3, 128, 128, 64, 2, 2, 2)      \
+  X(4, 64, 64, 128, 3, 2, 2)       \
+  X(5, 64, 64, 128, 4, 2, 2)       \
+  X(6, 64, 128, 128, 3, 2, 2)      \
+  X(7, 128, 128, 128, 3, 2, 2)     \
+  X(8, 128, 128, 64, 4, 2, 2)      \
+  X(9, 64, 64, 64, 4, 2, 2)        \
+  X(10, 128, 64, 128, 3, 2, 2)     \
+  X(11, 64, 128, 128, 4, 2, 2)     \
+  X(12, 128, 128, 128, 4, 2, 2)    \
+  X(13, 256, 128, 64, 3, 4, 2)     \
+  X(14, 256, 256, 64, 3, 4, 2)     \
+  X(15, 128, 256, 64, 3, 2, 4)     \
+  X(16, 256, 128, 64, 2, 4, 2)     \
+  X(17, 256, 256, 64, 2, 4, 2)     \
+  X(18, 256, 128, 128, 2, 4, 2)    \
+  X(19, 128, 128, 64, 3, 2, 2)     \
+  X(20, 256, 256, 128, 2, 4, 2)
 
-struct TileCfg { int id, bm, bn, bk, stages; };
+struct TileCfg { int id, bm, bn, bk, stages, wm, wn; };
 constexpr TileCfg kTileCfgs[] = {
-#define X(ID, BM, BN, BK, ST) {ID, BM, BN, BK, ST},
+#define X(ID, BM, BN, BK, ST, WM, WN) {ID, BM, BN, BK, ST, WM, WN},
     MIXDQ_IGEMM_CONFIGS(X)
 #undef X
 };
 
-// Automatic choice: the largest tile that still gives the 256 CUs at least ~1 block each.
-inline int select_cfg(int64_t M, int N) {
+// Automatic choice (tools/bench_gemm.py on MI355X): the largest tile that still fills the chip.
+// 8-wave 256-row tiles need ~2 blocks per CU of parallelism to pay; long-K problems take the
+// 256x256x128 tile (full 128-byte lines per DMA row, fewest L2->LDS bytes per MAC).
+inline int select_cfg(int64_t M, int N, int Ktot) {
   auto blocks = [&](int tm, int tn) {
     return ((M + tm - 1) / tm) * (int64_t)((N + tn - 1) / tn);
   };
+  if (blocks(256, 128) >= 2 * kNumCU)
+    return (Ktot >= 4096 && blocks(256, 256) >= kNumCU) ? 20 : 13;
   if (blocks(128, 128) >= kNumCU) return 3;    // 128x128x64, 2 stages
   if (blocks(64, 128) >= kNumCU) return 6;     // 64x128x128, 3 stages
   return 4;                                    // 64x64x128, 3 stages
@@ -532,10 +635,10 @@ int dispatch(IgemmParams& p, hipStream_t stream, int forced_cfg) {
     igemm_generic_kernel<CONV><<<(int)blocks, 256, 0, stream>>>(p);
     return launch_status();
   }
-  int cfg = forced_cfg > 0 ? forced_cfg : select_cfg(p.M, p.N);
+  int cfg = forced_cfg > 0 ? forced_cfg : select_cfg(p.M, p.N, p.Ktot);
   switch (cfg) {
-#define X(ID, BM, BN, BK, ST) \
-  case ID: return launch_tile<BM, BN, BK, ST, CONV>(p, stream);
+#define X(ID, BM, BN, BK, ST, WM, WN) \
+  case ID: return launch_tile<BM, BN, BK, ST, WM, WN, CONV>(p, stream);
     MIXDQ_IGEMM_CONFIGS(X)
 #undef X
     default: return MIXDQ_ERR_INVALID_ARG;
@@ -683,12 +786,12 @@ extern "C" const char* mixdq_status_string(int status) {
 
 extern "C" int mixdq_abi_version(void) { return MIXDQ_ABI_VERSION; }
 
-extern "C" int mixdq_igemm_select(int64_t M, int N, int k_align, int* bm, int* bn, int* bk,
-                                  int* stages) {
+extern "C" int mixdq_igemm_select(int64_t M, int N, int k_align, int k_total, int* bm, int* bn,
+                                  int* bk, int* stages) {
   if (!bm || !bn || !bk || !stages || M <= 0 || N <= 0) return MIXDQ_ERR_INVALID_ARG;
   if (k_align % 4 != 0 || N % 4 != 0) return MIXDQ_ERR_ALIGNMENT;
   if (k_align % 16 != 0) { *bm = *bn = *bk = *stages = 0; return MIXDQ_OK; }   // generic kernel
-  const int cfg = select_cfg(M, N);
+  const int cfg = select_cfg(M, N, k_total);
   for (const TileCfg& c : kTileCfgs)
     if (c.id == cfg) { *bm = c.bm; *bn = c.bn; *bk = c.bk; *stages = c.stages; }
   return MIXDQ_OK;

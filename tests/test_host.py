@@ -311,3 +311,28 @@ def test_calibration_checkpoint_schema():
     # 8-bit step = absmax / 127 of each output channel
     w = unet.conv_in.weight.detach().reshape(32, -1)
     assert torch.equal(e["delta_list"][2], (w.abs().max(dim=1)[0] / 127).half())
+
+
+def test_convert_ckpt_matches_reference_semantics():
+    """kernels/convert_ckpt.py:22-40: keep delta/zero-point lists, drop attention q/k/v activation
+    quantizers, fp16, weight -> [3, OC], act -> [3]."""
+    from collections import OrderedDict
+    from mixdq_amd.convert_ckpt import convert
+    buf_w = OrderedDict(delta_list=torch.rand(3, 8, 1, 1, 1), zero_point_list=torch.zeros(3, 8, 1, 1, 1),
+                        delta=torch.rand(8, 1, 1, 1), zero_point=torch.zeros(8, 1, 1, 1), alpha=None)
+    buf_a = OrderedDict(delta_list=torch.rand(3, 1, 1, 1), zero_point_list=torch.tensor(
+        [1., 7., 130.]).reshape(3, 1, 1, 1), delta=torch.rand(1), zero_point=torch.zeros(1))
+    ck = OrderedDict([("l.weight_quantizer", [buf_w, OrderedDict()]),
+                      ("l.act_quantizer", [buf_a, OrderedDict()]),
+                      ("blk.attn1.act_quantizer_q", [buf_a, OrderedDict()]),
+                      ("blk.attn1.act_quantizer_k", [buf_a, OrderedDict()]),
+                      ("blk.attn1.act_quantizer_v", [buf_a, OrderedDict()])])
+    new = convert(ck)
+    assert list(new) == ["l.weight_quantizer", "l.act_quantizer"]
+    assert new["l.weight_quantizer"]["delta_list"].shape == (3, 8)
+    assert new["l.weight_quantizer"]["delta_list"].dtype == torch.float16
+    assert new["l.act_quantizer"]["zero_point_list"].tolist() == [1., 7., 130.]
+    assert set(new["l.act_quantizer"]) == {"delta_list", "zero_point_list"}
+    from mixdq_amd.nn.utils import get_quant_para
+    s, z, _, _ = get_quant_para(new, 8, "l", "act")
+    assert float(z) == 2.0
