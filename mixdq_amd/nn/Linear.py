@@ -124,6 +124,16 @@ class QuantizedLinear(nn.Module):
         assert self.valid_for_acceleration and not getattr(self, "bos", False)
         return self._gemm(x_int, residual=residual)
 
+    def forward_bos_quantized(self, x_int_tail: torch.Tensor, B: int, T: int) -> torch.Tensor:
+        """BOS-path output [B, T, N] from the already quantized tokens 1..T-1 (int8 [B, T-1, K])."""
+        assert self.valid_for_acceleration and getattr(self, "bos", False)
+        out = torch.empty((B, T, self.out_features), dtype=torch.float16,
+                          device=x_int_tail.device)
+        out[:, :1, :] = self.bos_pre_computed
+        if T > 1:
+            self._gemm(x_int_tail, out=out, row_map=(T - 1, T, 1))
+        return out
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if not self.valid_for_acceleration:
             return F.linear(x, self.weight, self.bias)
@@ -132,10 +142,5 @@ class QuantizedLinear(nn.Module):
         if not getattr(self, "bos", False):
             return self._gemm(quant_op(x, self.act_scales_inv, self.act_zero_points))
         # BOS carve-out: token 0 is a precomputed FP16 row, tokens 1.. go through the kernels
-        B, T = x.shape[0], x.shape[1]
         x_int = quant_op(x[:, 1:, :], self.act_scales_inv, self.act_zero_points)
-        out = torch.empty((B, T, self.out_features), dtype=torch.float16, device=x.device)
-        out[:, :1, :] = self.bos_pre_computed
-        if T > 1:
-            self._gemm(x_int, out=out, row_map=(T - 1, T, 1))
-        return out
+        return self.forward_bos_quantized(x_int, x.shape[0], x.shape[1])

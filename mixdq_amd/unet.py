@@ -278,7 +278,15 @@ class BasicTransformerBlock(nn.Module):
         x = _linear_res(a.to_out[0], o, x)                          # x + attn1(norm1(x))
         a = self.attn2
         (fq,) = _ln_feed(self.norm2, x, [a.to_q])
-        o = a.attend(_run(a.to_q, fq), a.to_k(context), a.to_v(context))   # K/V: BOS path
+        kv = self.__dict__.pop("_kv", None)
+        if kv is not None:          # projected ahead of time on the side stream (SDXLUNet.forward)
+            k, v, ready = kv
+            torch.cuda.current_stream().wait_event(ready)
+            k.record_stream(torch.cuda.current_stream())
+            v.record_stream(torch.cuda.current_stream())
+        else:
+            k, v = a.to_k(context), a.to_v(context)                 # K/V: BOS path
+        o = a.attend(_run(a.to_q, fq), k, v)
         x = _linear_res(a.to_out[0], o, x)                          # x + attn2(norm2(x), ctx)
         (ff,) = _ln_feed(self.norm3, x, [self.ff.net[0].proj])
         return self.ff.forward_fused(ff, x)                         # x + ff(norm3(x))
@@ -443,6 +451,53 @@ class SDXLUNet(nn.Module):
 
     fused = False
 
+    def _project_context_ahead(self, context):
+        """Cross-attention keys / values depend only on the text embeddings, not on the latent: in
+        the fused graph all 2 x 70 to_k / to_v projections run on a side stream, concurrently with
+        the latent path, each block waiting only for its own pair (one event per block).  The
+        INT8 copy of the context (tokens 1.., BOS carve-out) is shared by every layer whose
+        activation quantizer is identical -- they are all calibrated on this same tensor."""
+        blocks = [m for m in self.modules() if isinstance(m, BasicTransformerBlock)]
+        if not blocks or not context.is_cuda:
+            return
+        if getattr(self, "_kv_stream", None) is None:
+            self._kv_stream = torch.cuda.Stream(device=context.device)
+        main = torch.cuda.current_stream()
+        side = self._kv_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            shared = []                       # [(representative layer, int8 context)]
+            for blk in blocks:
+                outs = []
+                for layer in (blk.attn2.to_k, blk.attn2.to_v):
+                    bos_w8a8 = (getattr(layer, "valid_for_acceleration", False)
+                                and getattr(layer, "bos", False)
+                                and context.dtype == torch.float16 and context.shape[1] > 1)
+                    if not bos_w8a8:
+                        outs.append(layer(context))
+                        continue
+                    x_int = None
+                    key = getattr(layer, "_ctx_group", None)
+                    if key is not None and key < len(shared):
+                        x_int = shared[key][1]
+                    else:
+                        for gi, (rep, xi) in enumerate(shared):
+                            if _same_qparams(rep, layer):
+                                layer._ctx_group, x_int = gi, xi
+                                break
+                    if x_int is None:
+                        from mixdq_amd.nn.Linear import quant_op
+                        x_int = quant_op(context[:, 1:, :], layer.act_scales_inv,
+                                         layer.act_zero_points)
+                        layer._ctx_group = len(shared)
+                        shared.append((layer, x_int))
+                    outs.append(layer.forward_bos_quantized(x_int, context.shape[0],
+                                                            context.shape[1]))
+                ready = torch.cuda.Event()
+                ready.record(side)
+                blk._kv = (outs[0], outs[1], ready)
+        context.record_stream(side)
+
     def set_fused(self, enabled: bool = True):
         """Switch the producer fusions on or off for the whole graph (see the top of this file)."""
         for m in self.modules():
@@ -466,6 +521,8 @@ class SDXLUNet(nn.Module):
         add = torch.cat([text_embeds, tid.reshape(B, -1).to(dtype)], dim=-1)
         emb = emb + self.add_embedding(add)
 
+        if self.fused and _fusable_f16(sample):
+            self._project_context_ahead(encoder_hidden_states)
         x = sample.contiguous(memory_format=torch.channels_last)
         x = self.conv_in(x)
         skips = [x]

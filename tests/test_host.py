@@ -38,9 +38,12 @@ def oracle_ops(monkeypatch, oracle):
         out.copy_(torch.from_numpy(oracle.quantize(x.numpy(), float(s_inv), float(zp))))
         return out
 
-    def qlin(x_int, w, ws, a_s, a_zp, wsum, scale, bias0, bias=None, _out=None, _row_map=None):
+    def qlin(x_int, w, ws, a_s, a_zp, wsum, scale, bias0, bias=None, _out=None, _row_map=None,
+             _residual=None, _residual_div=1, _cfg=0):
         D = torch.from_numpy(oracle.qlinear(x_int.contiguous().numpy(), w.numpy(), bias0.numpy(),
                                             scale.numpy(), None if bias is None else bias.numpy()))
+        if _residual is not None:
+            D = D + _residual.reshape(D.shape)
         if _out is None:
             return D
         g, stride, off = _row_map
@@ -49,13 +52,16 @@ def oracle_ops(monkeypatch, oracle):
         return _out
 
     def qconv(x_int, w, ws, a_s, a_zp, scale, wsum, bias0, bias=None, stride=1, padding=0,
-              dilation=1, _table=None):
+              dilation=1, _table=None, _residual=None, _residual_per_image=False, _cfg=0):
         D = oracle.qconv2d(x_int.permute(0, 2, 3, 1).contiguous().numpy(),
                            w.permute(0, 2, 3, 1).contiguous().numpy(), scale.numpy(),
                            None if wsum is None else wsum.numpy(), float(a_zp),
                            None if bias0 is None else bias0.numpy(),
                            None if bias is None else bias.numpy(), stride, padding)
-        return torch.from_numpy(D).permute(0, 3, 1, 2)
+        out = torch.from_numpy(D).permute(0, 3, 1, 2)
+        if _residual is not None:
+            out = out + (_residual[:, :, None, None] if _residual_per_image else _residual)
+        return out
 
     monkeypatch.setattr(L, "quant_op", quant)
     monkeypatch.setattr(L, "qlinear", qlin)
