@@ -254,12 +254,25 @@ def main():
 
     fp16 = None
     if not args.no_fp16:
+        # (a) the reference's comparison point: the same graph, stock PyTorch FP16 ops throughout
         if not args.no_graph:
             hip_graph_opt(unet)
         dt = time_steps(run_once, args.steps, args.warmup, device)
         fp16 = dict(ms_per_step=1e3 * dt / args.steps, images_per_s=world * B * args.steps / dt)
         if not args.no_graph:
             unet.forward = unet.forward.__wrapped__   # drop the FP16 graph
+        # (b) for transparency: FP16 GEMMs / convs by PyTorch, but with this repo's fused
+        #     GroupNorm / LayerNorm / GEGLU glue (fp16 outputs), so the INT8-vs-FP16 kernel effect
+        #     can be read separately from the glue effect
+        if not args.no_fuse:
+            unet.set_fused(True)
+            if not args.no_graph:
+                hip_graph_opt(unet)
+            dt = time_steps(run_once, args.steps, args.warmup, device)
+            fp16["fused_glue_ms_per_step"] = 1e3 * dt / args.steps
+            if not args.no_graph:
+                unet.forward = unet.forward.__wrapped__
+            unet.set_fused(False)
 
     quantize_unet(unet, Cfg(cfgs.load(args.w_config), cfgs.load(args.a_config)), ckpt,
                   bos=not args.no_bos, bos_dict=bos_dict)
@@ -307,6 +320,8 @@ def main():
     if fp16:
         out["fp16"] = fp16
         out["speedup_vs_fp16"] = fp16["ms_per_step"] / ms
+        if "fused_glue_ms_per_step" in fp16:
+            out["speedup_vs_fp16_with_fused_glue"] = fp16["fused_glue_ms_per_step"] / ms
     if roof_stats:
         dom = max(roof_stats, key=lambda k: roof_stats[k]["ms"])
         s = roof_stats[dom]

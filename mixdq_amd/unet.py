@@ -209,9 +209,9 @@ class Attention(nn.Module):
     def attend(self, q, k, v):
         B, T, C = q.shape
         h = self.heads
-        q = q.view(B, T, h, C // h).transpose(1, 2)
-        k = k.view(B, -1, h, C // h).transpose(1, 2)
-        v = v.view(B, -1, h, C // h).transpose(1, 2)
+        q = q.unflatten(-1, (h, C // h)).transpose(1, 2)    # views, also for column slices of a
+        k = k.unflatten(-1, (h, C // h)).transpose(1, 2)    # fused q|k|v projection
+        v = v.unflatten(-1, (h, C // h)).transpose(1, 2)
         o = F.scaled_dot_product_attention(q, k, v)   # FP16, as in the reference
         return o.transpose(1, 2).reshape(B, T, C)
 
@@ -270,11 +270,51 @@ class BasicTransformerBlock(nn.Module):
         x = x + self.attn2(self.norm2(x), context)
         return x + self.ff(self.norm3(x))
 
+    def _qkv_fused(self):
+        """Self-attention to_q / to_k / to_v read the same normalised tensor; when all three are
+        W8A8 with the SAME activation quantizer (they are calibrated on the same data) and carry no
+        bias, one GEMM against the row-concatenated weights [3C, C] replaces three: per-channel
+        scale / bias0 simply concatenate, so every output element is computed exactly as before.
+        The concatenated weight is the storage; the three layers' weight_int become views of it."""
+        cached = self.__dict__.get("_qkv")
+        if cached is not None:
+            return cached or None
+        a = self.attn1
+        layers = [a.to_q, a.to_k, a.to_v]
+        ok = (all(_accel(m) and m.bias is None for m in layers)
+              and _same_qparams(layers[0], layers[1]) and _same_qparams(layers[0], layers[2]))
+        if not ok:
+            self.__dict__["_qkv"] = False
+            return None
+        with torch.no_grad():
+            w = torch.cat([m.weight_int for m in layers], dim=0).contiguous()
+            C = layers[0].out_features
+            for i, m in enumerate(layers):
+                m.weight_int = w[i * C:(i + 1) * C]
+            pack = dict(
+                w=w, C=C,
+                wscale=torch.cat([m.weight_scales for m in layers]),
+                wsum=torch.cat([m.weight_sum_by_input_channels for m in layers]),
+                scale=torch.cat([m.scale for m in layers]).contiguous(),
+                bias0=torch.cat([m.bias0 for m in layers]).contiguous())
+        self.__dict__["_qkv"] = pack
+        return pack
+
     def forward_fused(self, x, context):
         x = x.contiguous()
         a = self.attn1
-        fq, fk, fv = _ln_feed(self.norm1, x, [a.to_q, a.to_k, a.to_v])
-        o = a.attend(_run(a.to_q, fq), _run(a.to_k, fk), _run(a.to_v, fv))
+        pack = self._qkv_fused()
+        feeds = _ln_feed(self.norm1, x, [a.to_q, a.to_k, a.to_v])
+        if pack is not None and feeds[0][1]:
+            from mixdq_amd.op.qlinear import qlinear
+            q0 = a.to_q
+            qkv = qlinear(feeds[0][0], pack["w"], pack["wscale"], q0.act_scales, q0.act_zero_points,
+                          pack["wsum"], pack["scale"], pack["bias0"], None)
+            C = pack["C"]
+            o = a.attend(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:])
+        else:
+            fq, fk, fv = feeds
+            o = a.attend(_run(a.to_q, fq), _run(a.to_k, fk), _run(a.to_v, fv))
         x = _linear_res(a.to_out[0], o, x)                          # x + attn1(norm1(x))
         a = self.attn2
         (fq,) = _ln_feed(self.norm2, x, [a.to_q])

@@ -21,6 +21,13 @@ def main():
             period = p
             break
     if period is None:
+        # multi-stream graphs interleave differently on every replay: match the multiset instead
+        for p in range(200, min(20000, len(names) // 3)):
+            a = collections.Counter(names[-p:])
+            if a == collections.Counter(names[-2 * p:-p]) == collections.Counter(names[-3 * p:-2 * p]):
+                period = p
+                break
+    if period is None:
         print("no periodic step found")
         return
     step = rows[-period:]
