@@ -329,8 +329,8 @@ def main():
         tot_ops = sum(v["ops"] for v in roof_stats.values())
         tot_ms = sum(v["ms"] for v in roof_stats.values())
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-        if os.path.exists(pmc):
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # from rocprofv3 --pmc passes
+        if os.path.exists(pmc) and args.px == 1024 and B == 1:       # (tools/pmc_probe.py)
             with open(pmc) as f:
                 traffic = json.load(f).get(dom, {}).get("hbm_bytes_per_launch")
         out["roofline"] = {
