@@ -45,6 +45,10 @@ def parse_args():
     ap.add_argument("--w-config", default="weight/uniform_8")
     ap.add_argument("--a-config", default="act/act_8.00")
     ap.add_argument("--no-bos", action="store_true")
+    ap.add_argument("--w4-kernel", action="store_true",
+                    help="run 4-/2-bit weight layers on the packed-W4 INT8 kernels (BASELINE config "
+                         "3, e.g. --w-config weight/weight_4.00 --a-config act/act_7.77); without "
+                         "it they fall back to FP16 as in the reference")
     ap.add_argument("--no-graph", action="store_true", help="eager launches (host-bound)")
     ap.add_argument("--no-fuse", action="store_true",
                     help="run the unfused drop-in graph (torch GroupNorm/LayerNorm/GELU + quantize)")
@@ -275,11 +279,12 @@ def main():
             unet.set_fused(False)
 
     quantize_unet(unet, Cfg(cfgs.load(args.w_config), cfgs.load(args.a_config)), ckpt,
-                  bos=not args.no_bos, bos_dict=bos_dict)
+                  bos=not args.no_bos, bos_dict=bos_dict, w4_kernel=args.w4_kernel)
     unet.set_fused(not args.no_fuse)
     bcast_bytes = shard.broadcast_module_state(unet, src=0)
     qmods = [m for m in unet.modules() if isinstance(m, (QuantizedLinear, QuantizedConv2d))]
     n_accel = sum(m.valid_for_acceleration for m in qmods)
+    n_w4 = sum(m.valid_for_acceleration and getattr(m, "w_packed4", False) for m in qmods)
     torch.cuda.empty_cache()
     weight_bytes = sum(b.numel() * b.element_size() for b in unet.buffers()) + sum(
         p.numel() * p.element_size() for p in unet.parameters())
@@ -299,17 +304,20 @@ def main():
     if rank != 0:
         return
     out = {
-        "metric": "sdxl_turbo_unet_w8a8_images_per_sec",
+        "metric": "sdxl_turbo_unet_w8a8_images_per_sec" if not args.w4_kernel
+        else "sdxl_turbo_unet_w4a8_mixed_images_per_sec",
         "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "int8", "data": "synthetic",
         "config": {
-            "workload": f"sdxl_turbo_unet_w8a8_{args.px}px_bs{B}_1step",
+            "workload": f"sdxl_turbo_unet_{'w4a8_mixed' if args.w4_kernel else 'w8a8'}"
+                        f"_{args.px}px_bs{B}_1step",
             "global_batch": world * B, "per_gpu_batch": B, "px": args.px, "latent": L,
             "w_config": args.w_config, "a_config": args.a_config, "bos": not args.no_bos,
             "parallelism": f"dp{world} (batch-sharded replicas, no step-loop collective)",
             "hip_graph": not args.no_graph, "producer_fusions": not args.no_fuse,
-            "accelerated_layers": n_accel, "quantizable_layers": len(qmods),
+            "accelerated_layers": n_accel, "w4_kernel_layers": n_w4,
+            "quantizable_layers": len(qmods),
             "epilogue_variant": "B" if C.FLAGS & 1 else "A",
         },
         "unet_step_latency_ms": ms,

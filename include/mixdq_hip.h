@@ -47,7 +47,15 @@ enum mixdq_flags {
   /* Epilogue / quantize rounding variant.  Default (0) = variant A: the
      multiply-add is one fused FMA (what nvcc -fmad=true makes of the reference's mul+add).
      MIXDQ_FLAG_UNFUSED = variant B: round after the multiply, then add.                          */
-  MIXDQ_FLAG_UNFUSED = 1
+  MIXDQ_FLAG_UNFUSED = 1,
+  /* The weight operand of mixdq_qlinear_w8a8_rows / mixdq_qconv2d_w8a8[_table] is PACKED signed
+     4-bit ("nibble-planar per 8": byte j of each 4-byte group holds k[8g+j] in the high nibble and
+     k[8g+4+j] in the low nibble, two's complement; [N, K/2] bytes, conv [K,R,S,C/2]).  Needs
+     K % 32 == 0 (conv: C % 32 == 0).  No reference counterpart: the reference's 4-bit layers
+     fall back to FP16 (nn/Linear.py:31,133-134); results equal the W8 path run on the unpacked
+     values.  bias0 / scale are those of the unpacked integers. */
+  MIXDQ_FLAG_W4 = 2
+  /* bits 8..15: force a kernel configuration id (tuning / tests); 0 = automatic */
 };
 
 const char* mixdq_status_string(int status);

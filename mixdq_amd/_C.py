@@ -77,6 +77,8 @@ IGEMM_CONFIGS = {1: (64, 64, 64, 2), 2: (64, 128, 64, 2), 3: (128, 128, 64, 2),
                  16: (256, 128, 64, 2), 17: (256, 256, 64, 2), 18: (256, 128, 128, 2),
                  19: (128, 128, 64, 3), 20: (256, 256, 128, 2)}
 
+FLAG_W4 = 2   # MIXDQ_FLAG_W4: the weight tensor holds packed signed 4-bit values
+
 # Rounding variant of the fused multiply-adds: "A" (default) = FMA,
 # "B" = separate multiply and add.  Read once at import; no other global state.
 FLAGS = 1 if os.environ.get("MIXDQ_EPILOGUE_VARIANT", "A").upper() == "B" else 0
@@ -148,7 +150,8 @@ def quantize_per_tensor_to_int8_vectorized(input, scale_inv, zero_point):
 
 def qlinear_w8_a8_ohalf(input_int8, weight_int8, weight_scale, input_scale, input_zero_point,
                         weight_sum_by_input_channels, scale, bias0, bias=None, *,
-                        _out=None, _row_map=None, _cfg=0, _residual=None, _residual_div=1):
+                        _out=None, _row_map=None, _cfg=0, _residual=None, _residual_div=1,
+                        _w4=False):
     _check(input_int8.is_cuda, "Input should be on GPU.")
     dev = input_int8.device
     _check(dev == weight_int8.device, "input and weight_int8 should be on the same device.")
@@ -174,7 +177,7 @@ def qlinear_w8_a8_ohalf(input_int8, weight_int8, weight_scale, input_scale, inpu
         _check(bias.dtype == torch.float16, "Currently only support bias with float16 type")
     _check(scale.dtype == torch.float32 and bias0.dtype == torch.float32,
            "scale and bias0 should be float32")
-    N, K = weight_int8.size(0), weight_int8.size(1)
+    N, K = weight_int8.size(0), weight_int8.size(1) * (2 if _w4 else 1)   # _w4: packed nibbles
     _check(weight_scale.numel() == N,
            "The size of the weight_scale vector should be equal to output_channels.")
     _check(weight_sum_by_input_channels.numel() == N,
@@ -203,7 +206,8 @@ def qlinear_w8_a8_ohalf(input_int8, weight_int8, weight_scale, input_scale, inpu
         code = _lib.mixdq_qlinear_w8a8_rows(a.data_ptr(), w.data_ptr(), b0.data_ptr(),
                                             sc.data_ptr(), _ptr(bs), D.data_ptr(), M, N, K,
                                             rm[0], rm[1], rm[2], _ptr(_residual), _residual_div,
-                                            FLAGS | (_cfg << 8), _stream())
+                                            FLAGS | (_cfg << 8) | (FLAG_W4 if _w4 else 0),
+                                            _stream())
     _status(code, "qlinear_w8_a8_ohalf")
     return D
 
@@ -219,7 +223,7 @@ def _conv_geometry(input_int8, weight_int8, stride, padding, dilation):
 def qconv2d_w8_a8_ohalf(input_int8, weight_int8, weight_scale, input_scale, input_zero_point,
                         scale, weight_sum_by_input_channels, bias0, bias=None, stride=1,
                         padding=0, dilation=1, *, _table=None, _cfg=0, _residual=None,
-                        _residual_per_image=False):
+                        _residual_per_image=False, _w4=False):
     stride = 1 if stride is None else int(stride)
     padding = 0 if padding is None else int(padding)
     dilation = 1 if dilation is None else int(dilation)
@@ -256,7 +260,8 @@ def qconv2d_w8_a8_ohalf(input_int8, weight_int8, weight_scale, input_scale, inpu
     _check(scale.dtype == torch.float32, "scale should be float32")
     _check(input_int8.dim() == 4 and weight_int8.dim() == 4, "input and weight should be 4-D")
     N, C, H, W, K, R, S, P, Q = _conv_geometry(input_int8, weight_int8, stride, padding, dilation)
-    _check(weight_int8.size(1) == C, "input and weight channel counts should match")
+    _check(weight_int8.size(1) * (2 if _w4 else 1) == C,
+           "input and weight channel counts should match")
     _check(weight_scale.numel() == K,
            "The size of the weight_scale vector should be equal to output_channels.")
     if padding == 0:
@@ -292,7 +297,8 @@ def qconv2d_w8_a8_ohalf(input_int8, weight_int8, weight_scale, input_scale, inpu
             code = _lib.mixdq_qconv2d_w8a8(
                 x.data_ptr(), w.data_ptr(), sc.data_ptr(), wsum.contiguous().data_ptr(),
                 input_zero_point.data_ptr(), None, _ptr(bs), D.data_ptr(), workspace.data_ptr(),
-                N, H, W, C, K, R, S, stride, padding, dilation, FLAGS | (_cfg << 8), _stream())
+                N, H, W, C, K, R, S, stride, padding, dilation,
+                FLAGS | (_cfg << 8) | (FLAG_W4 if _w4 else 0), _stream())
         else:
             _check(dilation == 1, "qconv2d_w8_a8_ohalf: unsupported configuration "
                                   "(dilation must be 1)")
@@ -302,8 +308,8 @@ def qconv2d_w8_a8_ohalf(input_int8, weight_int8, weight_scale, input_scale, inpu
             code = _lib.mixdq_qconv2d_w8a8_table(
                 x.data_ptr(), w.data_ptr(), sc.data_ptr(), _ptr(_table),
                 input_zero_point.data_ptr(), _ptr(b0), _ptr(bs), D.data_ptr(),
-                N, H, W, C, K, R, S, stride, padding, res_ptr, res_div, FLAGS | (_cfg << 8),
-                _stream())
+                N, H, W, C, K, R, S, stride, padding, res_ptr, res_div,
+                FLAGS | (_cfg << 8) | (FLAG_W4 if _w4 else 0), _stream())
     _status(code, "qconv2d_w8_a8_ohalf")
     return D
 

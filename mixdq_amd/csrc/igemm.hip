@@ -83,13 +83,24 @@ __device__ __forceinline__ uint32_t add_f16x2(uint32_t a, uint32_t b) {
 // DMA piece and the K-tile advance is a scalar add on the uniform base pointer (saddr form of
 // global_load_lds).  Rows past M / N are clamped to the last valid row instead of reading the
 // zero page: their accumulators are never stored.
-template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool CONV, bool FAST>
+//
+// W4: the weight operand is stored as packed signed 4-bit values (the
+// reference has no W4 kernel: its 4-bit layers fall back to FP16).  Layout "nibble-planar per 8":
+// byte j (0..3) of each 4-byte group holds  k[8g+j] in its HIGH nibble and k[8g+4+j] in its LOW
+// nibble (two's complement).  The packed bytes go through the same LDS-DMA pipeline at half the
+// bytes; a fragment read is one ds_read_b64 and the unpack is 3 VALU ops per packed dword:
+//     hi = w & 0xF0F0F0F0          -> int8 values 16 * q[8g .. 8g+3]
+//     lo = (w << 4) & 0xF0F0F0F0   -> int8 values 16 * q[8g+4 .. 8g+7]
+// i.e. the MFMA runs on 16*q (still int8, |16 q| <= 128) and the epilogue uses bias0 * 16 and
+// scale / 16 -- power-of-two factors, so every FP32 rounding is that of the unscaled arithmetic.
+template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool CONV, bool FAST, bool W4>
 __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p) {
   static_assert(!(CONV && FAST), "the fast staging path is for Linear");
   constexpr int NWAVES = WM * WN, NTHREADS = 64 * NWAVES;
   constexpr int WTM = BM / WM, WTN = BN / WN;     // wave tile (WM x WN waves)
   constexpr int TM = WTM / 32, TN = WTN / 32;     // 32x32 MFMA tiles per wave
-  constexpr int A_STAGE = BM * BK, B_STAGE = BN * BK, STAGE = A_STAGE + B_STAGE;
+  constexpr int WB = W4 ? 2 : 1;                  // weights per stored byte
+  constexpr int A_STAGE = BM * BK, B_STAGE = BN * BK / WB, STAGE = A_STAGE + B_STAGE;
   constexpr int A_NI = A_STAGE / 1024 / NWAVES;   // LDS-DMA instructions per wave per stage
   constexpr int B_NI = B_STAGE / 1024 / NWAVES;
   constexpr int CS_STRIDE = BN * 2 + 16;          // epilogue tile row stride (bytes)
@@ -170,13 +181,25 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
 #pragma unroll
   for (int j = 0; j < B_NI; ++j) {
     const int byte = (wid * B_NI + j) * 1024 + lane * 16;
-    const int row = byte / BK;
-    const int lc = ((byte % BK) >> 4) ^ swz<BK>(row);
+    int row, koff, boff;          // tile row; first k of this lane's 16-byte piece; its byte offset
+    if constexpr (!W4) {
+      row = byte / BK;
+      const int lc = ((byte % BK) >> 4) ^ swz<BK>(row);
+      koff = lc * 16;
+      boff = lc * 16;
+    } else {                      // packed: a 16-byte piece = 32 k-values = one MFMA k-step of a row
+      constexpr int KSP = BK / 32;
+      const int piece = byte >> 4;
+      row = piece / KSP;
+      const int ks = (piece % KSP) ^ ((row >> 3) & (KSP - 1));
+      koff = ks * 32;
+      boff = ks * 16;
+    }
     const int n = n0 + row;
     b_ok[j] = n < p.N;
-    b_base[j] = p.Wt + (int64_t)n * Ktot + lc * 16;
-    b_k[j] = lc * 16;
-    b_off32[j] = (uint32_t)min(n, p.N - 1) * (uint32_t)Ktot + lc * 16;
+    b_base[j] = p.Wt + (int64_t)n * (Ktot / WB) + boff;
+    b_k[j] = koff;
+    b_off32[j] = (uint32_t)min(n, p.N - 1) * (uint32_t)(Ktot / WB) + boff;
   }
 #pragma unroll
   for (int j = 0; j < A_NI; ++j) {
@@ -194,7 +217,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
       // tiles past the end of K (staged only to keep the vmcnt count uniform) re-read tile 0
       const int kk_u = __builtin_amdgcn_readfirstlane(kk < Ktot ? kk : 0);
       const int8_t* a_u = p.A + kk_u;
-      const int8_t* b_u = p.Wt + kk_u;
+      const int8_t* b_u = p.Wt + kk_u / WB;
 #pragma unroll
       for (int j = 0; j < A_NI; ++j) glds16(a_u + a_off32[j], As + (wid * A_NI + j) * 1024);
 #pragma unroll
@@ -224,7 +247,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
 #pragma unroll
     for (int j = 0; j < B_NI; ++j) {
       const bool ok = b_ok[j] && (kk + b_k[j] < Ktot);
-      const void* src = ok ? (const void*)(b_base[j] + kk) : (const void*)zero;
+      const void* src = ok ? (const void*)(b_base[j] + kk / WB) : (const void*)zero;
       glds16(src, Bs + (wid * B_NI + j) * 1024);
     }
   };
@@ -244,8 +267,12 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
   for (int t = 0; t < TN; ++t) {
     const int row = wn * WTN + t * 32 + lrow;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-      b_rd[t][ks] = A_STAGE + row * BK + (((ks * 2 + lhalf) ^ swz<BK>(row)) << 4);
+    for (int ks = 0; ks < KS; ++ks) {
+      if constexpr (!W4)
+        b_rd[t][ks] = A_STAGE + row * BK + (((ks * 2 + lhalf) ^ swz<BK>(row)) << 4);
+      else   // packed piece of (row, ks), this lane's half (8 bytes = 16 k-values)
+        b_rd[t][ks] = A_STAGE + row * (KS * 16) + ((ks ^ ((row >> 3) & (KS - 1))) << 4) + lhalf * 8;
+    }
   }
 
   v16i acc[TN][TM];
@@ -304,7 +331,17 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
 #pragma unroll
           for (int t = 0; t < TM; ++t) af[t] = *reinterpret_cast<const v4i*>(S0 + a_rd[t][ks]);
 #pragma unroll
-          for (int t = 0; t < TN; ++t) bf[t] = *reinterpret_cast<const v4i*>(S0 + b_rd[t][ks]);
+          for (int t = 0; t < TN; ++t) {
+            if constexpr (!W4) {
+              bf[t] = *reinterpret_cast<const v4i*>(S0 + b_rd[t][ks]);
+            } else {
+              const uint2 w = *reinterpret_cast<const uint2*>(S0 + b_rd[t][ks]);
+              bf[t][0] = (int)(w.x & 0xF0F0F0F0u);
+              bf[t][1] = (int)((w.x << 4) & 0xF0F0F0F0u);
+              bf[t][2] = (int)(w.y & 0xF0F0F0F0u);
+              bf[t][3] = (int)((w.y << 4) & 0xF0F0F0F0u);
+            }
+          }
 #pragma unroll
           for (int a = 0; a < TN; ++a)
 #pragma unroll
@@ -350,7 +387,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
           v4f b0 = *reinterpret_cast<const v4f*>(P_B0 + nl);
           if (b0row != nullptr) b0 = *reinterpret_cast<const v4f*>(b0row + n);
           if (use_table) b0 = b0 * zpv;                      // f32(sum of taps) * zp, one rounding
-          const v4f sc = *reinterpret_cast<const v4f*>(P_SC + nl);
+          v4f sc = *reinterpret_cast<const v4f*>(P_SC + nl);
+          if constexpr (W4) { b0 = b0 * 16.0f; sc = sc * 0.0625f; }   // exact: the MFMA ran on 16*q
           const v4h hb4 = *reinterpret_cast<const v4h*>(P_BS + nl);
           const v4f bs = __builtin_convertvector(hb4, v4f);  // exact
           uint32_t packed[2];
@@ -544,13 +582,13 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const __half* __restrict_
   }
 }
 
-template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool CONV, bool FAST>
+template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool CONV, bool FAST, bool W4 = false>
 int launch_kernel(IgemmParams& p, hipStream_t stream) {
   constexpr int SMEM = igemm_smem_bytes<BM, BN, BK, STAGES>();
   static_assert(SMEM <= 160 * 1024, "LDS is 160 KiB per CU");
   if constexpr (SMEM > 64 * 1024) {   // opt in to > 64 KiB of dynamic LDS, once per instantiation
     static const hipError_t attr = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&igemm_kernel<BM, BN, BK, STAGES, WM, WN, CONV, FAST>),
+        reinterpret_cast<const void*>(&igemm_kernel<BM, BN, BK, STAGES, WM, WN, CONV, FAST, W4>),
         hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (attr != hipSuccess) return MIXDQ_ERR_LAUNCH;
   }
@@ -558,9 +596,21 @@ int launch_kernel(IgemmParams& p, hipStream_t stream) {
   p.tiles_n = (p.N + BN - 1) / BN;
   const int64_t grid = (int64_t)p.tiles_m * p.tiles_n;
   if (grid <= 0 || grid > 0x7fffffff) return MIXDQ_ERR_INVALID_ARG;
-  igemm_kernel<BM, BN, BK, STAGES, WM, WN, CONV, FAST>
+  igemm_kernel<BM, BN, BK, STAGES, WM, WN, CONV, FAST, W4>
       <<<(int)grid, 64 * WM * WN, SMEM, stream>>>(p);
   return launch_status();
+}
+
+// W4 instantiations: tiles whose packed weight stage is a whole number of 1-KiB pieces per wave.
+template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool CONV>
+int launch_tile_w4(IgemmParams& p, hipStream_t stream) {
+  if constexpr (!CONV) {
+    const bool fits32 = (uint64_t)p.M * (uint64_t)p.Ktot < (1ull << 32) &&
+                        (uint64_t)p.N * (uint64_t)p.Ktot < (1ull << 32);
+    if (p.Ktot % BK == 0 && fits32)
+      return launch_kernel<BM, BN, BK, STAGES, WM, WN, false, true, true>(p, stream);
+  }
+  return launch_kernel<BM, BN, BK, STAGES, WM, WN, CONV, false, true>(p, stream);
 }
 
 template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool CONV>
@@ -620,6 +670,38 @@ inline int select_cfg(int64_t M, int N, int Ktot) {
   return 4;                                    // 64x64x128, 3 stages
 }
 
+inline int select_cfg_w4(int64_t M, int N, int Ktot) {
+  auto blocks = [&](int tm, int tn) {
+    return ((M + tm - 1) / tm) * (int64_t)((N + tn - 1) / tn);
+  };
+  if (blocks(256, 128) >= 2 * kNumCU)
+    return (Ktot >= 4096 && blocks(256, 256) >= kNumCU) ? 20 : 18;
+  if (blocks(128, 128) >= kNumCU) return 3;
+  if (blocks(64, 128) >= kNumCU) return 6;
+  return 4;
+}
+
+template <bool CONV>
+int dispatch_w4(IgemmParams& p, hipStream_t stream, int forced_cfg) {
+  if (p.M <= 0 || p.N <= 0) return MIXDQ_OK;
+  const int align_k = CONV ? p.C : p.Ktot;
+  if (align_k % 4 != 0 || p.N % 4 != 0) return MIXDQ_ERR_ALIGNMENT;
+  const bool ptr_ok = ((uintptr_t)p.A % 16 == 0) && ((uintptr_t)p.Wt % 16 == 0) &&
+                      ((uintptr_t)p.D % 16 == 0) && ((uintptr_t)p.scale % 16 == 0) &&
+                      ((uintptr_t)p.bias0 % 16 == 0) && ((uintptr_t)p.table % 16 == 0) &&
+                      ((uintptr_t)p.bias % 8 == 0) && ((uintptr_t)p.res % 16 == 0);
+  if (align_k % 32 != 0 || !ptr_ok) return MIXDQ_ERR_UNSUPPORTED;   // packed pieces span 32 k
+  const int cfg = forced_cfg > 0 ? forced_cfg : select_cfg_w4(p.M, p.N, p.Ktot);
+  switch (cfg) {
+    case 3: return launch_tile_w4<128, 128, 64, 2, 2, 2, CONV>(p, stream);
+    case 4: return launch_tile_w4<64, 64, 128, 3, 2, 2, CONV>(p, stream);
+    case 6: return launch_tile_w4<64, 128, 128, 3, 2, 2, CONV>(p, stream);
+    case 18: return launch_tile_w4<256, 128, 128, 2, 4, 2, CONV>(p, stream);
+    case 20: return launch_tile_w4<256, 256, 128, 2, 4, 2, CONV>(p, stream);
+    default: return MIXDQ_ERR_INVALID_ARG;
+  }
+}
+
 template <bool CONV>
 int dispatch(IgemmParams& p, hipStream_t stream, int forced_cfg) {
   if (p.M <= 0 || p.N <= 0) return MIXDQ_OK;
@@ -669,6 +751,7 @@ extern "C" int mixdq_qlinear_w8a8_rows(const int8_t* A, const int8_t* W, const f
   p.res_div = residual_row_div > 0 ? residual_row_div : 1;
   if (p.res && group_rows > 0) return MIXDQ_ERR_UNSUPPORTED;   // residual rows follow m, not D_row
   p.unfused = (flags & MIXDQ_FLAG_UNFUSED) ? 1 : 0;
+  if (flags & MIXDQ_FLAG_W4) return dispatch_w4<false>(p, (hipStream_t)stream, (flags >> 8) & 0xff);
   return dispatch<false>(p, (hipStream_t)stream, (flags >> 8) & 0xff);
 }
 
@@ -721,6 +804,7 @@ extern "C" int mixdq_qconv2d_w8a8_table(const int8_t* X, const int8_t* Wt, const
   p.res = (const __half*)residual_f16_or_null;
   p.res_div = residual_row_div > 0 ? residual_row_div : 1;
   p.unfused = (flags & MIXDQ_FLAG_UNFUSED) ? 1 : 0;
+  if (flags & MIXDQ_FLAG_W4) return dispatch_w4<true>(p, (hipStream_t)stream, (flags >> 8) & 0xff);
   return dispatch<true>(p, (hipStream_t)stream, (flags >> 8) & 0xff);
 }
 

@@ -21,7 +21,7 @@ import torch.nn.functional as F
 from torch.ao.quantization import QConfig
 
 from mixdq_amd import _C
-from mixdq_amd.nn.utils import create_qparams_from_dtype
+from mixdq_amd.nn.utils import create_qparams_from_dtype, pack_w4, unpack_w4
 from mixdq_amd.op.quant import quantize_per_tensor_vectorized
 
 __all__ = ["QuantizedConv2d"]
@@ -31,18 +31,24 @@ quant_op = quantize_per_tensor_vectorized
 _INT8 = (torch.qint8, torch.quint8)
 
 
-def _w8a8_ok(w, a) -> bool:
+def _w8a8_ok(w, a, w4_kernel=False) -> bool:
+    w_ok = w is not None and (w.dtype in _INT8 or (w4_kernel and w.dtype == torch.quint4x2))
     return bool(
-        w is not None and a is not None and w.dtype in _INT8 and a.dtype in _INT8
+        w_ok and a is not None and a.dtype in _INT8
         and w.qscheme == torch.per_channel_affine and a.qscheme == torch.per_tensor_affine
         and torch.all(w.zero_points == 0.0).item())
 
 
 class QuantizedConv2d(nn.Module):
+    w4_kernel = False   # W4A8 kernel path, see QuantizedLinear.w4_kernel
+
     def __init__(self, in_channels: int, out_channels: int, kernel_size, stride, padding,
                  dilation, groups=1, bias=True, device=None, w_qparams=None, w_qparams_0=None,
-                 a_qparams=None, a_qparams_0=None, module_name=None, split=0) -> None:
+                 a_qparams=None, a_qparams_0=None, module_name=None, split=0,
+                 w4_kernel=False) -> None:
         super().__init__()
+        self.w_packed4 = bool(w4_kernel and w_qparams is not None
+                              and w_qparams.dtype == torch.quint4x2)
         self.module_name = module_name
         self.split = split   # > 0: up-block conv_shortcut, input = cat(hidden[:split], skip)
         self.in_channels = in_channels
@@ -56,9 +62,13 @@ class QuantizedConv2d(nn.Module):
         square = (len(set(stride)) == 1 and len(set(padding)) == 1 and len(set(dilation)) == 1
                   and dilation[0] == 1 and groups == 1)
         self.valid_for_acceleration = (
-            _w8a8_ok(w_qparams, a_qparams)
-            and (split == 0 or _w8a8_ok(w_qparams_0, a_qparams_0))
+            _w8a8_ok(w_qparams, a_qparams, w4_kernel)
+            and (split == 0 or _w8a8_ok(w_qparams_0, a_qparams_0, w4_kernel))
             and square)
+        if self.valid_for_acceleration and self.w_packed4:
+            cins = [in_channels] if split == 0 else [split, in_channels - split]
+            if any(c % 32 != 0 for c in cins):       # packed pieces span 32 input channels
+                self.valid_for_acceleration = False
         if self.valid_for_acceleration and (in_channels % 4 != 0 or out_channels % 4 != 0):
             logging.warning(
                 f"Conv2d layer with in_channels = {in_channels} and out_channels = "
@@ -80,10 +90,16 @@ class QuantizedConv2d(nn.Module):
     def _register_weight(self, sfx, weight, w_qparams, pad):
         scales = getattr(self, "weight_scales" + sfx)
         azp = getattr(self, "act_zero_points" + sfx)
-        weight_int = torch.quantize_per_channel(
-            weight.float(), scales, getattr(self, "weight_zero_points" + sfx),
-            axis=w_qparams.axis, dtype=w_qparams.dtype).int_repr()
-        self.register_buffer("weight_int" + sfx, weight_int)
+        if self.w_packed4:   # the Path A integers, packed along C in [K, R, S, C] order
+            weight_int = torch.clamp(torch.round(weight.float() / scales[:, None, None, None]),
+                                     -8, 7).to(torch.int8)
+            packed = pack_w4(weight_int.permute(0, 2, 3, 1).contiguous())      # [K, R, S, C/2]
+            self.register_buffer("weight_int4" + sfx, packed.permute(0, 3, 1, 2))
+        else:
+            weight_int = torch.quantize_per_channel(
+                weight.float(), scales, getattr(self, "weight_zero_points" + sfx),
+                axis=w_qparams.axis, dtype=w_qparams.dtype).int_repr()
+            self.register_buffer("weight_int" + sfx, weight_int)
         if pad == 0:
             # per-channel zero-point term (nn/Conv2d.py:166-171)
             self.register_buffer("bias0" + sfx, weight_int.float().sum(dim=[1, 2, 3]) * azp)
@@ -115,7 +131,8 @@ class QuantizedConv2d(nn.Module):
                       float_mod.stride, float_mod.padding, float_mod.dilation, float_mod.groups,
                       float_mod.bias is not None, device=device, w_qparams=w_qparams,
                       w_qparams_0=w_qparams_0, a_qparams=a_qparams, a_qparams_0=a_qparams_0,
-                      module_name=float_mod.module_name, split=split)
+                      module_name=float_mod.module_name, split=split,
+                      w4_kernel=getattr(float_mod, "w4_kernel", cls.w4_kernel))
         weight = float_mod.weight.detach()
         pad = float_mod.padding[0]
         if new_mod.valid_for_acceleration:
@@ -133,11 +150,19 @@ class QuantizedConv2d(nn.Module):
         return new_mod
 
     def _get_name(self):
-        return "QuantizedConv2dW8A8" if self.valid_for_acceleration else "QuantizedConv2dFPFallback"
+        if not self.valid_for_acceleration:
+            return "QuantizedConv2dFPFallback"
+        return "QuantizedConv2dW4A8" if self.w_packed4 else "QuantizedConv2dW8A8"
+
+    def _weight_values(self, sfx=""):
+        if not self.w_packed4:
+            return getattr(self, "weight_int" + sfx)
+        p = getattr(self, "weight_int4" + sfx).permute(0, 2, 3, 1).contiguous()   # [K,R,S,C/2]
+        return unpack_w4(p).permute(0, 3, 1, 2)
 
     def forward_fallback(self, x: torch.Tensor):
         def deq(sfx):
-            w = getattr(self, "weight_int" + sfx).float()
+            w = self._weight_values(sfx).float()
             return (w * getattr(self, "weight_scales" + sfx)[:, None, None, None]).to(x.dtype)
 
         bias = self.bias.to(x.dtype) if self.bias is not None else None
@@ -169,12 +194,13 @@ class QuantizedConv2d(nn.Module):
 
     def _conv(self, x_int, sfx, bias, residual=None, residual_per_image=False):
         return _C.qconv2d_w8_a8_ohalf(
-            x_int, getattr(self, "weight_int" + sfx), getattr(self, "weight_scales" + sfx),
+            x_int, getattr(self, ("weight_int4" if self.w_packed4 else "weight_int") + sfx),
+            getattr(self, "weight_scales" + sfx),
             getattr(self, "act_scales" + sfx), getattr(self, "act_zero_points" + sfx),
             getattr(self, "scale" + sfx), getattr(self, "weight_sum_by_input_channels" + sfx),
             getattr(self, "bias0" + sfx), bias, self.stride[0], self.padding[0], 1,
             _table=self._border_table(sfx), _residual=residual,
-            _residual_per_image=residual_per_image)
+            _residual_per_image=residual_per_image, _w4=self.w_packed4)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if not self.valid_for_acceleration:

@@ -20,7 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.ao.quantization import QConfig
 
-from mixdq_amd.nn.utils import create_qparams_from_dtype
+from mixdq_amd.nn.utils import create_qparams_from_dtype, pack_w4, unpack_w4
 from mixdq_amd.op.quant import quantize_per_tensor_vectorized
 from mixdq_amd.op.qlinear import qlinear
 
@@ -31,25 +31,38 @@ quant_op = quantize_per_tensor_vectorized
 _INT8 = (torch.qint8, torch.quint8)
 
 
-def _w8a8_ok(w_qparams, a_qparams) -> bool:
-    """nn/Linear.py:27-36: per-channel symmetric int8 weights, per-tensor int8 activations."""
+def _w8a8_ok(w_qparams, a_qparams, w4_kernel=False) -> bool:
+    """nn/Linear.py:27-36: per-channel symmetric int8 weights, per-tensor int8 activations.
+    With w4_kernel (this build's W4A8 path, off by default) 4-bit weights qualify too."""
+    w_ok = w_qparams is not None and (
+        w_qparams.dtype in _INT8 or (w4_kernel and w_qparams.dtype == torch.quint4x2))
     return bool(
-        w_qparams is not None and a_qparams is not None
-        and w_qparams.dtype in _INT8 and a_qparams.dtype in _INT8
+        w_ok and a_qparams is not None and a_qparams.dtype in _INT8
         and w_qparams.qscheme == torch.per_channel_affine
         and a_qparams.qscheme == torch.per_tensor_affine
         and torch.all(w_qparams.zero_points == 0.0).item())
 
 
 class QuantizedLinear(nn.Module):
+    # W4A8 kernel path (SURVEY.md section 8 f-2).  False = the reference's behaviour: 4-/2-bit
+    # layers keep their FP16 weight and run F.linear.  True: weights are stored as packed signed
+    # 4-bit integers (the Path A integers: clamp(round(w / delta), -8, 7)) and run on the INT8
+    # MFMA kernels with an in-kernel unpack.  Set per float module (`mod.w4_kernel = True`) or via
+    # quantize_unet(..., w4_kernel=True).
+    w4_kernel = False
+
     def __init__(self, in_features: int, out_features: int, bias: bool = True, device=None,
-                 w_qparams=None, a_qparams=None, module_name=None) -> None:
+                 w_qparams=None, a_qparams=None, module_name=None, w4_kernel=False) -> None:
         super().__init__()
         self.module_name = module_name
         self.in_features = in_features
         self.out_features = out_features
         self.device = device
-        self.valid_for_acceleration = _w8a8_ok(w_qparams, a_qparams)
+        self.w_packed4 = bool(w4_kernel and w_qparams is not None
+                              and w_qparams.dtype == torch.quint4x2)
+        self.valid_for_acceleration = _w8a8_ok(w_qparams, a_qparams, w4_kernel)
+        if self.valid_for_acceleration and self.w_packed4 and in_features % 32 != 0:
+            self.valid_for_acceleration = False      # packed pieces span 32 input channels
         if self.valid_for_acceleration and (in_features % 4 != 0 or out_features % 4 != 0):
             logging.warning(
                 f"Linear layer with in_features = {in_features} and out_features = "
@@ -81,17 +94,24 @@ class QuantizedLinear(nn.Module):
                                                      **common)
         new_mod = cls(float_mod.in_features, float_mod.out_features, float_mod.bias is not None,
                       device=device, w_qparams=w_qparams, a_qparams=a_qparams,
-                      module_name=float_mod.module_name)
+                      module_name=float_mod.module_name,
+                      w4_kernel=getattr(float_mod, "w4_kernel", cls.w4_kernel))
         weight = float_mod.weight.detach()
         name = float_mod.module_name
         if "attn2" in name and ("to_k" in name or "to_v" in name):
             new_mod.bos = float_mod.bos
             new_mod.register_buffer("bos_pre_computed", float_mod.bos_pre_computed)
-        if new_mod.valid_for_acceleration:
+        if new_mod.valid_for_acceleration and new_mod.w_packed4:
+            # the Path A integers (base_quantizer.py:119-127, sym, n_levels = 7)
+            weight_int = torch.clamp(torch.round(weight.float() / new_mod.weight_scales[:, None]),
+                                     -8, 7).to(torch.int8)
+            new_mod.register_buffer("weight_int4", pack_w4(weight_int))
+        elif new_mod.valid_for_acceleration:
             weight_int = torch.quantize_per_channel(
                 weight.float(), new_mod.weight_scales, new_mod.weight_zero_points,
                 axis=w_qparams.axis, dtype=w_qparams.dtype).int_repr()
             new_mod.register_buffer("weight_int", weight_int)
+        if new_mod.valid_for_acceleration:
             # auxiliary vectors of the epilogue  D = (acc - bias0) * scale + bias
             wsum = weight_int.float().sum(dim=1)
             new_mod.register_buffer("weight_sum_by_input_channels", wsum)
@@ -106,13 +126,23 @@ class QuantizedLinear(nn.Module):
         return new_mod
 
     def _get_name(self):
-        return "QuantizedLinearW8A8" if self.valid_for_acceleration else "QuantizedLinearFPFallback"
+        if not self.valid_for_acceleration:
+            return "QuantizedLinearFPFallback"
+        return "QuantizedLinearW4A8" if self.w_packed4 else "QuantizedLinearW8A8"
+
+    def _weight_values(self):
+        return unpack_w4(self.weight_int4) if self.w_packed4 else self.weight_int
 
     def forward_fallback(self, x):
-        w = (self.weight_int.float() * self.weight_scales[:, None]).to(x.dtype)
+        w = (self._weight_values().float() * self.weight_scales[:, None]).to(x.dtype)
         return F.linear(x, w, self.bias.to(x.dtype) if self.bias is not None else None)
 
     def _gemm(self, x_int, out=None, row_map=None, residual=None):
+        if self.w_packed4:
+            return qlinear(x_int, self.weight_int4, self.weight_scales, self.act_scales,
+                           self.act_zero_points, self.weight_sum_by_input_channels, self.scale,
+                           self.bias0, self.bias, _out=out, _row_map=row_map, _residual=residual,
+                           _w4=True)
         return qlinear(x_int, self.weight_int, self.weight_scales, self.act_scales,
                        self.act_zero_points, self.weight_sum_by_input_channels, self.scale,
                        self.bias0, self.bias, _out=out, _row_map=row_map, _residual=residual)

@@ -108,3 +108,27 @@ def unpack_uint4(input):
 def dequantize_per_tensor_uint4(input, scale, zero_point):
     x = unpack_uint4(input)
     return (x.to(torch.float32) - _bcast(zero_point, x.dim())) * _bcast(scale, x.dim())
+
+
+# ---- W4 storage of this build ("nibble-planar per 8", include/mixdq_hip.h MIXDQ_FLAG_W4) ------
+# The reference defines a 4-bit pack (above: high nibble = even index) but no kernel reads it.
+# The MI355X kernel wants an unpack of 3 VALU ops per packed dword, which this layout gives:
+# within every group of 8 consecutive k, byte j holds k[j] in the high and k[4+j] in the low
+# nibble (two's complement).  Last dimension is K (Linear [N, K]; Conv [K, R, S, C] i.e. the
+# channels-last weight): packed last dimension = K / 2.
+def pack_w4(q: torch.Tensor) -> torch.Tensor:
+    """int8 values in [-8, 7], last dim % 8 == 0  ->  int8 packed, last dim / 2."""
+    assert q.dtype == torch.int8 and q.shape[-1] % 8 == 0
+    assert int(q.min()) >= -8 and int(q.max()) <= 7, "W4 values must be in [-8, 7]"
+    g = q.reshape(*q.shape[:-1], q.shape[-1] // 8, 2, 4).to(torch.int16)   # [.., group, half, j]
+    packed = ((g[..., 0, :] & 0xF) << 4) | (g[..., 1, :] & 0xF)
+    return packed.to(torch.uint8).view(torch.int8).reshape(*q.shape[:-1], q.shape[-1] // 2)
+
+
+def unpack_w4(packed: torch.Tensor) -> torch.Tensor:
+    """Inverse of pack_w4: int8 packed [..., K/2] -> int8 values [..., K]."""
+    b = packed.view(torch.uint8).to(torch.int16).reshape(*packed.shape[:-1], packed.shape[-1] // 4, 4)
+    hi, lo = (b >> 4) & 0xF, b & 0xF
+    v = torch.stack([hi, lo], dim=-2)                         # [.., group, half, j]
+    v = torch.where(v >= 8, v - 16, v)
+    return v.to(torch.int8).reshape(*packed.shape[:-1], packed.shape[-1] * 2)

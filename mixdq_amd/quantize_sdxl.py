@@ -95,8 +95,14 @@ def convert_to_quantized(unet, ckpt):
             inplace=True, ckpt=ckpt)
 
 
-def quantize_unet(unet, args, ckpt, bos, bos_dict):
+def quantize_unet(unet, args, ckpt, bos, bos_dict, w4_kernel=False):
+    """`w4_kernel=True` (not in the reference): 4-/2-bit weight layers run the packed-W4 INT8
+    kernels instead of falling back to FP16 (mixdq_amd.nn.QuantizedLinear.w4_kernel)."""
     register_qconfig_from_input_files(unet, args, bos=bos, bos_dict=bos_dict)
+    if w4_kernel:
+        for mod in unet.modules():
+            if getattr(mod, "w_bit", 8) in (2, 4):
+                mod.w4_kernel = True
     convert_to_quantized(unet, ckpt)
 
 

@@ -226,6 +226,20 @@ def geglu_quantize(h, scale_inv, zero_point, variant=VARIANT_FUSED):
     return q, o
 
 
+def unpack_w4(packed: np.ndarray) -> np.ndarray:
+    """W4 storage of include/mixdq_hip.h (MIXDQ_FLAG_W4), restated independently: within each
+    group of 8 k-values, byte j holds k[j] in its high nibble and k[4+j] in its low nibble, two's
+    complement.  int8/uint8 [..., K/2] -> int8 [..., K].  The W4 kernels must equal the W8
+    restatement run on these unpacked integers."""
+    b = np.ascontiguousarray(packed).view(np.uint8).astype(np.int16)
+    b = b.reshape(b.shape[:-1] + (b.shape[-1] // 4, 4))
+    out = np.empty(b.shape[:-1] + (8,), dtype=np.int16)
+    out[..., 0:4] = (b >> 4) & 0xF
+    out[..., 4:8] = b & 0xF
+    out = np.where(out >= 8, out - 16, out)
+    return out.astype(np.int8).reshape(packed.shape[:-1] + (packed.shape[-1] * 2,))
+
+
 # ------------------------------------------------------------------------------------------
 # NumPy mirror: an independent second restatement of the same arithmetic, used by
 # tests/test_oracle.py to cross-check the C code (two restatements that agree bit-for-bit).

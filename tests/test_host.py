@@ -39,7 +39,9 @@ def oracle_ops(monkeypatch, oracle):
         return out
 
     def qlin(x_int, w, ws, a_s, a_zp, wsum, scale, bias0, bias=None, _out=None, _row_map=None,
-             _residual=None, _residual_div=1, _cfg=0):
+             _residual=None, _residual_div=1, _cfg=0, _w4=False):
+        if _w4:
+            w = torch.from_numpy(oracle.unpack_w4(w.contiguous().numpy()))
         D = torch.from_numpy(oracle.qlinear(x_int.contiguous().numpy(), w.numpy(), bias0.numpy(),
                                             scale.numpy(), None if bias is None else bias.numpy()))
         if _residual is not None:
@@ -52,9 +54,12 @@ def oracle_ops(monkeypatch, oracle):
         return _out
 
     def qconv(x_int, w, ws, a_s, a_zp, scale, wsum, bias0, bias=None, stride=1, padding=0,
-              dilation=1, _table=None, _residual=None, _residual_per_image=False, _cfg=0):
-        D = oracle.qconv2d(x_int.permute(0, 2, 3, 1).contiguous().numpy(),
-                           w.permute(0, 2, 3, 1).contiguous().numpy(), scale.numpy(),
+              dilation=1, _table=None, _residual=None, _residual_per_image=False, _cfg=0,
+              _w4=False):
+        wk = w.permute(0, 2, 3, 1).contiguous().numpy()
+        if _w4:
+            wk = oracle.unpack_w4(wk)
+        D = oracle.qconv2d(x_int.permute(0, 2, 3, 1).contiguous().numpy(), wk, scale.numpy(),
                            None if wsum is None else wsum.numpy(), float(a_zp),
                            None if bias0 is None else bias0.numpy(),
                            None if bias is None else bias.numpy(), stride, padding)
@@ -342,3 +347,71 @@ def test_convert_ckpt_matches_reference_semantics():
     from mixdq_amd.nn.utils import get_quant_para
     s, z, _, _ = get_quant_para(new, 8, "l", "act")
     assert float(z) == 2.0
+
+
+# ----------------------------------------------------------------------------- W4A8 (f-2)
+def test_w4_pack_layout_and_default_fallback(modules_golden, oracle):
+    from mixdq_amd.nn import QuantizedLinear
+    from mixdq_amd.nn.utils import pack_w4, unpack_w4
+    q = torch.tensor([[-8, -1, 0, 7, 1, 2, 3, -4] * 4], dtype=torch.int8)
+    p = pack_w4(q)
+    assert p.shape == (1, 16)
+    # byte j of a group: high nibble k[j], low nibble k[4+j], two's complement
+    assert p.view(torch.uint8)[0, :4].tolist() == [0x81, 0xF2, 0x03, 0x7C]
+    assert torch.equal(unpack_w4(p), q)
+    assert np.array_equal(oracle.unpack_w4(p.numpy()), q.numpy())
+    c = MODULE_CASES[0]
+    ck = module_ckpt(c, modules_golden)
+    # default: 4-bit weights fall back to FP16 exactly as the reference (nn/Linear.py:31)
+    assert not QuantizedLinear.from_float(prepared(c, modules_golden, w_bit=4), ckpt=ck
+                                          ).valid_for_acceleration
+    fm = prepared(c, modules_golden, w_bit=4)
+    fm.w4_kernel = True
+    qm = QuantizedLinear.from_float(fm, ckpt=ck)
+    assert qm.valid_for_acceleration and qm.w_packed4 and qm._get_name() == "QuantizedLinearW4A8"
+    assert "weight_int4" in dict(qm.named_buffers()) and "weight_int" not in dict(qm.named_buffers())
+    assert qm.weight_int4.shape == (c["cout"], c["cin"] // 2)
+    # the stored integers are the Path A integers: clamp(round(w / delta_4bit), -8, 7)
+    w = make_float_module(c).half().weight.detach().float()
+    d4 = ck[c["name"] + ".weight_quantizer"]["delta_list"][1].float()
+    want = torch.clamp(torch.round(w / d4[:, None]), -8, 7).to(torch.int8)
+    assert torch.equal(unpack_w4(qm.weight_int4), want)
+    assert torch.equal(qm.bias0, want.float().sum(dim=1) * qm.act_zero_points)
+
+
+@pytest.mark.parametrize("c", [c for c in MODULE_CASES if c["cin"] % 32 == 0 and not c.get("split")],
+                         ids=[c["key"] for c in MODULE_CASES if c["cin"] % 32 == 0 and not c.get("split")])
+def test_w4_forward_tracks_path_a_4bit(modules_golden, fakequant_golden, oracle_ops, c):
+    """W4A8 module (oracle-backed ops on CPU) vs the reference QuantLayer at 4-bit weights."""
+    from mixdq_amd.nn import QuantizedConv2d, QuantizedLinear
+    cls = QuantizedLinear if c["kind"] == "linear" else QuantizedConv2d
+    fm = prepared(c, modules_golden, w_bit=4)
+    fm.w4_kernel = True
+    qm = cls.from_float(fm, ckpt=module_ckpt(c, modules_golden))
+    assert qm.valid_for_acceleration and qm.w_packed4
+    with torch.no_grad():
+        y = qm(module_input(c)).float()
+    # Path A restated (oracle/fakequant.py, pinned to the reference QuantLayer) with the SAME fp16
+    # checkpoint scales the module uses: rtol = atol = 1e-2 (the reference's tolerance)
+    from oracle.fakequant import quant_layer_forward
+    key = c["key"]
+
+    def ck(sfx, field, i):
+        return torch.from_numpy(modules_golden[f"{key}.ckpt.{sfx}.{field}"]).float()[i]
+
+    fm32 = make_float_module(c).half().float()
+    kw = None
+    if c["kind"] == "conv":
+        kw = dict(stride=fm32.stride, padding=fm32.padding, dilation=fm32.dilation, groups=1)
+    with torch.no_grad():
+        sim = quant_layer_forward(module_input(c).float(), fm32.weight, fm32.bias,
+                                  ck("weight_quantizer", "delta_list", 1),
+                                  ck("act_quantizer", "delta_list", 2),
+                                  ck("act_quantizer", "zero_point_list", 2), 4, 8, kw)
+    ref = torch.from_numpy(fakequant_golden[f"{key}.pathA_w4a8"])
+    if c.get("bos"):
+        y, sim, ref = y[:, 1:], sim[:, 1:], ref[:, 1:]
+    torch.testing.assert_close(y, sim, rtol=1e-2, atol=1e-2)
+    # vs the reference QuantLayer's own output (fp32 scales; the fp16 rounding of a 4-bit step can
+    # move a weight by one LSB = delta, hence the wider bound on isolated elements)
+    assert (y - ref).abs().mean().item() <= 2e-3 * ref.abs().max().item() + 1e-3

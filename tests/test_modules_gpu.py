@@ -246,3 +246,77 @@ def test_fused_path_with_fp16_fallback_layers(C):
         out = unet(**inp)[0].float()
     assert torch.isfinite(out).all()
     assert (out - ref).abs().max().item() < 0.05 * ref.abs().max().item() + 0.02
+
+
+# ----------------------------------------------------------------------------- W4A8 (f-2)
+@pytest.mark.parametrize("c", [c for c in MODULE_CASES if c["cin"] % 32 == 0 and not c.get("split")],
+                         ids=[c["key"] for c in MODULE_CASES if c["cin"] % 32 == 0 and not c.get("split")])
+def test_w4a8_module_on_hip_kernels_tracks_path_a(C, modules_golden, fakequant_golden, c):
+    """w4_kernel=True: the layer runs the packed-W4 INT8 kernels (the reference would fall back to
+    FP16).  Oracle = Path A at 4-bit weights: restated with the same fp16
+    checkpoint scales, rtol = atol = 1e-2."""
+    from mixdq_amd.nn import QuantizedConv2d, QuantizedLinear
+    from oracle.fakequant import quant_layer_forward
+    from tests.cases import make_float_module
+    cls = QuantizedLinear if c["kind"] == "linear" else QuantizedConv2d
+    fm = prepared(c, modules_golden, w_bit=4)
+    fm.w4_kernel = True
+    qm = cls.from_float(fm, ckpt=module_ckpt(c, modules_golden)).to(DEV)
+    assert qm.valid_for_acceleration and qm.w_packed4
+    x = module_input(c)
+    with torch.no_grad():
+        y = qm(x.to(DEV)).float().cpu()
+    key = c["key"]
+
+    def ck(sfx, field, i):
+        return torch.from_numpy(modules_golden[f"{key}.ckpt.{sfx}.{field}"]).float()[i]
+
+    fm32 = make_float_module(c).half().float()
+    kw = None
+    if c["kind"] == "conv":
+        kw = dict(stride=fm32.stride, padding=fm32.padding, dilation=fm32.dilation, groups=1)
+    with torch.no_grad():
+        sim = quant_layer_forward(x.float(), fm32.weight, fm32.bias,
+                                  ck("weight_quantizer", "delta_list", 1),
+                                  ck("act_quantizer", "delta_list", 2),
+                                  ck("act_quantizer", "zero_point_list", 2), 4, 8, kw)
+    if c.get("bos"):
+        y, sim = y[:, 1:], sim[:, 1:]
+    torch.testing.assert_close(y, sim, rtol=1e-2, atol=1e-2)
+
+
+def test_mixed_precision_unet_with_w4_kernels(C):
+    """A mixed 8/4/2-bit weight config (the shape of the reference's weight_4.00.yaml): with
+    w4_kernel=True every layer whose shape allows runs on the INT8 kernels, and the network tracks
+    its FP16 version at 4-bit quantization-noise level."""
+    from mixdq_amd.calib import calibrate, precompute_bos
+    from mixdq_amd.nn import QuantizedConv2d, QuantizedLinear
+    from mixdq_amd.quantize_sdxl import quantize_unet
+    from mixdq_amd.unet import build_unet, quantizable_layers
+    unet = build_unet(DEV, cfg=TINY)
+    inp = tiny_inputs(B=1, L=16)
+    inp = dict(sample=inp["sample"].half().to(DEV), timestep=inp["timestep"].to(DEV),
+               encoder_hidden_states=inp["encoder_hidden_states"].half().to(DEV),
+               added_cond_kwargs={k: v.half().to(DEV) for k, v in inp["added_cond_kwargs"].items()})
+    with torch.no_grad():
+        ref = unet(**inp)[0].float()
+    ckpt = calibrate(unet, [inp])
+    bos = precompute_bos(unet, inp["encoder_hidden_states"])
+    names = list(quantizable_layers(unet))
+    bits = {"model." + n: (8, 4, 8, 4, 2)[i % 5] if i % 10 else 2 for i, n in enumerate(names)}
+    quantize_unet(unet, Args(bits, {"model." + n: 8 for n in names}), ckpt, bos=True, bos_dict=bos,
+                  w4_kernel=True)
+    q = [m for m in unet.modules() if isinstance(m, (QuantizedLinear, QuantizedConv2d))]
+    n4 = sum(m.valid_for_acceleration and m.w_packed4 for m in q)
+    assert n4 > len(q) // 3
+    outs = []
+    for fused in (False, True):
+        unet.set_fused(fused)
+        with torch.no_grad():
+            out = unet(**inp)[0].float()
+        assert torch.isfinite(out).all()
+        outs.append(out)
+        # 4-/2-bit weights on a random-weight network: large but bounded quantization noise
+        assert (out - ref).abs().mean().item() < ref.abs().mean().item() + 0.02
+    # the fused and unfused graphs agree far better than either agrees with FP16
+    assert (outs[0] - outs[1]).abs().mean().item() < 0.5 * (outs[0] - ref).abs().mean().item() + 0.01

@@ -463,3 +463,63 @@ def test_every_kernel_configuration_is_bit_exact(C, oracle, cfg):
                                 None, t(bias), stride, pad, _cfg=cfg)
     want = oracle.qconv2d(x, wt, scale, wsum, in_zp, None, bias, stride, pad, C.FLAGS & 1)
     assert_bits_equal(out.permute(0, 2, 3, 1).contiguous().cpu().numpy(), want, f"conv cfg {cfg}")
+
+
+# --------------------------------------------------------------------- packed W4 weights (f-2)
+W4_LINEAR = [(203, 1280, 136, True), (1024, 1280, 1280, False), (64, 5120, 640, True),
+             (4096, 640, 640, True), (3000, 1280, 5120, False), (77, 2048, 640, False)]
+
+
+@pytest.mark.parametrize("M,K,N,bias", W4_LINEAR)
+def test_qlinear_w4_equals_w8_on_unpacked_values(C, oracle, M, K, N, bias):
+    """MIXDQ_FLAG_W4: packed signed 4-bit weights, unpacked in the kernel.  Must equal the oracle's
+    W8 restatement run on oracle.unpack_w4(packed) bit for bit (every kernel configuration)."""
+    from mixdq_amd.nn.utils import pack_w4
+    a = dd.int8(91, (M, K))
+    q = dd.int8(92, (N, K), -8, 8)
+    packed = pack_w4(torch.from_numpy(q))
+    wsum = q.astype(np.float32).sum(axis=1, dtype=np.float32)
+    b0 = (wsum * np.float32(-7.0)).astype(np.float32)
+    sc = dd.f32(93, (N,), 1e-3, 1e-2)
+    bs = dd.f16(94, (N,), -1, 1) if bias else None
+    want = oracle.qlinear(a, oracle.unpack_w4(packed.numpy()), b0, sc, bs, C.FLAGS & 1)
+    assert np.array_equal(oracle.unpack_w4(packed.numpy()), q)
+    for cfg in (0, 3, 4, 6, 18, 20):
+        out = C.qlinear_w8_a8_ohalf(t(a), packed.to(DEV), t(sc), scal(1), scal(0), t(wsum), t(sc),
+                                    t(b0), None if bs is None else t(bs), _w4=True, _cfg=cfg)
+        assert_bits_equal(out.cpu().numpy(), want, f"w4 linear cfg {cfg}")
+
+
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[4] % 32 == 0 and c[0] in (
+    "conv_res_320", "conv_res_960_640", "conv_down_s2", "conv_shortcut_1x1", "conv_odd_hw",
+    "conv_tiny_hw", "conv_s2_odd")], ids=lambda c: c[0])
+def test_qconv2d_w4_equals_w8_on_unpacked_values(C, oracle, case):
+    from mixdq_amd.nn.utils import pack_w4
+    name, n, h, w_, c, k, r, s, pad, stride, has_bias, rng, seed = case
+    x = dd.int8(seed + 1000, (n, h, w_, c))
+    q = dd.int8(seed, (k, r, s, c), -8, 8)
+    packed = pack_w4(torch.from_numpy(q))                          # [K, R, S, C/2]
+    sc = dd.f32(seed + 2000, (k,), 1e-3, 1e-2)
+    zp = np.float32(-11.0)
+    bias = dd.f16(seed + 3000, (k,)) if has_bias else None
+    wsum = q.astype(np.float32).sum(axis=3, dtype=np.float32)
+    bias0 = (wsum.reshape(k, -1).sum(axis=1, dtype=np.float32) * zp).astype(np.float32)
+    want = oracle.qconv2d(x, oracle.unpack_w4(packed.numpy()), sc, wsum if pad else None, zp,
+                          bias0 if not pad else None, bias, stride, pad, C.FLAGS & 1)
+    win = packed.to(DEV).permute(0, 3, 1, 2)                       # [K, C/2, R, S] channels-last
+    for cfg in (0, 3, 4, 6, 18, 20):
+        out = C.qconv2d_w8_a8_ohalf(t(x).permute(0, 3, 1, 2), win, t(sc), scal(1), scal(zp), t(sc),
+                                    t(wsum.reshape(k, 1, r, s)) if pad else None,
+                                    t(bias0) if not pad else None,
+                                    None if bias is None else t(bias), stride, pad, _w4=True,
+                                    _cfg=cfg)
+        assert_bits_equal(out.permute(0, 2, 3, 1).contiguous().cpu().numpy(), want,
+                          f"w4 conv {name} cfg {cfg}")
+
+
+def test_w4_rejects_unaligned_k(C):
+    a = torch.zeros(4, 48, dtype=torch.int8, device=DEV)
+    w = torch.zeros(8, 24, dtype=torch.int8, device=DEV)
+    v = torch.zeros(8, device=DEV)
+    with pytest.raises(RuntimeError, match="unsupported"):
+        C.qlinear_w8_a8_ohalf(a, w, v, scal(0), scal(0), v, v, v, None, _w4=True)
