@@ -282,17 +282,20 @@ class BasicTransformerBlock(nn.Module):
         a = self.attn1
         layers = [a.to_q, a.to_k, a.to_v]
         ok = (all(_accel(m) and m.bias is None for m in layers)
+              and len({bool(m.w_packed4) for m in layers}) == 1
               and _same_qparams(layers[0], layers[1]) and _same_qparams(layers[0], layers[2]))
         if not ok:
             self.__dict__["_qkv"] = False
             return None
+        w4 = bool(layers[0].w_packed4)
+        attr = "weight_int4" if w4 else "weight_int"     # packed rows concatenate the same way
         with torch.no_grad():
-            w = torch.cat([m.weight_int for m in layers], dim=0).contiguous()
+            w = torch.cat([getattr(m, attr) for m in layers], dim=0).contiguous()
             C = layers[0].out_features
             for i, m in enumerate(layers):
-                m.weight_int = w[i * C:(i + 1) * C]
+                setattr(m, attr, w[i * C:(i + 1) * C])
             pack = dict(
-                w=w, C=C,
+                w=w, C=C, w4=w4,
                 wscale=torch.cat([m.weight_scales for m in layers]),
                 wsum=torch.cat([m.weight_sum_by_input_channels for m in layers]),
                 scale=torch.cat([m.scale for m in layers]).contiguous(),
@@ -309,7 +312,7 @@ class BasicTransformerBlock(nn.Module):
             from mixdq_amd.op.qlinear import qlinear
             q0 = a.to_q
             qkv = qlinear(feeds[0][0], pack["w"], pack["wscale"], q0.act_scales, q0.act_zero_points,
-                          pack["wsum"], pack["scale"], pack["bias0"], None)
+                          pack["wsum"], pack["scale"], pack["bias0"], None, _w4=pack["w4"])
             C = pack["C"]
             o = a.attend(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:])
         else:
