@@ -57,6 +57,8 @@ def parse_args():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--sweep-reps", type=int, default=5)
+    ap.add_argument("--tiny", action="store_true",
+                    help="small UNet config (tests of the harness itself; not a benchmark)")
     return ap.parse_args()
 
 
@@ -231,10 +233,13 @@ def cpu_fake_quant_baseline(seconds_budget):
 def main():
     args = parse_args()
     from mixdq_amd import shard
-    rank, local_rank, world = shard.init_distributed()
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU fallback)"
-    device = torch.device("cuda", local_rank)
+    # MIXDQ_DIST_BACKEND=gloo + MIXDQ_SHARE_DEVICE=1: several ranks on ONE GPU, to exercise the
+    # N > 1 code path on a single-GPU box (harness test only).
+    share = os.environ.get("MIXDQ_SHARE_DEVICE") == "1"
+    rank, local_rank, world = shard.init_distributed(os.environ.get("MIXDQ_DIST_BACKEND"))
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    device = torch.device("cuda", 0 if share else local_rank)
     torch.cuda.set_device(device)
 
     import mixdq_amd._C as C
@@ -247,7 +252,13 @@ def main():
     L = args.px // 8
     B = args.batch
     t_setup = time.perf_counter()
-    unet = build_unet(device)
+    tiny_cfg = None
+    if args.tiny:
+        tiny_cfg = dict(block_out_channels=(32, 64, 128), transformer_layers_per_block=(0, 1, 2),
+                        mid_transformer_layers=1, head_dim=16, cross_attention_dim=2048,
+                        time_embed_dim=128, addition_time_embed_dim=16,
+                        projection_class_embeddings_input_dim=1280 + 96, norm_num_groups=8)
+    unet = build_unet(device, cfg=tiny_cfg)
     inputs = example_inputs(B, L, device, seed=42 + rank)
     shapes = layer_shapes(unet, inputs)
     ckpt = calibrate(unet, [inputs], bos=not args.no_bos)
@@ -278,8 +289,15 @@ def main():
                 unet.forward = unet.forward.__wrapped__
             unet.set_fused(False)
 
-    quantize_unet(unet, Cfg(cfgs.load(args.w_config), cfgs.load(args.a_config)), ckpt,
-                  bos=not args.no_bos, bos_dict=bos_dict, w4_kernel=args.w4_kernel)
+    if args.tiny:
+        from mixdq_amd.unet import quantizable_layers
+        names = list(quantizable_layers(unet))
+        w_cfg = {n: 8 for n in names}
+        a_cfg = {n: 8 for n in names if n not in ("conv_in", "conv_out")}
+    else:
+        w_cfg, a_cfg = cfgs.load(args.w_config), cfgs.load(args.a_config)
+    quantize_unet(unet, Cfg(w_cfg, a_cfg), ckpt, bos=not args.no_bos, bos_dict=bos_dict,
+                  w4_kernel=args.w4_kernel)
     unet.set_fused(not args.no_fuse)
     bcast_bytes = shard.broadcast_module_state(unet, src=0)
     qmods = [m for m in unet.modules() if isinstance(m, (QuantizedLinear, QuantizedConv2d))]
