@@ -209,6 +209,26 @@ int mixdq_geglu_quantize(const void* h_f16, int64_t M, int D,
                          int8_t* out_q_or_null, void* out_f16_or_null, int flags,
                          mixdq_stream_t stream);
 
+/* FP16 attention core, head_dim 64: out[b, t, h*64 + d] = softmax_k(q . k * softmax_scale) v, per
+ * head h.  The reference keeps these matmuls in FP16 (quant_block.py:630-637: get_attention_scores
+ * + torch.bmm; diffusers' AttnProcessor at run time) — only to_q/to_k/to_v/to_out.0 are quantized
+ * Linears — so this is a floating-point op with a tolerance oracle, not an integer one.
+ * q [batch, tq, heads*64], k/v [batch, tkv, heads*64] fp16 with arbitrary batch/row strides in
+ * ELEMENTS (multiples of 8; column slices of a fused q|k|v projection are fine).  Softmax in FP32,
+ * P rounded to FP16 for the second product, output rounded to FP16.
+ * out: fp16 rows (out_scale_inv == null), or — fused producer of to_out.0's INT8 operand — int8
+ * rows q = sat8(rint(f16_out * scale_inv + zero_point)) (same arithmetic as mixdq_quantize_f16_i8).
+ * flags: MIXDQ_FLAG_UNFUSED selects the unfused quantize variant; bits 8..15 force the workgroup
+ * shape (4 = 128 query rows, 2 = 64). */
+int mixdq_attention_f16(const void* q_f16, const void* k_f16, const void* v_f16, void* out,
+                        int batch, int heads, int head_dim, int tq, int tkv,
+                        int64_t q_batch_stride, int64_t q_row_stride,
+                        int64_t k_batch_stride, int64_t k_row_stride,
+                        int64_t v_batch_stride, int64_t v_row_stride,
+                        int64_t out_batch_stride, int64_t out_row_stride,
+                        float softmax_scale, const float* out_scale_inv_or_null,
+                        const float* out_zero_point_or_null, int flags, mixdq_stream_t stream);
+
 /* Which kernel instantiation mixdq_qlinear_w8a8 / mixdq_qconv2d_w8a8 will launch for a problem of
  * M rows x N output channels (k_align = K for Linear, C for Conv2d; k_total = K or R*S*C): the block tile BM x BN x BK
  * and LDS stage count of `igemm_kernel<BM,BN,BK,STAGES,CONV>`, or zeros for the small-alignment

@@ -23,7 +23,7 @@ import os
 import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libmixdq_hip.so")
+LIB_PATH = os.environ.get("MIXDQ_HIP_LIB") or os.path.join(_PKG, "libmixdq_hip.so")
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(
@@ -456,3 +456,34 @@ def geglu_quantize(h, scale_inv=None, zero_point=None, want_f16=False):
                                          _ptr(out_q), _ptr(out_h), FLAGS, _stream())
     _status(code, "geglu_quantize")
     return out_q, out_h
+
+
+_lib.mixdq_attention_f16.argtypes = [_vp] * 4 + [_i32] * 5 + [_i64] * 8 + [ctypes.c_float, _vp, _vp,
+                                                                       _i32, _vp]
+_lib.mixdq_attention_f16.restype = _i32
+
+
+def attention_f16(q, k, v, heads, scale_inv=None, zero_point=None, softmax_scale=None, _cfg=0):
+    """FP16 attention core (the reference's get_attention_scores + bmm, quant_block.py:630-637).
+
+    q [B, Tq, C], k/v [B, Tkv, C] fp16 with unit stride along C (column slices of a fused projection
+    are read in place); C = heads * 64.  Returns fp16 [B, Tq, C], or — when `scale_inv`/`zero_point`
+    (to_out.0's activation quantizer) are given — its int8 quantization.
+    """
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        _check(t.is_cuda and t.dtype == torch.float16 and t.dim() == 3 and t.stride(-1) == 1,
+               f"{n} should be a [B, T, C] fp16 GPU tensor with unit stride along C")
+    B, Tq, C = q.shape
+    _check(k.shape == v.shape and k.shape[0] == B and k.shape[2] == C, "q/k/v shapes disagree")
+    _check(C == heads * 64, "head_dim must be 64")
+    quant = scale_inv is not None
+    out = torch.empty((B, Tq, C), dtype=torch.int8 if quant else torch.float16, device=q.device)
+    sc = float(softmax_scale) if softmax_scale is not None else 0.125
+    with torch.cuda.device(q.device):
+        code = _lib.mixdq_attention_f16(
+            q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, heads, 64, Tq, k.shape[1],
+            q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
+            out.stride(0), out.stride(1), sc, _ptr(scale_inv), _ptr(zero_point),
+            FLAGS | (int(_cfg) << 8), _stream())
+    _status(code, "attention_f16")
+    return out

@@ -11,13 +11,17 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libmixdq_hip.so")
-SOURCES = ["quantize.hip", "igemm.hip", "fused_norm.hip"]
+SOURCES = ["quantize.hip", "igemm.hip", "fused_norm.hip", "attention.hip"]
 HEADERS = ["common.h", os.path.join("..", "..", "include", "mixdq_hip.h"),
            os.path.join("..", "..", "include", "mixdq_math.h")]
 # -ffp-contract=off: every fused multiply-add in the arithmetic specification is written
 # explicitly (__builtin_fmaf); the compiler must not introduce others.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
          "-fno-fast-math", "-Wall", "-Wno-unused-function"]
+# Per-file extras.  attention.hip: keep the MFMA accumulators in VGPRs — the softmax works on them
+# between the two products, and the default AGPR form costs ~190 v_accvgpr moves per K/V tile.
+EXTRA = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+OBJ = os.path.join(PKG, "_obj")
 
 
 def _hipcc():
@@ -37,7 +41,25 @@ def needs_build() -> bool:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     if force or needs_build():
-        cmd = [_hipcc()] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+        os.makedirs(OBJ, exist_ok=True)
+        hdr_t = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+        hdr_t = max(hdr_t, os.path.getmtime(os.path.abspath(__file__)))
+        procs, objs = [], []
+        for src in SOURCES:
+            path = os.path.join(CSRC, src)
+            obj = os.path.join(OBJ, src.replace(".hip", ".o"))
+            objs.append(obj)
+            if (not force and os.path.exists(obj)
+                    and os.path.getmtime(obj) > max(hdr_t, os.path.getmtime(path))):
+                continue
+            cmd = [_hipcc()] + FLAGS + EXTRA.get(src, []) + ["-c", "-o", obj, path]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((cmd, subprocess.Popen(cmd)))
+        for cmd, pr in procs:                      # the files compile in parallel
+            if pr.wait() != 0:
+                raise subprocess.CalledProcessError(pr.returncode, cmd)
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

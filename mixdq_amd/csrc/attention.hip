@@ -1,0 +1,381 @@
+// FP16 attention core for gfx950 (head_dim 64): O = softmax(Q K^T * scale) V, flash-style.
+//
+// The reference keeps the attention matmuls in FP16 in both of its paths (SURVEY.md §0:
+// quant_block.py:630-637 — plain get_attention_scores + torch.bmm; only to_q/to_k/to_v/to_out.0 are
+// quantized).  This kernel is that FP16 core, written for CDNA4, reading q/k/v straight out of the
+// (fused) projection output — head h is the 64-column slice h*64.. of each row, any row stride —
+// and writing either FP16 rows or, fused, the INT8 operand of to_out.0 (same quantize arithmetic as
+// mixdq_quantize_f16_i8 applied to the FP16-rounded output).
+//
+// Structure per workgroup: WAVES waves x 32 query rows; K/V tiles of 64 keys, double-buffered in
+// LDS through registers (loads for tile t+1 are issued before the MFMAs of tile t and written after
+// them: one barrier per tile).
+//   S^T = K Q^T      v_mfma_f32_32x32x16_f16, A = K rows (ds_read_b128, XOR-swizzled image),
+//                    B = Q^T held in registers.  Lane (q = lane%32, h = lane/32) then owns, for ITS
+//                    query, keys 32kb + 8g + 4h + 0..3: the row max / row sum are in-lane reductions
+//                    plus one v_permlane32_swap.
+//   O^T = V^T P^T    B = P^T is the S^T accumulator itself, converted to FP16 in place (k-slot j of
+//                    half h <-> key 32kb + 16u + 8(j/4) + 4h + j%4); A = V^T comes from the row-major
+//                    V image through ds_read_b64_tr_b16 with the same slot order (192-B row stride:
+//                    the four rows of a transposed read fall in four disjoint 16-bank ranges).
+// Softmax in FP32 with base-2 exponentials (v_exp_f32), P rounded to FP16 for the second MFMA, row
+// sums accumulated in FP32 from the unrounded P; O staged through LDS and stored as whole 128-B rows.
+#include "common.h"
+
+namespace mixdq {
+namespace {
+
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef short v4s16 __attribute__((__vector_size__(4 * sizeof(short))));
+
+constexpr int kHeadDim = 64;
+constexpr int kKeys = 64;            // keys per tile
+constexpr int kRow = 128;            // K and V images: 64 halfs per key, XOR-swizzled 16-B chunks
+constexpr int kTileBytes = kKeys * kRow;          // one K (or V) tile
+constexpr int kStageBytes = 2 * kTileBytes;       // K tile then V tile
+constexpr int kORow = 144;           // output staging row (32 x 144 B per wave)
+
+struct AttnParams {
+  const __half* q; const __half* k; const __half* v;
+  void* out;                       // f16 rows or int8 rows
+  long q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;   // batch / row strides in elements
+  int tq, tkv, heads, qblocks;
+  float scale_log2;                // softmax scale * log2(e)
+  const float* s_inv; const float* zp;
+  int unfused;
+};
+
+__device__ __forceinline__ float half_max(float x) {
+  // max over lanes l and l^32
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float half_sum(float x) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+__device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds(
+      (const __attribute__((address_space(1))) void*)gsrc,
+      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+typedef int v2i __attribute__((ext_vector_type(2)));
+union VFrag { struct { v2i lo, hi; } r; v8h h; };
+
+// Two transposed reads (keys k..k+3 and k+8..k+11 of 16 output columns) = one A operand.
+template <int OFF>
+__device__ __forceinline__ void tr_read2_imm(VFrag& f, unsigned addr) {
+  asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
+               : "=&v"(f.r.lo), "=&v"(f.r.hi)
+               : "v"(addr), "n"(OFF), "n"(OFF + 8 * kRow)
+               : "memory");
+}
+__device__ __forceinline__ void s_waitcnt_lgkm0() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);   // keep register-only MFMAs behind the wait
+}
+
+template <int WAVES, int STAGES, bool QUANT>
+__global__ __launch_bounds__(WAVES * 64) void attn_fwd_kernel(const AttnParams p) {
+  constexpr int NI = 16 / WAVES;                 // LDS-DMA wave-instructions per wave per tile
+  constexpr int PRE = STAGES - 1;                // tiles staged ahead of the one whose V is consumed
+  static_assert(STAGES >= 3, "tiles t (V) and t+1 (K) are read while t+2.. are in flight");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keep it scalar
+  const int l32 = lane & 31, hh = lane >> 5;
+  const int qb = blockIdx.x % p.qblocks;
+  const int head = (blockIdx.x / p.qblocks) % p.heads;
+  const int b = blockIdx.x / (p.qblocks * p.heads);
+  const int q0 = qb * (WAVES * 32) + wave * 32;
+
+  // Q^T fragments: lane's query row, d = 16 ks + 8 h .. + 7
+  v8h qf[4];
+  {
+    const int qr = min(q0 + l32, p.tq - 1);
+    const __half* qrow = p.q + b * p.q_bs + (long)qr * p.q_rs + head * kHeadDim + hh * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const v8h*>(qrow + ks * 16);
+  }
+
+  // LDS-DMA staging: one wave-instruction fills 8 keys x 128 B, lane -> (key l/8, slot l%8); the
+  // slot holds chunk slot ^ swizzle(key), so the SOURCE address carries the permutation.
+  //   K image: chunk ^ ((key >> 1) & 7)     (conflict-free ds_read_b128 of the A operand)
+  //   V image: chunk ^ 4*((key >> 1) & 1)   (the 4 rows of a transposed read -> 4 disjoint ranges)
+  // A wave's NI instructions are all-K or all-V (waves 0..WAVES/2-1 stage K, the rest V).
+  const int srow = lane >> 3, spos = lane & 7;
+  const bool stage_v = wave * NI >= 8;
+  const __half* sbase = (stage_v ? p.v + b * p.v_bs : p.k + b * p.k_bs) + head * kHeadDim;
+  const int srs = (int)(stage_v ? p.v_rs : p.k_rs);
+  const int last_key = p.tkv - 1;
+  int row_off[NI], col_off[NI];                  // element offsets of this lane's rows / chunks
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int krow = ((wave * NI + i) & 7) * 8 + srow;     // key row within the tile
+    const int sw = stage_v ? ((krow >> 1) & 1) << 2 : (krow >> 1) & 7;
+    col_off[i] = (spos ^ sw) * 8;
+    row_off[i] = krow * srs + col_off[i];
+  }
+  auto stage = [&](int buf, int t) {
+    char* dst = smem + buf * kStageBytes + wave * NI * 1024;
+    if ((t + 1) * kKeys <= p.tkv) {                       // whole tile in range (wave-uniform)
+      const int tile_off = t * kKeys * srs;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) glds16(sbase + (tile_off + row_off[i]), dst + i * 1024);
+    } else {
+      // keys past the end re-read the last key: finite data whose scores are masked to -inf below
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int key = min(t * kKeys + ((wave * NI + i) & 7) * 8 + srow, last_key);
+        glds16(sbase + (key * srs + col_off[i]), dst + i * 1024);
+      }
+    }
+  };
+
+  // per-lane LDS read offsets
+  int k_rd[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) k_rd[ks] = l32 * kRow + (((2 * ks + hh) ^ ((l32 >> 1) & 7)) << 4);
+  const int q4 = (lane & 15) >> 2, pp = lane & 3, g16 = (lane >> 4) & 1;
+  const int v_rd0 = kTileBytes + (4 * hh + q4) * kRow +
+                    (((2 * g16 + (pp >> 1)) ^ (((q4 >> 1) & 1) << 2)) << 4) + 8 * (pp & 1);
+  const int v_rd1 = v_rd0 ^ 64;                  // output columns 32..63: chunk index ^ 4
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned v_a0 = lds0 + v_rd0, v_a1 = lds0 + v_rd1;
+  unsigned k_a[4];                               // absolute LDS addresses: offsets fold to immediates
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) k_a[ks] = lds0 + k_rd[ks];
+
+  const int ntiles = (p.tkv + kKeys - 1) / kKeys;
+  const bool ragged = (p.tkv & (kKeys - 1)) != 0;
+
+  // S^T = K Q^T for the tile in buffer `buf` (tile index t for the ragged-tail mask)
+  auto qk = [&](int buf, int t, v16f (&s)[2]) {
+    v8h kf[2][4];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        kf[kb][ks] = *(const __attribute__((address_space(3))) v8h*)(size_t)(
+            k_a[ks] + (buf * kStageBytes + kb * 32 * kRow));
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][ks], qf[ks], s[kb], 0, 0, 0);
+    }
+    if (ragged && t == ntiles - 1) {               // mask the absent keys of the last tile
+      asm volatile("" ::: "memory");               // a real branch: not worth if-converting
+      const int lim = p.tkv - t * kKeys - 4 * hh;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (32 * kb + 8 * (r >> 2) + (r & 3) >= lim) s[kb][r] = -INFINITY;
+    }
+  };
+
+  static_assert(STAGES % 2 == 0, "the score registers ping-pong with the buffer parity");
+  v16f o[2], lsum;                               // lsum: row sums, every register of a lane equal
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; lsum[i] = 0.f; }
+  float m_i = -INFINITY;
+  const float c = p.scale_log2;
+  v8h ones;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ones[i] = (_Float16)1.f;
+
+#pragma unroll
+  for (int s = 0; s < PRE; ++s) stage(s, s);     // tiles past the end re-stage the last key
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((PRE - 1) * NI) : "memory");
+  v16f S[2][2];                                  // scores: S[t & 1] softmaxed now, S[~t & 1] next
+  qk(0, 0, S[0]);
+
+  // Software pipeline, per iteration t: [V(t) transposed reads, K(t+1) reads] -> QK^T(t+1) MFMAs
+  // -> softmax(t) on the VALU while those MFMAs run -> PV(t) MFMAs (+ the row sums, as a product
+  // with a ones operand: the sums of the FP16-rounded P the second product actually uses).
+  for (int t0 = 0; t0 < ntiles; t0 += STAGES) {
+#pragma unroll
+    for (int sb = 0; sb < STAGES; ++sb) {          // tile t0 + sb lives in buffer sb (compile-time)
+      const int t = t0 + sb;
+      if (t >= ntiles) break;
+      v16f (&sc)[2] = S[sb & 1];
+      v16f (&sn)[2] = S[(sb + 1) & 1];
+      // tile t+1 has landed (PRE-2 younger tiles may still fly); every wave is past tile t-1,
+      // whose buffer is restaged next
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((PRE - 2) * NI) : "memory");
+      stage((sb + PRE) % STAGES, t + PRE);
+
+      // V^T fragments of tile t.  Inline asm: hipcc puts `s_waitcnt vmcnt(0)` in front of the
+      // ds_read_tr builtin while an LDS-DMA is in flight (draining the prefetch ring every tile);
+      // the asm reads are counted by hand (s_waitcnt_lgkm0 below).
+      VFrag vf[2][2][2];
+      {
+        const unsigned a0 = v_a0 + sb * kStageBytes, a1 = v_a1 + sb * kStageBytes;
+        tr_read2_imm<0 * kRow>(vf[0][0][0], a0);
+        tr_read2_imm<0 * kRow>(vf[0][0][1], a1);
+        tr_read2_imm<16 * kRow>(vf[0][1][0], a0);
+        tr_read2_imm<16 * kRow>(vf[0][1][1], a1);
+        tr_read2_imm<32 * kRow>(vf[1][0][0], a0);
+        tr_read2_imm<32 * kRow>(vf[1][0][1], a1);
+        tr_read2_imm<48 * kRow>(vf[1][1][0], a0);
+        tr_read2_imm<48 * kRow>(vf[1][1][1], a1);
+      }
+
+      // ---- scores of the NEXT tile: these MFMAs run under the softmax below ----
+      if (t + 1 < ntiles) qk((sb + 1) % STAGES, t + 1, sn);
+
+      // ---- online softmax of tile t (lane = one query row; the other 32 keys: lane ^ 32) ----
+      float mx = sc[0][0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[0][r]);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[1][r]);
+      mx = half_max(mx);
+      const float m_new = fmaxf(m_i, mx);
+      const bool grew = m_new > m_i;
+      const float mc = m_new * c;
+      v8h pf[2][2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          pf[kb][r >> 3][r & 7] =
+              (_Float16)__builtin_amdgcn_exp2f(__builtin_fmaf(sc[kb][r], c, -mc));
+      if (__builtin_amdgcn_ballot_w64(grew)) {     // some row's maximum moved: rescale O and sums
+        const float alpha = __builtin_amdgcn_exp2f((m_i - m_new) * c);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+        lsum[0] *= alpha;
+      }
+      m_i = m_new;
+
+      // ---- O^T += V^T P^T, row sums += 1^T P^T ----
+      s_waitcnt_lgkm0();
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+          for (int db = 0; db < 2; ++db)
+            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[kb][u][db].h, pf[kb][u], o[db], 0, 0, 0);
+          lsum = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf[kb][u], lsum, 0, 0, 0);
+        }
+    }
+  }
+  // the DMAs staged for tiles >= ntiles may still be in flight: drain before LDS reuse
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- normalise, stage through LDS, store whole rows ----
+  const float inv = 1.f / lsum[0];
+  char* Os = smem + wave * (32 * kORow);
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      v4h w;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w[j] = (_Float16)(o[db][4 * g + j] * inv);
+      *reinterpret_cast<v4h*>(Os + l32 * kORow + (32 * db + 8 * g + 4 * hh) * 2) = w;
+    }
+  __syncthreads();
+  float s_inv = 0.f, zp = 0.f;
+  if constexpr (QUANT) { s_inv = *p.s_inv; zp = *p.zp; }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int id = lane + 64 * i, row = id >> 3, ch = id & 7;
+    if (q0 + row >= p.tq) continue;
+    const uint4 w = *reinterpret_cast<const uint4*>(Os + row * kORow + ch * 16);
+    const long off = b * p.o_bs + (long)(q0 + row) * p.o_rs + head * kHeadDim + ch * 8;
+    if constexpr (!QUANT) {
+      *reinterpret_cast<uint4*>(reinterpret_cast<__half*>(p.out) + off) = w;
+    } else {
+      const __half* hv = reinterpret_cast<const __half*>(&w);
+      uint32_t pk[2] = {0u, 0u};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float x = __half2float(hv[j]);
+        const int qv = p.unfused ? quantize_one<true>(x, s_inv, zp) : quantize_one<false>(x, s_inv, zp);
+        pk[j >> 2] |= (uint32_t)(qv & 0xff) << (8 * (j & 3));
+      }
+      *reinterpret_cast<uint2*>(reinterpret_cast<int8_t*>(p.out) + off) = make_uint2(pk[0], pk[1]);
+    }
+  }
+}
+
+constexpr int attn_smem_bytes(int waves, int stages) {
+  const int kv = stages * kStageBytes;
+  const int os = waves * 32 * kORow;
+  return kv > os ? kv : os;
+}
+
+template <int WAVES, int STAGES>
+int launch_attn(const AttnParams& p, int batch, bool quant, hipStream_t stream) {
+  const int grid = p.qblocks * p.heads * batch;
+  const int smem = attn_smem_bytes(WAVES, STAGES);
+  if (quant)
+    hipLaunchKernelGGL((attn_fwd_kernel<WAVES, STAGES, true>), dim3(grid), dim3(WAVES * 64), smem,
+                       stream, p);
+  else
+    hipLaunchKernelGGL((attn_fwd_kernel<WAVES, STAGES, false>), dim3(grid), dim3(WAVES * 64), smem,
+                       stream, p);
+  return launch_status();
+}
+
+}  // namespace
+}  // namespace mixdq
+
+using namespace mixdq;
+
+extern "C" int mixdq_attention_f16(const void* q, const void* k, const void* v, void* out,
+                                   int batch, int heads, int head_dim, int tq, int tkv,
+                                   int64_t q_batch_stride, int64_t q_row_stride,
+                                   int64_t k_batch_stride, int64_t k_row_stride,
+                                   int64_t v_batch_stride, int64_t v_row_stride,
+                                   int64_t out_batch_stride, int64_t out_row_stride,
+                                   float softmax_scale, const float* out_scale_inv,
+                                   const float* out_zero_point, int flags, mixdq_stream_t stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (batch < 0 || heads <= 0 || tq < 0 || tkv <= 0) return MIXDQ_ERR_INVALID_ARG;
+  if ((out_scale_inv == nullptr) != (out_zero_point == nullptr)) return MIXDQ_ERR_INVALID_ARG;
+  if (head_dim != kHeadDim) return MIXDQ_ERR_UNSUPPORTED;
+  if (batch == 0 || tq == 0) return MIXDQ_OK;       // nothing to write (pointers may be null)
+  if (!q || !k || !v || !out) return MIXDQ_ERR_INVALID_ARG;
+  const bool quant = out_scale_inv != nullptr;
+  // 16-byte vector accesses: rows of 8 halfs, bases and strides multiples of 8 elements
+  const int64_t strides[] = {q_batch_stride, q_row_stride, k_batch_stride, k_row_stride,
+                             v_batch_stride, v_row_stride, out_batch_stride, out_row_stride};
+  for (int64_t s : strides)
+    if (s % 8) return MIXDQ_ERR_ALIGNMENT;
+  // key-row offsets are formed in 32 bits
+  if ((int64_t)tkv * k_row_stride >= (1ll << 31) || (int64_t)tkv * v_row_stride >= (1ll << 31))
+    return MIXDQ_ERR_UNSUPPORTED;
+  if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) return MIXDQ_ERR_ALIGNMENT;
+  if ((uintptr_t)out & (quant ? 7 : 15)) return MIXDQ_ERR_ALIGNMENT;
+
+  AttnParams p;
+  p.q = (const __half*)q; p.k = (const __half*)k; p.v = (const __half*)v; p.out = out;
+  p.q_bs = q_batch_stride; p.q_rs = q_row_stride;
+  p.k_bs = k_batch_stride; p.k_rs = k_row_stride;
+  p.v_bs = v_batch_stride; p.v_rs = v_row_stride;
+  p.o_bs = out_batch_stride; p.o_rs = out_row_stride;
+  p.tq = tq; p.tkv = tkv; p.heads = heads;
+  p.scale_log2 = softmax_scale * 1.4426950408889634f;
+  p.s_inv = out_scale_inv; p.zp = out_zero_point;
+  p.unfused = (flags & MIXDQ_FLAG_UNFUSED) ? 1 : 0;
+
+  // 128-query workgroups when they still fill the chip twice over, 64-query ones otherwise
+  const int force = (flags >> 8) & 0xff;         // 4 / 2: waves per workgroup
+  const long blocks128 = (long)((tq + 127) / 128) * heads * batch;
+  const bool big = force ? force == 4 : blocks128 >= kNumCU / 2;
+  p.qblocks = big ? (tq + 127) / 128 : (tq + 63) / 64;
+  if (big) return launch_attn<4, 4>(p, batch, quant, stream);
+  return launch_attn<2, 4>(p, batch, quant, stream);
+}

@@ -215,6 +215,23 @@ class Attention(nn.Module):
         o = F.scaled_dot_product_attention(q, k, v)   # FP16, as in the reference
         return o.transpose(1, 2).reshape(B, T, C)
 
+    def attend_out(self, q, k, v, residual):
+        """residual + to_out[0](attention(q, k, v)) on the fused path: the HIP FP16 attention core
+        reads q/k/v in place (column slices of the fused projection included) and, when to_out[0]
+        is W8A8, emits its INT8 operand directly; the residual add rides in the GEMM epilogue."""
+        from mixdq_amd import _C
+        out = self.to_out[0]
+        C = q.shape[-1]
+        ok = (C == self.heads * 64 and all(_fusable_f16(t) and t.dim() == 3 and t.stride(-1) == 1
+                                           and t.stride(0) % 8 == 0 and t.stride(1) % 8 == 0
+                                           and t.data_ptr() % 16 == 0 for t in (q, k, v)))
+        if not ok:
+            return _linear_res(out, self.attend(q, k, v), residual)
+        if _accel(out) and residual.is_contiguous():
+            o_int = _C.attention_f16(q, k, v, self.heads, *_qp(out))
+            return out.forward_quantized(o_int, residual=residual)
+        return out(_C.attention_f16(q, k, v, self.heads)) + residual
+
 
 class GEGLU(nn.Module):
     def __init__(self, dim, inner):
@@ -314,11 +331,10 @@ class BasicTransformerBlock(nn.Module):
             qkv = qlinear(feeds[0][0], pack["w"], pack["wscale"], q0.act_scales, q0.act_zero_points,
                           pack["wsum"], pack["scale"], pack["bias0"], None, _w4=pack["w4"])
             C = pack["C"]
-            o = a.attend(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:])
+            x = a.attend_out(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], x)
         else:
-            fq, fk, fv = feeds
-            o = a.attend(_run(a.to_q, fq), _run(a.to_k, fk), _run(a.to_v, fv))
-        x = _linear_res(a.to_out[0], o, x)                          # x + attn1(norm1(x))
+            fq, fk, fv = feeds                                      # x + attn1(norm1(x))
+            x = a.attend_out(_run(a.to_q, fq), _run(a.to_k, fk), _run(a.to_v, fv), x)
         a = self.attn2
         (fq,) = _ln_feed(self.norm2, x, [a.to_q])
         kv = self.__dict__.pop("_kv", None)
@@ -329,8 +345,7 @@ class BasicTransformerBlock(nn.Module):
             v.record_stream(torch.cuda.current_stream())
         else:
             k, v = a.to_k(context), a.to_v(context)                 # K/V: BOS path
-        o = a.attend(_run(a.to_q, fq), k, v)
-        x = _linear_res(a.to_out[0], o, x)                          # x + attn2(norm2(x), ctx)
+        x = a.attend_out(_run(a.to_q, fq), k, v, x)                 # x + attn2(norm2(x), ctx)
         (ff,) = _ln_feed(self.norm3, x, [self.ff.net[0].proj])
         return self.ff.forward_fused(ff, x)                         # x + ff(norm3(x))
 

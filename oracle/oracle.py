@@ -226,6 +226,30 @@ def geglu_quantize(h, scale_inv, zero_point, variant=VARIANT_FUSED):
     return q, o
 
 
+def attention_f16(q, k, v, heads, softmax_scale=None):
+    """FP16 attention core, restated in float64: out[b, t, h*D + d] = softmax_k(q.k * scale) v per
+    head (the reference's get_attention_scores + torch.bmm, quant_block.py:630-637, diffusers'
+    AttnProcessor semantics; FP16 tensors, no mask).  q [B, Tq, C], k/v [B, Tkv, C] float16.
+    Returns (float16 result, float64 result).  A floating-point op: the HIP kernel is held to a
+    stated tolerance against this, not to bit equality (its INT8 output variant is then checked
+    bit-exactly as quantize() of its own FP16 output)."""
+    q = np.asarray(q, np.float16).astype(np.float64)
+    k = np.asarray(k, np.float16).astype(np.float64)
+    v = np.asarray(v, np.float16).astype(np.float64)
+    B, Tq, C = q.shape
+    D = C // heads
+    sc = (1.0 / np.sqrt(D)) if softmax_scale is None else float(softmax_scale)
+    qh = q.reshape(B, Tq, heads, D).transpose(0, 2, 1, 3)
+    kh = k.reshape(B, -1, heads, D).transpose(0, 2, 1, 3)
+    vh = v.reshape(B, -1, heads, D).transpose(0, 2, 1, 3)
+    s = np.einsum("bhqd,bhkd->bhqk", qh, kh) * sc
+    s -= s.max(axis=-1, keepdims=True)
+    p = np.exp(s)
+    p /= p.sum(axis=-1, keepdims=True)
+    o = np.einsum("bhqk,bhkd->bhqd", p, vh).transpose(0, 2, 1, 3).reshape(B, Tq, C)
+    return o.astype(np.float16), o
+
+
 def unpack_w4(packed: np.ndarray) -> np.ndarray:
     """W4 storage of include/mixdq_hip.h (MIXDQ_FLAG_W4), restated independently: within each
     group of 8 k-values, byte j holds k[j] in its high nibble and k[4+j] in its low nibble, two's
