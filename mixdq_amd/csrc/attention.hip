@@ -78,7 +78,7 @@ __device__ __forceinline__ void s_waitcnt_lgkm0() {
   __builtin_amdgcn_sched_barrier(0);   // keep register-only MFMAs behind the wait
 }
 
-template <int WAVES, int STAGES, bool QUANT>
+template <int WAVES, int STAGES, bool QUANT, bool RAGGED>
 __global__ __launch_bounds__(WAVES * 64) void attn_fwd_kernel(const AttnParams p) {
   constexpr int NI = 16 / WAVES;                 // LDS-DMA wave-instructions per wave per tile
   constexpr int PRE = STAGES - 1;                // tiles staged ahead of the one whose V is consumed
@@ -151,7 +151,6 @@ __global__ __launch_bounds__(WAVES * 64) void attn_fwd_kernel(const AttnParams p
   for (int ks = 0; ks < 4; ++ks) k_a[ks] = lds0 + k_rd[ks];
 
   const int ntiles = (p.tkv + kKeys - 1) / kKeys;
-  const bool ragged = (p.tkv & (kKeys - 1)) != 0;
 
   // S^T = K Q^T for the tile in buffer `buf` (tile index t for the ragged-tail mask)
   auto qk = [&](int buf, int t, v16f (&s)[2]) {
@@ -170,7 +169,7 @@ __global__ __launch_bounds__(WAVES * 64) void attn_fwd_kernel(const AttnParams p
       for (int ks = 0; ks < 4; ++ks)
         s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][ks], qf[ks], s[kb], 0, 0, 0);
     }
-    if (ragged && t == ntiles - 1) {               // mask the absent keys of the last tile
+    if (RAGGED && t == ntiles - 1) {               // mask the absent keys of the last tile
       asm volatile("" ::: "memory");               // a real branch: not worth if-converting
       const int lim = p.tkv - t * kKeys - 4 * hh;
 #pragma unroll
@@ -229,7 +228,8 @@ __global__ __launch_bounds__(WAVES * 64) void attn_fwd_kernel(const AttnParams p
       }
 
       // ---- scores of the NEXT tile: these MFMAs run under the softmax below ----
-      if (t + 1 < ntiles) qk((sb + 1) % STAGES, t + 1, sn);
+      // (past the last tile this reads a re-staged copy of the last key; the scores are unused)
+      qk((sb + 1) % STAGES, t + 1, sn);
 
       // ---- online softmax of tile t (lane = one query row; the other 32 keys: lane ^ 32) ----
       float mx = sc[0][0];
@@ -248,6 +248,18 @@ __global__ __launch_bounds__(WAVES * 64) void attn_fwd_kernel(const AttnParams p
         for (int r = 0; r < 16; ++r)
           pf[kb][r >> 3][r & 7] =
               (_Float16)__builtin_amdgcn_exp2f(__builtin_fmaf(sc[kb][r], c, -mc));
+      // pin P here: otherwise the exponentials sink below the rescale branch, away from the MFMAs
+      asm volatile("" ::"v"(pf[0][0]), "v"(pf[0][1]), "v"(pf[1][0]), "v"(pf[1][1]));
+      if constexpr (!RAGGED) {
+        // QK^T(t+1) MFMAs are independent of this softmax: spread them through it, one MFMA per
+        // 16 VALU instructions (a wave issues in order — left clustered, the MFMAs and the VALU
+        // work would run back to back instead of side by side)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);  // 16 VALU
+        }
+      }
       if (__builtin_amdgcn_ballot_w64(grew)) {     // some row's maximum moved: rescale O and sums
         const float alpha = __builtin_amdgcn_exp2f((m_i - m_new) * c);
 #pragma unroll
@@ -320,12 +332,13 @@ template <int WAVES, int STAGES>
 int launch_attn(const AttnParams& p, int batch, bool quant, hipStream_t stream) {
   const int grid = p.qblocks * p.heads * batch;
   const int smem = attn_smem_bytes(WAVES, STAGES);
-  if (quant)
-    hipLaunchKernelGGL((attn_fwd_kernel<WAVES, STAGES, true>), dim3(grid), dim3(WAVES * 64), smem,
-                       stream, p);
-  else
-    hipLaunchKernelGGL((attn_fwd_kernel<WAVES, STAGES, false>), dim3(grid), dim3(WAVES * 64), smem,
-                       stream, p);
+  const dim3 g(grid), b(WAVES * 64);
+  const bool ragged = (p.tkv & (kKeys - 1)) != 0;   // whole key tiles: no masking code at all
+#define MIXDQ_ATTN_LAUNCH(Q, R) \
+  hipLaunchKernelGGL((attn_fwd_kernel<WAVES, STAGES, Q, R>), g, b, smem, stream, p)
+  if (quant) { if (ragged) MIXDQ_ATTN_LAUNCH(true, true); else MIXDQ_ATTN_LAUNCH(true, false); }
+  else       { if (ragged) MIXDQ_ATTN_LAUNCH(false, true); else MIXDQ_ATTN_LAUNCH(false, false); }
+#undef MIXDQ_ATTN_LAUNCH
   return launch_status();
 }
 

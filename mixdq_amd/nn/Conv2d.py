@@ -99,6 +99,8 @@ class QuantizedConv2d(nn.Module):
             weight_int = torch.quantize_per_channel(
                 weight.float(), scales, getattr(self, "weight_zero_points" + sfx),
                 axis=w_qparams.axis, dtype=w_qparams.dtype).int_repr()
+            # KRSC in memory (the layout the kernel reads): stored once, never re-laid-out per call
+            weight_int = weight_int.contiguous(memory_format=torch.channels_last)
             self.register_buffer("weight_int" + sfx, weight_int)
         if pad == 0:
             # per-channel zero-point term (nn/Conv2d.py:166-171)

@@ -178,7 +178,13 @@ class ResnetBlock2D(nn.Module):
         return x + h
 
     def forward_fused(self, x, temb):
-        t = self.time_emb_proj(F.silu(temb))                       # [N, Cout]
+        ahead = self.__dict__.pop("_t", None)
+        if ahead is not None:       # projected ahead of time on the side stream (SDXLUNet.forward)
+            t, ready = ahead
+            torch.cuda.current_stream().wait_event(ready)
+            t.record_stream(torch.cuda.current_stream())
+        else:
+            t = self.time_emb_proj(F.silu(temb))                   # [N, Cout]
         feed, q = _gn_feed(self.norm1, x, self.conv1, silu=True)
         if q:   # h = conv1(..) + t[:, :, None, None], the add folded into the conv epilogue
             h = self.conv1.forward_quantized(feed, residual=t.contiguous(), residual_per_image=True)
@@ -556,6 +562,47 @@ class SDXLUNet(nn.Module):
                 blk._kv = (outs[0], outs[1], ready)
         context.record_stream(side)
 
+    def _project_temb_ahead(self, emb):
+        """Every ResnetBlock2D adds time_emb_proj(silu(emb)): 22 M = batch GEMMs (plus their SiLU
+        and quantize launches) that depend only on the time embedding.  In the fused graph they
+        run on the side stream before the keys / values; SiLU runs once, and layers with identical
+        activation quantizers (all calibrated on this same tensor) share one INT8 copy."""
+        resnets = [m for m in self.modules() if isinstance(m, ResnetBlock2D)]
+        if not resnets or not emb.is_cuda:
+            return
+        if getattr(self, "_kv_stream", None) is None:
+            self._kv_stream = torch.cuda.Stream(device=emb.device)
+        main = torch.cuda.current_stream()
+        side = self._kv_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            s = F.silu(emb)
+            shared = []
+            for res in resnets:
+                layer = res.time_emb_proj
+                if _accel(layer) and _fusable_f16(s):
+                    x_int = None
+                    key = getattr(layer, "_t_group", None)
+                    if key is not None and key < len(shared):
+                        x_int = shared[key][1]
+                    else:
+                        for gi, (rep, xi) in enumerate(shared):
+                            if _same_qparams(rep, layer):
+                                layer._t_group, x_int = gi, xi
+                                break
+                    if x_int is None:
+                        from mixdq_amd.nn.Linear import quant_op
+                        x_int = quant_op(s, *_qp(layer))
+                        layer._t_group = len(shared)
+                        shared.append((layer, x_int))
+                    t = layer.forward_quantized(x_int)
+                else:
+                    t = layer(s)
+                ready = torch.cuda.Event()
+                ready.record(side)
+                res._t = (t, ready)
+        emb.record_stream(side)
+
     def set_fused(self, enabled: bool = True):
         """Switch the producer fusions on or off for the whole graph (see the top of this file)."""
         for m in self.modules():
@@ -580,6 +627,7 @@ class SDXLUNet(nn.Module):
         emb = emb + self.add_embedding(add)
 
         if self.fused and _fusable_f16(sample):
+            self._project_temb_ahead(emb)
             self._project_context_ahead(encoder_hidden_states)
         x = sample.contiguous(memory_format=torch.channels_last)
         x = self.conv_in(x)
