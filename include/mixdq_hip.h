@@ -209,6 +209,18 @@ int mixdq_geglu_quantize(const void* h_f16, int64_t M, int D,
                          int8_t* out_q_or_null, void* out_f16_or_null, int flags,
                          mixdq_stream_t stream);
 
+/* ff.net.0.proj + GEGLU + quantize in one launch: the GEMM of mixdq_qlinear_w8a8 whose N = 2D
+ * output columns arrive as value/gate groups of 32 ([v 0..31 | g 0..31 | v 32..63 | g 32..63 ...]:
+ * the caller stores W, bias0, scale and bias with rows in that order), reduced in the epilogue to
+ * out[m, d] = sat8(rint(y * scale_inv + zero_point)), y = f16(f16(v) * f16(gelu(f16(g)))) -- every
+ * rounding point of GEMM -> fp16 -> mixdq_geglu_quantize is kept, so the int8 [M, D] result is
+ * bit-identical to that two-launch chain (diffusers GEGLU: hidden, gate = proj(x).chunk(2);
+ * hidden * gelu(gate)).  N % 64 == 0, K % 16 == 0 (MIXDQ_ERR_UNSUPPORTED otherwise). */
+int mixdq_qlinear_w8a8_geglu(const int8_t* A, const int8_t* W_interleaved, const float* bias0,
+                             const float* scale, const void* bias_f16_or_null, int8_t* out_i8,
+                             int64_t M, int N, int K, const float* out_scale_inv,
+                             const float* out_zero_point, int flags, mixdq_stream_t stream);
+
 /* FP16 attention core, head_dim 64: out[b, t, h*64 + d] = softmax_k(q . k * softmax_scale) v, per
  * head h.  The reference keeps these matmuls in FP16 (quant_block.py:630-637: get_attention_scores
  * + torch.bmm; diffusers' AttnProcessor at run time) — only to_q/to_k/to_v/to_out.0 are quantized

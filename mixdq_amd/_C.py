@@ -75,7 +75,8 @@ IGEMM_CONFIGS = {1: (64, 64, 64, 2), 2: (64, 128, 64, 2), 3: (128, 128, 64, 2),
                  10: (128, 64, 128, 3), 11: (64, 128, 128, 4), 12: (128, 128, 128, 4),
                  13: (256, 128, 64, 3), 14: (256, 256, 64, 3), 15: (128, 256, 64, 3),
                  16: (256, 128, 64, 2), 17: (256, 256, 64, 2), 18: (256, 128, 128, 2),
-                 19: (128, 128, 64, 3), 20: (256, 256, 128, 2)}
+                 19: (128, 128, 64, 3), 20: (256, 256, 128, 2), 21: (64, 64, 128, 6),
+                 22: (64, 64, 128, 5)}
 
 FLAG_W4 = 2   # MIXDQ_FLAG_W4: the weight tensor holds packed signed 4-bit values
 
@@ -210,6 +211,41 @@ def qlinear_w8_a8_ohalf(input_int8, weight_int8, weight_scale, input_scale, inpu
                                             _stream())
     _status(code, "qlinear_w8_a8_ohalf")
     return D
+
+
+_lib.mixdq_qlinear_w8a8_geglu.argtypes = [_vp] * 6 + [_i64, _i32, _i32, _vp, _vp, _i32, _vp]
+_lib.mixdq_qlinear_w8a8_geglu.restype = _i32
+
+
+def geglu_row_order(D: int, device=None) -> torch.Tensor:
+    """Row order of mixdq_qlinear_w8a8_geglu's weight: value/gate groups of 32.  perm[i] = the row
+    of the ordinary [2D, K] GEGLU projection (values 0..D-1, gates D..2D-1) stored at row i."""
+    g = torch.arange(D // 32, device=device)[:, None] * 32 + torch.arange(32, device=device)[None, :]
+    return torch.stack([g, g + D], dim=1).reshape(-1)
+
+
+def qlinear_geglu(input_int8, weight_int8, scale, bias0, bias, out_scale_inv, out_zero_point, *,
+                  _cfg=0, _w4=False):
+    """int8 [..., K] x value/gate-interleaved W [2D, K] -> int8 [..., D]: ff.net.0.proj + GEGLU +
+    the quantizer of ff.net.2 in one launch (include/mixdq_hip.h: mixdq_qlinear_w8a8_geglu)."""
+    _check(input_int8.is_cuda and input_int8.dtype == torch.int8, "input_int8 should be int8 on GPU")
+    _check(weight_int8.dtype == torch.int8, "weight_int8 should be int8 type")
+    N, K = weight_int8.size(0), weight_int8.size(1) * (2 if _w4 else 1)
+    _check(input_int8.size(-1) == K, "The last dimension of input and weight should match")
+    _check(scale.numel() == N and bias0.numel() == N, "scale and bias0 should have 2D elements")
+    a, w = input_int8.contiguous(), weight_int8.contiguous()
+    M = a.numel() // K if K else 0
+    out = torch.empty(list(input_int8.shape[:-1]) + [N // 2], dtype=torch.int8, device=a.device)
+    sc, b0 = _f32vec(scale), _f32vec(bias0)
+    bs = None if bias is None else bias.contiguous()
+    with torch.cuda.device(a.device):
+        code = _lib.mixdq_qlinear_w8a8_geglu(a.data_ptr(), w.data_ptr(), b0.data_ptr(),
+                                             sc.data_ptr(), _ptr(bs), out.data_ptr(), M, N, K,
+                                             _ptr(out_scale_inv), _ptr(out_zero_point),
+                                             FLAGS | (_cfg << 8) | (FLAG_W4 if _w4 else 0),
+                                             _stream())
+    _status(code, "qlinear_geglu")
+    return out
 
 
 def _conv_geometry(input_int8, weight_int8, stride, padding, dilation):

@@ -21,6 +21,7 @@
 //     materialising an [N,P,Q,K] f32 tensor per call as the reference does.
 //   * blockIdx -> tile map is XCD-aware (blocks that share a weight panel share an L2).
 #include "common.h"
+#include "../../include/mixdq_math.h"
 
 namespace mixdq {
 namespace {
@@ -44,6 +45,12 @@ struct IgemmParams {
   int64_t res_div;       //   D = f16(f32(f16(epilogue)) + f32(res[(m / res_div) * N + n]))
   int tiles_m, tiles_n;
   int unfused;
+  // GEGLU epilogue (Dq != null): the N = 2D output columns are value/gate groups of 32
+  // ([v 0..31 | g 0..31 | v 32..63 | ...], weight rows pre-interleaved by the host); the tile is
+  // reduced to int8 q(f16(f16(v) * f16(gelu(f16(g))))) [M, D] -- ff.net.2's operand -- instead of D.
+  int8_t* Dq;
+  const float* g_sinv;
+  const float* g_zp;
 };
 
 template <int BK>
@@ -414,6 +421,39 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
     }
   }
   __syncthreads();
+  if (p.Dq != nullptr) {
+    // GEGLU + quantize on the staged fp16 tile: every rounding point of the unfused chain
+    // (GEMM -> fp16, gelu -> fp16, product -> fp16, quantize) is kept, so the int8 tensor is the
+    // one mixdq_geglu_quantize produces from this GEMM's fp16 output.
+    constexpr int VCH = BN / 16;               // 8-column value chunks per tile row
+    constexpr int RPI = NTHREADS / VCH;
+    static_assert(BN % 64 == 0 && NTHREADS % VCH == 0, "geglu copy-out geometry");
+    const int vc = tid % VCH, grp = vc >> 2, j8 = (vc & 3) * 8;
+    if (n0 + 64 * grp < p.N) {                 // N % 64 == 0: groups are whole
+      const float s_inv = *p.g_sinv, zpq = *p.g_zp;
+      const int Dh = p.N >> 1;
+      const int oc = (n0 >> 1) + 32 * grp + j8;
+      for (int row = tid / VCH; row < BM; row += RPI) {
+        const int64_t m = m0 + row;
+        if (m >= p.M) break;
+        const uint4 xv = *reinterpret_cast<const uint4*>(Cs + row * CS_STRIDE + (64 * grp + j8) * 2);
+        const uint4 gv =
+            *reinterpret_cast<const uint4*>(Cs + row * CS_STRIDE + (64 * grp + 32 + j8) * 2);
+        const __half* xh = reinterpret_cast<const __half*>(&xv);
+        const __half* gh = reinterpret_cast<const __half*>(&gv);
+        uint32_t pk[2] = {0u, 0u};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float ge = __half2float(f32_to_f16_rn(mixdq_geluf(__half2float(gh[j]))));
+          const float y = __half2float(f32_to_f16_rn(__fmul_rn(__half2float(xh[j]), ge)));
+          const int q = unfused ? quantize_one<true>(y, s_inv, zpq) : quantize_one<false>(y, s_inv, zpq);
+          pk[j >> 2] |= (uint32_t)(q & 0xff) << (8 * (j & 3));
+        }
+        *reinterpret_cast<uint2*>(p.Dq + m * Dh + oc) = make_uint2(pk[0], pk[1]);
+      }
+    }
+    return;
+  }
   constexpr int CPRO = BN / 8;   // 16-byte chunks per output row of the tile
   constexpr int ROWS_PER_IT = NTHREADS / CPRO;
   static_assert(NTHREADS % CPRO == 0 && BM % ROWS_PER_IT == 0, "copy-out geometry");
@@ -647,7 +687,9 @@ int launch_tile(IgemmParams& p, hipStream_t stream) {
   X(17, 256, 256, 64, 2, 4, 2)     \
   X(18, 256, 128, 128, 2, 4, 2)    \
   X(19, 128, 128, 64, 3, 2, 2)     \
-  X(20, 256, 256, 128, 2, 4, 2)
+  X(20, 256, 256, 128, 2, 4, 2)    \
+  X(21, 64, 64, 128, 6, 2, 2)      \
+  X(22, 64, 64, 128, 5, 2, 2)
 
 struct TileCfg { int id, bm, bn, bk, stages, wm, wn; };
 constexpr TileCfg kTileCfgs[] = {
@@ -750,6 +792,31 @@ extern "C" int mixdq_qlinear_w8a8_rows(const int8_t* A, const int8_t* W, const f
   p.res = (const __half*)residual_f16_or_null;
   p.res_div = residual_row_div > 0 ? residual_row_div : 1;
   if (p.res && group_rows > 0) return MIXDQ_ERR_UNSUPPORTED;   // residual rows follow m, not D_row
+  p.unfused = (flags & MIXDQ_FLAG_UNFUSED) ? 1 : 0;
+  if (flags & MIXDQ_FLAG_W4) return dispatch_w4<false>(p, (hipStream_t)stream, (flags >> 8) & 0xff);
+  return dispatch<false>(p, (hipStream_t)stream, (flags >> 8) & 0xff);
+}
+
+extern "C" int mixdq_qlinear_w8a8_geglu(const int8_t* A, const int8_t* W, const float* bias0,
+                                        const float* scale, const void* bias_f16_or_null,
+                                        int8_t* out_i8, int64_t M, int N, int K,
+                                        const float* out_scale_inv, const float* out_zero_point,
+                                        int flags, mixdq_stream_t stream) {
+  if (M < 0 || N < 0 || K < 0) return MIXDQ_ERR_INVALID_ARG;
+  if (M == 0 || N == 0) return MIXDQ_OK;
+  if (!A || !W || !bias0 || !scale || !out_i8 || !out_scale_inv || !out_zero_point)
+    return MIXDQ_ERR_INVALID_ARG;
+  // whole value/gate groups per tile, the LDS-DMA kernels only, 8-byte output stores
+  if (N % 64 != 0 || K % 16 != 0 || ((uintptr_t)out_i8 & 7)) return MIXDQ_ERR_UNSUPPORTED;
+  if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)scale | (uintptr_t)bias0) & 15)
+    return MIXDQ_ERR_UNSUPPORTED;
+  if ((uintptr_t)bias_f16_or_null & 7) return MIXDQ_ERR_UNSUPPORTED;
+  IgemmParams p{};
+  p.A = A; p.Wt = W; p.bias0 = bias0; p.scale = scale; p.bias = (const __half*)bias_f16_or_null;
+  p.D = nullptr; p.Dq = out_i8; p.g_sinv = out_scale_inv; p.g_zp = out_zero_point;
+  p.M = M; p.N = N; p.Ktot = K;
+  p.H = p.W = p.P = p.Q = 1; p.C = K; p.R = p.S = 1; p.stride = 1; p.pad = 0;
+  p.res_div = 1;
   p.unfused = (flags & MIXDQ_FLAG_UNFUSED) ? 1 : 0;
   if (flags & MIXDQ_FLAG_W4) return dispatch_w4<false>(p, (hipStream_t)stream, (flags >> 8) & 0xff);
   return dispatch<false>(p, (hipStream_t)stream, (flags >> 8) & 0xff);

@@ -154,6 +154,31 @@ class QuantizedLinear(nn.Module):
         assert self.valid_for_acceleration and not getattr(self, "bos", False)
         return self._gemm(x_int, residual=residual)
 
+    # per-output-channel tensors, reordered together by permute_output_rows_
+    _ROW_TENSORS = ("weight_int", "weight_int4", "weight", "weight_scales", "weight_zero_points",
+                    "weight_sum_by_input_channels", "scale", "bias0", "bias")
+
+    @torch.no_grad()
+    def permute_output_rows_(self, perm: torch.Tensor):
+        """Reorder the output channels IN PLACE (storage addresses stay valid for captured graphs):
+        row i of every per-channel tensor becomes the old row perm[i].  Used to store a GEGLU
+        projection in the value/gate-interleaved order of the fused GEMM+GEGLU kernel; the caller
+        undoes it with the inverse permutation."""
+        for name in self._ROW_TENSORS:
+            t = getattr(self, name, None)
+            if torch.is_tensor(t) and t.dim() >= 1 and t.size(0) == self.out_features:
+                t.copy_(t[perm.to(t.device)])
+
+    def forward_quantized_geglu(self, x_int: torch.Tensor, consumer) -> torch.Tensor:
+        """For a GEGLU projection whose rows are stored interleaved (unet.FeedForward): int8
+        operand of `consumer` (ff.net.2), = consumer's quantizer applied to fp16(value *
+        fp16(gelu(gate))) of this layer's fp16 output, in one launch."""
+        from mixdq_amd._C import qlinear_geglu
+        assert self.valid_for_acceleration and not getattr(self, "bos", False)
+        w = self.weight_int4 if self.w_packed4 else self.weight_int
+        return qlinear_geglu(x_int, w, self.scale, self.bias0, self.bias, consumer.act_scales_inv,
+                             consumer.act_zero_points, _w4=self.w_packed4)
+
     def forward_bos_quantized(self, x_int_tail: torch.Tensor, B: int, T: int) -> torch.Tensor:
         """BOS-path output [B, T, N] from the already quantized tokens 1..T-1 (int8 [B, T-1, K])."""
         assert self.valid_for_acceleration and getattr(self, "bos", False)

@@ -255,14 +255,37 @@ class FeedForward(nn.Module):
         self.net = nn.ModuleList([GEGLU(dim, dim * 4), nn.Identity(), nn.Linear(dim * 4, dim)])
 
     def forward(self, x):
+        assert not self.__dict__.get("_interleaved"), "rows are interleaved: fused path only"
         return self.net[2](self.net[0](x))
+
+    def set_interleaved(self, on: bool):
+        """Store ff.net.0.proj's rows as value/gate groups of 32 (on) or in the ordinary
+        [values | gates] order (off).  Interleaved, one GEMM launch produces net.2's INT8 operand
+        (GEMM + GEGLU + quantize); only W8A8 pairs qualify."""
+        from mixdq_amd import _C
+        proj, out_layer = self.net[0].proj, self.net[2]
+        have = bool(self.__dict__.get("_interleaved"))
+        if on == have:
+            return
+        if on and not (_accel(proj) and _accel(out_layer) and proj.out_features % 64 == 0
+                       and proj.in_features % 16 == 0 and proj.weight_scales.is_cuda):
+            return
+        perm = _C.geglu_row_order(proj.out_features // 2, proj.weight_scales.device)
+        if not on:
+            perm = torch.argsort(perm)
+        proj.permute_output_rows_(perm)
+        self.__dict__["_interleaved"] = on
 
     def forward_fused(self, feed, residual):
         """residual + net2(geglu(proj(feed))): GEGLU fused with net.2's quantizer, the residual add
         folded into net.2's epilogue."""
         from mixdq_amd import _C
-        h = _run(self.net[0].proj, feed)
         out_layer = self.net[2]
+        if self.__dict__.get("_interleaved"):
+            assert feed[1], "interleaved rows need the quantized feed"
+            q = self.net[0].proj.forward_quantized_geglu(feed[0], out_layer)
+            return out_layer.forward_quantized(q, residual=residual)
+        h = _run(self.net[0].proj, feed)
         D = h.shape[-1] // 2
         if _fusable_f16(h) and h.is_contiguous() and D % 8 == 0:
             if _accel(out_layer):
@@ -608,6 +631,8 @@ class SDXLUNet(nn.Module):
         for m in self.modules():
             if hasattr(type(m), "fused"):
                 m.fused = bool(enabled)
+            if isinstance(m, FeedForward):
+                m.set_interleaved(bool(enabled))
         return self
 
     def forward(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None,

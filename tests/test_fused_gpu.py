@@ -141,3 +141,45 @@ def test_shared_math_spec_matches_on_device(C, oracle):
     with np.errstate(over="ignore"):
         want = np.array([np.float16(L.mixdq_oracle_geluf(float(a))) for a in v], np.float16)
     assert np.array_equal(o.cpu().numpy().reshape(-1).view(np.uint16), want.view(np.uint16))
+
+
+GEGLU_GEMM_CASES = [  # M, D, K, forced tile config (0 = automatic), bias
+    (1024, 640, 320, 0, True), (96, 64, 64, 4, True), (77, 32, 48, 4, False),
+    (200, 160, 128, 3, True), (200, 160, 128, 6, True), (300, 128, 256, 13, True),
+    (513, 256, 192, 18, False), (257, 256, 128, 20, True), (1, 32, 16, 0, True),
+]
+
+
+@pytest.mark.parametrize("case", GEGLU_GEMM_CASES, ids=[f"m{c[0]}_d{c[1]}_k{c[2]}_cfg{c[3]}" for c in GEGLU_GEMM_CASES])
+def test_qlinear_geglu_equals_gemm_then_geglu_quantize(C, oracle, case):
+    """GEMM + GEGLU + quantize in one launch (value/gate-interleaved weight rows) is bit-identical
+    to the oracle's qlinear followed by its geglu_quantize on the ordinary row order."""
+    M, D, K, cfg, has_bias = case
+    a = dd.int8(51, (M, K))
+    w = dd.int8(52, (2 * D, K))
+    scale = dd.f32(53, (2 * D,), 2e-4, 9e-4)
+    bias0 = (dd.f32(54, (2 * D,), -300, 300)).astype(np.float32)
+    bias = dd.normal_f16(55, (2 * D,), 0.5) if has_bias else None
+    s_inv, zp = float(np.float32(1) / np.float32(0.02)), -60.0
+    h = oracle.qlinear(a, w, bias0, scale, bias, C.FLAGS & 1)
+    q_ref, _ = oracle.geglu_quantize(h, s_inv, zp, C.FLAGS & 1)
+    perm = C.geglu_row_order(D, DEV)
+    wd, sd, bd = t(w)[perm].contiguous(), t(scale)[perm].contiguous(), t(bias0)[perm].contiguous()
+    biasd = t(bias)[perm].contiguous() if has_bias else None
+    got = C.qlinear_geglu(t(a), wd, sd, bd, biasd, scal(s_inv), scal(zp), _cfg=cfg)
+    assert got.shape == (M, D) and got.dtype == torch.int8
+    assert np.array_equal(got.cpu().numpy(), q_ref)
+    assert len(np.unique(q_ref)) > min(16, q_ref.size // 4)   # the case exercises the int8 range
+    # and equals the two-launch HIP chain on the ordinary row order
+    hd = C.qlinear_w8_a8_ohalf(t(a), t(w), t(scale), scal(1), scal(0), t(bias0), t(scale), t(bias0),
+                               None if bias is None else t(bias))
+    q2, _ = C.geglu_quantize(hd, scal(s_inv), scal(zp))
+    assert torch.equal(got, q2)
+
+
+def test_qlinear_geglu_argument_checks(C):
+    a = torch.zeros(8, 64, dtype=torch.int8, device=DEV)
+    w = torch.zeros(96, 64, dtype=torch.int8, device=DEV)      # N = 96: not whole 64-groups
+    v = torch.zeros(96, dtype=torch.float32, device=DEV)
+    with pytest.raises(RuntimeError):
+        C.qlinear_geglu(a, w, v, v, None, scal(1), scal(0))
