@@ -69,6 +69,16 @@ def _gn_feed(norm: nn.GroupNorm, x, consumer, silu: bool):
     return (F.silu(h) if silu else h), False
 
 
+_SHORTCUT_STREAMS = {}
+
+
+def _shortcut_stream(device):
+    s = _SHORTCUT_STREAMS.get(device)
+    if s is None:
+        s = _SHORTCUT_STREAMS[device] = torch.cuda.Stream(device=device)
+    return s
+
+
 def _ln_feed(norm: nn.LayerNorm, x, consumers):
     """LayerNorm of x [B, T, C] for several consumer layers: one fused kernel produces an int8
     tensor per distinct activation quantizer (and the fp16 tensor if some consumer needs it).
@@ -185,13 +195,24 @@ class ResnetBlock2D(nn.Module):
             t.record_stream(torch.cuda.current_stream())
         else:
             t = self.time_emb_proj(F.silu(temb))                   # [N, Cout]
+        sc = None
+        if self.conv_shortcut is not None:
+            # the 1x1 shortcut (quantize + GEMM, twice for a split layer) only meets the main path
+            # at conv2's residual add: it runs beside norm1 / conv1 / norm2 on a side stream
+            main, side = torch.cuda.current_stream(), _shortcut_stream(x.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                sc = self.conv_shortcut(x)
+            x.record_stream(side)
         feed, q = _gn_feed(self.norm1, x, self.conv1, silu=True)
         if q:   # h = conv1(..) + t[:, :, None, None], the add folded into the conv epilogue
             h = self.conv1.forward_quantized(feed, residual=t.contiguous(), residual_per_image=True)
         else:
             h = self.conv1(feed) + t[:, :, None, None]
-        if self.conv_shortcut is not None:
-            x = self.conv_shortcut(x)
+        if sc is not None:
+            main.wait_stream(side)
+            sc.record_stream(main)
+            x = sc
         feed, q = _gn_feed(self.norm2, h, self.conv2, silu=True)
         if q and x.is_contiguous(memory_format=torch.channels_last):
             return self.conv2.forward_quantized(feed, residual=x)  # x + conv2(..)
