@@ -55,9 +55,9 @@ struct IgemmParams {
 
 template <int BK>
 __device__ __forceinline__ int swz(int row) {
-  // 256-B LDS bank row holds 4 (BK=64) or 2 (BK=128) tile rows; XOR so that the 16 lanes of a
+  // 256-B LDS bank row holds 4 (BK=64), 2 (BK=128) or 1 (BK=256) tile rows; XOR so that the 16 lanes of a
   // ds_read_b128 group (rows r..r+3, r+12.., r+20..) land in 16 distinct 16-byte slots.
-  return BK == 64 ? ((row >> 2) & 3) : ((row >> 1) & 7);
+  return BK == 64 ? ((row >> 2) & 3) : BK == 128 ? ((row >> 1) & 7) : (row & 15);
 }
 
 __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
@@ -689,7 +689,9 @@ int launch_tile(IgemmParams& p, hipStream_t stream) {
   X(19, 128, 128, 64, 3, 2, 2)     \
   X(20, 256, 256, 128, 2, 4, 2)    \
   X(21, 64, 64, 128, 6, 2, 2)      \
-  X(22, 64, 64, 128, 5, 2, 2)
+  X(22, 64, 64, 128, 5, 2, 2)      \
+  X(23, 64, 64, 256, 2, 2, 2)      \
+  X(24, 64, 128, 256, 2, 2, 2)
 
 struct TileCfg { int id, bm, bn, bk, stages, wm, wn; };
 constexpr TileCfg kTileCfgs[] = {
