@@ -58,6 +58,10 @@ SMALL = [  # B, Tq, Tkv, C, fused layout, forced workgroup shape
     (1, 1, 300, 128, False, 0),        # a single query
     (1, 64, 640, 64, True, 0),         # 10 key tiles: the prefetch ring wraps
     (1, 320, 320, 128, True, 4),
+    # key-split 8-wave variant (two waves per row group, alternating key tiles)
+    (1, 128, 64, 128, False, 8), (2, 256, 256, 192, True, 8), (1, 100, 77, 128, False, 8),
+    (2, 96, 130, 64, False, 8), (3, 33, 1, 64, False, 8), (1, 64, 640, 64, True, 8),
+    (1, 320, 704, 128, False, 8), (1, 1, 300, 128, False, 8),
 ]
 
 
