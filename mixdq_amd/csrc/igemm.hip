@@ -330,8 +330,24 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
       const int kt = kt0 + s;
       if (kt < nk) {
         asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((PRE - 1) * NI) : "memory");
-        stage((s + PRE) % STAGES, (kt + PRE) * BK);
         const char* S0 = smem + s * STAGE;
+        if constexpr (TM * TN == 1 && !W4) {
+          // 64x64 tiles run one wave per SIMD and are latency-bound: put every fragment read of
+          // the K-tile in flight FIRST, issue the next stage's DMAs (address arithmetic) under
+          // the LDS latency, then the MFMAs
+          v4i af[KS], bf[KS];
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            af[ks] = *reinterpret_cast<const v4i*>(S0 + a_rd[0][ks]);
+            bf[ks] = *reinterpret_cast<const v4i*>(S0 + b_rd[0][ks]);
+          }
+          stage((s + PRE) % STAGES, (kt + PRE) * BK);
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks)
+            acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[ks], af[ks], acc[0][0], 0, 0, 0);
+          continue;
+        }
+        stage((s + PRE) % STAGES, (kt + PRE) * BK);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           v4i af[TM], bf[TN];
