@@ -442,79 +442,73 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
     // (GEMM -> fp16, gelu -> fp16, product -> fp16, quantize) is kept, so the int8 tensor is the
     // one mixdq_geglu_quantize produces from this GEMM's fp16 output.
     constexpr int VCH = BN / 16;               // 8-column value chunks per tile row
-    constexpr int RPI = NTHREADS / VCH;
-    static_assert(BN % 64 == 0 && NTHREADS % VCH == 0, "geglu copy-out geometry");
-    const int vc = tid % VCH, grp = vc >> 2, j8 = (vc & 3) * 8;
-    if (n0 + 64 * grp < p.N) {                 // N % 64 == 0: groups are whole
-      const float s_inv = *p.g_sinv, zpq = *p.g_zp;
-      const int Dh = p.N >> 1;
+    static_assert(BN % 64 == 0, "geglu copy-out geometry");
+    const float s_inv = *p.g_sinv, zpq = *p.g_zp;
+    const int Dh = p.N >> 1;
+    for (int idx = tid; idx < BM * VCH; idx += NTHREADS) {
+      const int row = idx / VCH, vc = idx - row * VCH;
+      const int grp = vc >> 2, j8 = (vc & 3) * 8;
+      const int64_t m = m0 + row;
+      if (m >= p.M || n0 + 64 * grp >= p.N) continue;   // N % 64 == 0: groups are whole
       const int oc = (n0 >> 1) + 32 * grp + j8;
-      for (int row = tid / VCH; row < BM; row += RPI) {
-        const int64_t m = m0 + row;
-        if (m >= p.M) break;
-        const uint4 xv = *reinterpret_cast<const uint4*>(Cs + row * CS_STRIDE + (64 * grp + j8) * 2);
-        const uint4 gv =
-            *reinterpret_cast<const uint4*>(Cs + row * CS_STRIDE + (64 * grp + 32 + j8) * 2);
-        const __half* xh = reinterpret_cast<const __half*>(&xv);
-        const __half* gh = reinterpret_cast<const __half*>(&gv);
-        uint32_t pk[2] = {0u, 0u};
+      const uint4 xv = *reinterpret_cast<const uint4*>(Cs + row * CS_STRIDE + (64 * grp + j8) * 2);
+      const uint4 gv =
+          *reinterpret_cast<const uint4*>(Cs + row * CS_STRIDE + (64 * grp + 32 + j8) * 2);
+      const __half* xh = reinterpret_cast<const __half*>(&xv);
+      const __half* gh = reinterpret_cast<const __half*>(&gv);
+      uint32_t pk[2] = {0u, 0u};
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float ge = __half2float(f32_to_f16_rn(mixdq_geluf(__half2float(gh[j]))));
-          const float y = __half2float(f32_to_f16_rn(__fmul_rn(__half2float(xh[j]), ge)));
-          const int q = unfused ? quantize_one<true>(y, s_inv, zpq) : quantize_one<false>(y, s_inv, zpq);
-          pk[j >> 2] |= (uint32_t)(q & 0xff) << (8 * (j & 3));
-        }
-        *reinterpret_cast<uint2*>(p.Dq + m * Dh + oc) = make_uint2(pk[0], pk[1]);
+      for (int j = 0; j < 8; ++j) {
+        const float ge = __half2float(f32_to_f16_rn(mixdq_geluf(__half2float(gh[j]))));
+        const float y = __half2float(f32_to_f16_rn(__fmul_rn(__half2float(xh[j]), ge)));
+        const int q = unfused ? quantize_one<true>(y, s_inv, zpq) : quantize_one<false>(y, s_inv, zpq);
+        pk[j >> 2] |= (uint32_t)(q & 0xff) << (8 * (j & 3));
       }
+      *reinterpret_cast<uint2*>(p.Dq + m * Dh + oc) = make_uint2(pk[0], pk[1]);
     }
     return;
   }
   constexpr int CPRO = BN / 8;   // 16-byte chunks per output row of the tile
-  constexpr int ROWS_PER_IT = NTHREADS / CPRO;
-  static_assert(NTHREADS % CPRO == 0 && BM % ROWS_PER_IT == 0, "copy-out geometry");
   const bool n8 = (p.N & 7) == 0;
-  const int cc = tid % CPRO;
-  const int n = n0 + cc * 8;
   const bool identity_rows = p.grp_rows <= 0;
   const bool res_full = p.res != nullptr && p.res_div == 1;
-  if (n < p.N) {
-
-    for (int row = tid / CPRO; row < BM; row += ROWS_PER_IT) {
-      const int64_t m = m0 + row;
-      if (m >= p.M) break;
-      int64_t drow = m;
-      if (!identity_rows) {
-        const int64_t gq = m / p.grp_rows;
-        drow = gq * p.grp_stride + p.grp_off + (m - gq * p.grp_rows);
-      }
-      uint4 v = *reinterpret_cast<const uint4*>(Cs + row * CS_STRIDE + cc * 16);
-      if (p.res != nullptr) {
-        const int64_t rrow = res_full ? m : m / p.res_div;
-        const __half* rp = p.res + rrow * p.N + n;
-        uint32_t rw[4];
-        if (n8) {
-          const uint4 r = *reinterpret_cast<const uint4*>(rp);
-          rw[0] = r.x; rw[1] = r.y; rw[2] = r.z; rw[3] = r.w;
-        } else {
-          const uint2 r0 = *reinterpret_cast<const uint2*>(rp);
-          rw[0] = r0.x; rw[1] = r0.y; rw[2] = 0; rw[3] = 0;
-          if (n + 8 <= p.N) {
-            const uint2 r1 = *reinterpret_cast<const uint2*>(rp + 4);
-            rw[2] = r1.x; rw[3] = r1.y;
-          }
-        }
-        uint32_t* vw = reinterpret_cast<uint32_t*>(&v);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) vw[e] = add_f16x2(vw[e], rw[e]);
-      }
-      __half* dst = p.D + drow * p.N + n;
+  // thread -> (row, chunk): chunk-fastest, so the lanes of a wave write whole output rows
+  for (int idx = tid; idx < BM * CPRO; idx += NTHREADS) {
+    const int row = idx / CPRO, cc = idx - row * CPRO;
+    const int n = n0 + cc * 8;
+    const int64_t m = m0 + row;
+    if (m >= p.M || n >= p.N) continue;
+    int64_t drow = m;
+    if (!identity_rows) {
+      const int64_t gq = m / p.grp_rows;
+      drow = gq * p.grp_stride + p.grp_off + (m - gq * p.grp_rows);
+    }
+    uint4 v = *reinterpret_cast<const uint4*>(Cs + row * CS_STRIDE + cc * 16);
+    if (p.res != nullptr) {
+      const int64_t rrow = res_full ? m : m / p.res_div;
+      const __half* rp = p.res + rrow * p.N + n;
+      uint32_t rw[4];
       if (n8) {
-        *reinterpret_cast<uint4*>(dst) = v;
-      } else {   // N % 8 == 4: rows are only 8-byte aligned
-        *reinterpret_cast<uint2*>(dst) = make_uint2(v.x, v.y);
-        if (n + 8 <= p.N) *reinterpret_cast<uint2*>(dst + 4) = make_uint2(v.z, v.w);
+        const uint4 r = *reinterpret_cast<const uint4*>(rp);
+        rw[0] = r.x; rw[1] = r.y; rw[2] = r.z; rw[3] = r.w;
+      } else {
+        const uint2 r0 = *reinterpret_cast<const uint2*>(rp);
+        rw[0] = r0.x; rw[1] = r0.y; rw[2] = 0; rw[3] = 0;
+        if (n + 8 <= p.N) {
+          const uint2 r1 = *reinterpret_cast<const uint2*>(rp + 4);
+          rw[2] = r1.x; rw[3] = r1.y;
+        }
       }
+      uint32_t* vw = reinterpret_cast<uint32_t*>(&v);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) vw[e] = add_f16x2(vw[e], rw[e]);
+    }
+    __half* dst = p.D + drow * p.N + n;
+    if (n8) {
+      *reinterpret_cast<uint4*>(dst) = v;
+    } else {   // N % 8 == 4: rows are only 8-byte aligned
+      *reinterpret_cast<uint2*>(dst) = make_uint2(v.x, v.y);
+      if (n + 8 <= p.N) *reinterpret_cast<uint2*>(dst + 4) = make_uint2(v.z, v.w);
     }
   }
 }
@@ -707,7 +701,8 @@ int launch_tile(IgemmParams& p, hipStream_t stream) {
   X(21, 64, 64, 128, 6, 2, 2)      \
   X(22, 64, 64, 128, 5, 2, 2)      \
   X(23, 64, 64, 256, 2, 2, 2)      \
-  X(24, 64, 128, 256, 2, 2, 2)
+  X(24, 64, 128, 256, 2, 2, 2)     \
+  X(25, 128, 320, 128, 2, 4, 2)
 
 struct TileCfg { int id, bm, bn, bk, stages, wm, wn; };
 constexpr TileCfg kTileCfgs[] = {
@@ -723,6 +718,10 @@ inline int select_cfg(int64_t M, int N, int Ktot) {
   auto blocks = [&](int tm, int tn) {
     return ((M + tm - 1) / tm) * (int64_t)((N + tn - 1) / tn);
   };
+  // exactly one (or two) 128x320 workgroups per CU: no tail round, the fewest L2->LDS bytes per MAC
+  // among the tiles that still use every CU (M = 8192, N = 1280: 26.0 vs 28.2 us, K = 5120: 66 vs 78)
+  const int64_t b320 = blocks(128, 320);
+  if (N % 320 == 0 && Ktot % 128 == 0 && (b320 == kNumCU || b320 == 2 * kNumCU)) return 25;
   if (blocks(256, 128) >= 2 * kNumCU)
     return (Ktot >= 4096 && blocks(256, 256) >= kNumCU) ? 20 : 13;
   if (blocks(128, 128) >= kNumCU) return 3;    // 128x128x64, 2 stages
