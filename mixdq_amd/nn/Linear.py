@@ -179,12 +179,16 @@ class QuantizedLinear(nn.Module):
         return qlinear_geglu(x_int, w, self.scale, self.bias0, self.bias, consumer.act_scales_inv,
                              consumer.act_zero_points, _w4=self.w_packed4)
 
-    def forward_bos_quantized(self, x_int_tail: torch.Tensor, B: int, T: int) -> torch.Tensor:
-        """BOS-path output [B, T, N] from the already quantized tokens 1..T-1 (int8 [B, T-1, K])."""
+    def forward_bos_quantized(self, x_int_tail: torch.Tensor, B: int, T: int,
+                              out: torch.Tensor = None) -> torch.Tensor:
+        """BOS-path output [B, T, N] from the already quantized tokens 1..T-1 (int8 [B, T-1, K]).
+        `out`: a caller-owned [B, T, N] buffer whose row 0 already holds bos_pre_computed (the row
+        never changes, so a caller that keeps the buffer saves the copy): only rows 1.. are written."""
         assert self.valid_for_acceleration and getattr(self, "bos", False)
-        out = torch.empty((B, T, self.out_features), dtype=torch.float16,
-                          device=x_int_tail.device)
-        out[:, :1, :] = self.bos_pre_computed
+        if out is None:
+            out = torch.empty((B, T, self.out_features), dtype=torch.float16,
+                              device=x_int_tail.device)
+            out[:, :1, :] = self.bos_pre_computed
         if T > 1:
             self._gemm(x_int_tail, out=out, row_map=(T - 1, T, 1))
         return out

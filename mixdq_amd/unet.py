@@ -599,8 +599,18 @@ class SDXLUNet(nn.Module):
                                          layer.act_zero_points)
                         layer._ctx_group = len(shared)
                         shared.append((layer, x_int))
+                    # persistent K / V buffer per layer, BOS row written once (it is a constant):
+                    # 140 copy kernels fewer per step; consumed by this forward's attention only
+                    key = (context.shape[0], context.shape[1], context.device,
+                           layer.bos_pre_computed._version)
+                    buf = layer.__dict__.get("_kv_buf")
+                    if buf is None or buf[0] != key:
+                        o = torch.empty((context.shape[0], context.shape[1], layer.out_features),
+                                        dtype=torch.float16, device=context.device)
+                        o[:, :1, :] = layer.bos_pre_computed
+                        buf = layer.__dict__["_kv_buf"] = (key, o)
                     outs.append(layer.forward_bos_quantized(x_int, context.shape[0],
-                                                            context.shape[1]))
+                                                            context.shape[1], out=buf[1]))
                 ready = torch.cuda.Event()
                 ready.record(side)
                 blk._kv = (outs[0], outs[1], ready)
