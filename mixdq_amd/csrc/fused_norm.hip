@@ -209,13 +209,27 @@ __global__ __launch_bounds__(256) void ln_quant_kernel(
   if (row >= M) return;
   const int nch = C / 8;
   const __half* xr = x + row * C;
-  Half8 h[kLnMaxChunks];
-  float s = 0.f;
+  Half8 h[kLnMaxChunks], gmv[kLnMaxChunks], btv[kLnMaxChunks];
+  // everything the row needs is requested up front: the kernel is a latency chain (load ->
+  // reduce -> reduce -> store), and gamma / beta / the quantizer scalars would otherwise add a
+  // second memory round trip after the reductions
 #pragma unroll
   for (int i = 0; i < kLnMaxChunks; ++i) {
     const int c = lane + 64 * i;
     if (c < nch) {
       h[i] = *reinterpret_cast<const Half8*>(xr + 8 * c);
+      gmv[i] = *reinterpret_cast<const Half8*>(gamma + 8 * c);
+      btv[i] = *reinterpret_cast<const Half8*>(beta + 8 * c);
+    }
+  }
+  const float si0 = q0 ? *s_inv0 : 0.f, z0 = q0 ? *zp0 : 0.f;
+  const float si1 = q1 ? *s_inv1 : 0.f, z1 = q1 ? *zp1 : 0.f;
+  const float si2 = q2 ? *s_inv2 : 0.f, z2 = q2 ? *zp2 : 0.f;
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < kLnMaxChunks; ++i) {
+    const int c = lane + 64 * i;
+    if (c < nch) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) s = __fadd_rn(s, half_at(h[i], j));
     }
@@ -234,15 +248,11 @@ __global__ __launch_bounds__(256) void ln_quant_kernel(
     }
   }
   const float rstd = 1.0f / sqrtf(__fadd_rn(wave_sum(v) / (float)C, eps));
-  const float si0 = q0 ? *s_inv0 : 0.f, z0 = q0 ? *zp0 : 0.f;
-  const float si1 = q1 ? *s_inv1 : 0.f, z1 = q1 ? *zp1 : 0.f;
-  const float si2 = q2 ? *s_inv2 : 0.f, z2 = q2 ? *zp2 : 0.f;
 #pragma unroll
   for (int i = 0; i < kLnMaxChunks; ++i) {
     const int c = lane + 64 * i;
     if (c < nch) {
-      const Half8 gm = *reinterpret_cast<const Half8*>(gamma + 8 * c);
-      const Half8 bt = *reinterpret_cast<const Half8*>(beta + 8 * c);
+      const Half8 gm = gmv[i], bt = btv[i];
       Half8 oh;
       Char8 a, b, d;
       a.w[0] = a.w[1] = b.w[0] = b.w[1] = d.w[0] = d.w[1] = 0;

@@ -49,6 +49,9 @@ def main():
         a = torch.randint(-128, 128, (M, 1280), generator=g, dtype=torch.int8).to(DEV)
         print(f"qlinear M={M} N=K=1280      ", round(timed(
             lambda: C.qlinear_w8_a8_ohalf(a, wt, sc, z, z, sc, sc, sc, None)), 2))
+        res = torch.randn(M, 1280, device=DEV, dtype=torch.float16)
+        print(f"  + residual epilogue       ", round(timed(
+            lambda: C.qlinear_w8_a8_ohalf(a, wt, sc, z, z, sc, sc, sc, None, _residual=res)), 2))
 
 
 if __name__ == "__main__":
