@@ -50,8 +50,9 @@ __device__ __forceinline__ void put_q(Char8& c, int j, int q) {
 struct GnGeom {
   int C, G, cg, OC, PP;
   int64_t HW;
-  int ppb;      // pixels per block (multiple of PP)
-  int nchunk;   // blocks per image
+  int ppb;      // statistics: pixels per block (multiple of PP)
+  int nchunk;   // statistics: blocks per image (<= 64: one partial per lane in the reduction)
+  int ppb_apply, nchunk_apply;   // apply pass: its own, finer split (elementwise: order-free)
 };
 
 __global__ void gn_stats_kernel(const __half* __restrict__ x, float2* __restrict__ partial,
@@ -102,10 +103,11 @@ __device__ __forceinline__ float wave_sum_gn(float v) {
   return v;
 }
 
-__global__ __launch_bounds__(64) void gn_finalize_kernel(const float2* __restrict__ partial,
-                                                         float2* __restrict__ stats, GnGeom g,
-                                                         float eps) {
-  const int grp = blockIdx.x, n = blockIdx.y, lane = threadIdx.x;
+// mean / rstd of group `grp` of image n from the chunk partials, by one 64-lane wave; the result
+// goes to out[grp] (the apply kernel's LDS table).
+__device__ __forceinline__ void gn_finalize_group(const float2* __restrict__ partial, float2* out,
+                                                  const GnGeom& g, float eps, int grp, int n,
+                                                  int lane) {
   float s = 0.f, q = 0.f;
   for (int c = lane; c < g.nchunk; c += 64) {
     const float2 v = partial[((int64_t)n * g.nchunk + c) * g.G + grp];
@@ -120,25 +122,36 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float2* __restric
     float var = __builtin_fmaf(-mean, mean, q / cnt);
     var = fmaxf(var, 0.f);
     const float rstd = 1.0f / sqrtf(__fadd_rn(var, eps));
-    stats[(int64_t)n * g.G + grp] = make_float2(mean, rstd);
+    out[grp] = make_float2(mean, rstd);
   }
 }
 
 template <bool SILU, bool UNFUSED>
-__global__ void gn_apply_kernel(const __half* __restrict__ x, const float2* __restrict__ stats,
-                                const __half* __restrict__ gamma, const __half* __restrict__ beta,
+__global__ void gn_apply_kernel(const __half* __restrict__ x, const float2* __restrict__ partial,
+                                float eps, const __half* __restrict__ gamma,
+                                const __half* __restrict__ beta,
                                 const float* __restrict__ s_inv_p, const float* __restrict__ zp_p,
                                 int8_t* __restrict__ out_q, __half* __restrict__ out_h, GnGeom g) {
+  __shared__ float2 s_stats[1024];   // G <= OC * PP <= 1024
   const int t = threadIdx.x;
   const int o = t % g.OC, pp = t / g.OC;
   const int n = blockIdx.y, chunk = blockIdx.x;
   const int g0 = (8 * o) / g.cg;
   const int jb = min(8, (g0 + 1) * g.cg - 8 * o);
-  const float2 st0 = stats[(int64_t)n * g.G + g0];
-  const float2 st1 = stats[(int64_t)n * g.G + min(g0 + 1, g.G - 1)];
-  float a[8], b[8];
   const Half8 gm = *reinterpret_cast<const Half8*>(gamma + 8 * o);
   const Half8 bt = *reinterpret_cast<const Half8*>(beta + 8 * o);
+  // mean / rstd of this image's groups from the statistics partials (<= 64 per group: one per
+  // lane, then the fixed butterfly): every block does this small reduction itself, which costs
+  // less than the kernel boundary a separate finalize launch would add
+  {
+    const int nfull = (int)blockDim.x >> 6, wave = t >> 6;   // complete waves only
+    if (wave < nfull)
+      for (int grp = wave; grp < g.G; grp += nfull) gn_finalize_group(partial, s_stats, g, eps, grp, n, t & 63);
+    __syncthreads();
+  }
+  const float2 st0 = s_stats[g0];
+  const float2 st1 = s_stats[min(g0 + 1, g.G - 1)];
+  float a[8], b[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const float mean = j < jb ? st0.x : st1.x, rstd = j < jb ? st0.y : st1.y;
@@ -147,8 +160,8 @@ __global__ void gn_apply_kernel(const __half* __restrict__ x, const float2* __re
   }
   const bool want_q = out_q != nullptr;
   const float s_inv = want_q ? *s_inv_p : 0.f, zp = want_q ? *zp_p : 0.f;
-  const int64_t p_begin = (int64_t)chunk * g.ppb;
-  const int64_t p_end = min(g.HW, p_begin + g.ppb);
+  const int64_t p_begin = (int64_t)chunk * g.ppb_apply;
+  const int64_t p_end = min(g.HW, p_begin + g.ppb_apply);
   const int64_t img = ((int64_t)n * g.HW) * g.C + 8 * o;
   for (int64_t p = p_begin + pp; p < p_end; p += g.PP) {
     const Half8 h = *reinterpret_cast<const Half8*>(x + img + p * g.C);
@@ -176,13 +189,19 @@ inline bool make_gn_geom(int N, int64_t HW, int C, int G, GnGeom& g) {
     if ((8 * o + 7) / g.cg - (8 * o) / g.cg > 1) return false;
   g.PP = g.OC >= 256 ? 1 : 256 / g.OC;
   if (G > g.OC * g.PP) return false;              // the block reduces with G threads
-  // Blocks per image: about 512 blocks in total, a whole number of block-iterations each.
-  // (Fixed rule: the oracle restates it, because it fixes the summation order.)
-  const int64_t target = (512 + N - 1) / N;
+  // Statistics blocks per image: about 512 blocks in total but at most 64 per image (every apply
+  // block reduces an image's partials itself, one per lane), a whole number of block-iterations
+  // each.  (Fixed rule: the oracle restates it, because it fixes the summation order.)
+  const int64_t target_apply = (512 + N - 1) / N;
+  const int64_t target = target_apply < 64 ? target_apply : 64;
   int64_t ppb = (HW + target - 1) / target;
   ppb = ((ppb + g.PP - 1) / g.PP) * g.PP;
   g.ppb = (int)ppb;
   g.nchunk = (int)((HW + ppb - 1) / ppb);
+  int64_t ppa = (HW + target_apply - 1) / target_apply;
+  ppa = ((ppa + g.PP - 1) / g.PP) * g.PP;
+  g.ppb_apply = (int)ppa;
+  g.nchunk_apply = (int)((HW + ppa - 1) / ppa);
   return true;
 }
 
@@ -315,7 +334,7 @@ using namespace mixdq;
 extern "C" size_t mixdq_groupnorm_workspace_bytes(int N, int64_t HW, int C, int G) {
   GnGeom g;
   if (!make_gn_geom(N, HW, C, G, g)) return 0;
-  return ((size_t)N * g.nchunk * G + (size_t)N * G) * sizeof(float2);
+  return (size_t)N * g.nchunk * G * sizeof(float2);
 }
 
 extern "C" int mixdq_groupnorm_silu_quantize(const void* x_nhwc, const void* gamma,
@@ -334,16 +353,14 @@ extern "C" int mixdq_groupnorm_silu_quantize(const void* x_nhwc, const void* gam
     return MIXDQ_ERR_ALIGNMENT;
   hipStream_t stream = (hipStream_t)stream_;
   float2* partial = (float2*)workspace;
-  float2* stats = partial + (size_t)N * g.nchunk * G;
   const int threads = g.OC * g.PP;
-  const dim3 grid(g.nchunk, N);
-  gn_stats_kernel<<<grid, threads, threads * 4 * sizeof(float), stream>>>((const __half*)x_nhwc,
-                                                                           partial, g);
-  gn_finalize_kernel<<<dim3(G, N), 64, 0, stream>>>(partial, stats, g, eps);
+  gn_stats_kernel<<<dim3(g.nchunk, N), threads, threads * 4 * sizeof(float), stream>>>(
+      (const __half*)x_nhwc, partial, g);
+  const dim3 grid(g.nchunk_apply, N);
   const bool unfused = flags & MIXDQ_FLAG_UNFUSED;
 #define GN_APPLY(S, U)                                                                          \
   gn_apply_kernel<S, U><<<grid, threads, 0, stream>>>(                                          \
-      (const __half*)x_nhwc, stats, (const __half*)gamma, (const __half*)beta, scale_inv,       \
+      (const __half*)x_nhwc, partial, eps, (const __half*)gamma, (const __half*)beta, scale_inv, \
       zero_point, out_q_or_null, (__half*)out_f16_or_null, g)
   if (apply_silu) { if (unfused) GN_APPLY(true, true); else GN_APPLY(true, false); }
   else            { if (unfused) GN_APPLY(false, true); else GN_APPLY(false, false); }

@@ -124,18 +124,26 @@ def test_non_fp16_input_uses_dequantised_weight_fallback(C, modules_golden):
 
 
 def _tiny_quantized_gpu():
+    """Tiny SDXL-shaped UNet, quantized W8A8 on the GPU.  Calibration and the BOS rows come from a
+    CPU FP32 copy of the same (seeded) network: PyTorch's FP16 GEMMs on the GPU are not bit-
+    reproducible from run to run, and scales that wobble in their last bits would make the exact-
+    wiring checks below depend on rounding luck."""
     from mixdq_amd.calib import calibrate, precompute_bos
     from mixdq_amd.quantize_sdxl import quantize_unet
     from mixdq_amd.unet import build_unet, quantizable_layers
+    host = tiny_inputs(B=2, L=16)
+    unet_c = build_unet("cpu", dtype=torch.float32, cfg=TINY)
+    with torch.no_grad():
+        ckpt = calibrate(unet_c, [host])
+        bos = {k: v.half().to(DEV) for k, v in
+               precompute_bos(unet_c, host["encoder_hidden_states"]).items()}
+    del unet_c
     unet = build_unet(DEV, cfg=TINY)
-    inp = tiny_inputs(B=2, L=16)
-    inp = dict(sample=inp["sample"].half().to(DEV), timestep=inp["timestep"].to(DEV),
-               encoder_hidden_states=inp["encoder_hidden_states"].half().to(DEV),
-               added_cond_kwargs={k: v.half().to(DEV) for k, v in inp["added_cond_kwargs"].items()})
+    inp = dict(sample=host["sample"].half().to(DEV), timestep=host["timestep"].to(DEV),
+               encoder_hidden_states=host["encoder_hidden_states"].half().to(DEV),
+               added_cond_kwargs={k: v.half().to(DEV) for k, v in host["added_cond_kwargs"].items()})
     with torch.no_grad():
         ref = unet(**inp)[0].float()
-    ckpt = calibrate(unet, [inp])
-    bos = precompute_bos(unet, inp["encoder_hidden_states"])
     names = list(quantizable_layers(unet))
     quantize_unet(unet, Args({"model." + n: 8 for n in names}, {"model." + n: 8 for n in names}),
                   ckpt, bos=True, bos_dict=bos)
@@ -191,19 +199,27 @@ def test_fused_unet_tracks_fp16_at_least_as_well_as_unfused(C):
     assert (fused - unfused).abs().mean().item() <= 2.0 * e_unf + 1e-3
 
 
-def test_fused_transformer_blocks_are_bit_identical_to_unfused(C):
-    """LayerNorm / GEGLU fusions and the residual epilogues reproduce the unfused transformer
-    blocks bit for bit on this input (PyTorch's FP16 LayerNorm and GELU agree with the fused
-    arithmetic here), which pins the fused wiring: quantizer choice, BOS path, residual adds."""
+def test_fused_transformer_blocks_match_unfused_within_quantization_noise(C):
+    """LayerNorm / GEGLU fusions and the residual epilogues against the unfused transformer blocks:
+    same rounding points, but PyTorch's FP16 LayerNorm / GELU and the fused arithmetic may round an
+    element differently, which flips an INT8 value now and then -- so the two graphs agree to well
+    within the quantization noise (their distance from the FP16 network), not bit for bit.  A
+    wiring mistake (wrong quantizer, BOS row, residual) is an O(1) error and fails this."""
     import mixdq_amd.unet as U
-    unet, inp, _ = _tiny_quantized_gpu()
+    unet, inp, ref = _tiny_quantized_gpu()
     with torch.no_grad():
-        unfused = unet(**inp)[0]
+        unfused = unet(**inp)[0].float()
         for m in unet.modules():
             if type(m) is U.BasicTransformerBlock:
                 m.fused = True
-        fused = unet(**inp)[0]
-    assert (fused.float() - unfused.float()).abs().max().item() <= 2e-3 * unfused.abs().max().item()
+        fused = unet(**inp)[0].float()
+        again = unet(**inp)[0].float()
+    assert torch.equal(fused, again)
+    noise_max = (unfused - ref).abs().max().item()
+    noise_mean = (unfused - ref).abs().mean().item()
+    d = (fused - unfused).abs()
+    assert d.max().item() <= noise_max + 1e-3, (d.max().item(), noise_max)
+    assert d.mean().item() <= 0.5 * noise_mean + 1e-4, (d.mean().item(), noise_mean)
 
 
 def test_fused_unet_graph_replay(C):
