@@ -50,9 +50,9 @@ __device__ __forceinline__ void put_q(Char8& c, int j, int q) {
 struct GnGeom {
   int C, G, cg, OC, PP;
   int64_t HW;
-  int ppb;      // statistics: pixels per block (multiple of PP)
-  int nchunk;   // statistics: blocks per image (<= 64: one partial per lane in the reduction)
-  int ppb_apply, nchunk_apply;   // apply pass: its own, finer split (elementwise: order-free)
+  int ppb;      // pixels per block (multiple of PP)
+  int nchunk;   // blocks per image
+  int ppb_apply, nchunk_apply;   // apply pass split (elementwise: order-free; = the statistics')
 };
 
 __global__ void gn_stats_kernel(const __half* __restrict__ x, float2* __restrict__ partial,
@@ -126,9 +126,17 @@ __device__ __forceinline__ void gn_finalize_group(const float2* __restrict__ par
   }
 }
 
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float2* __restrict__ partial,
+                                                         float2* __restrict__ stats, GnGeom g,
+                                                         float eps) {
+  gn_finalize_group(partial, stats + (int64_t)blockIdx.y * g.G, g, eps, blockIdx.x, blockIdx.y,
+                    threadIdx.x);
+}
+
 template <bool SILU, bool UNFUSED>
 __global__ void gn_apply_kernel(const __half* __restrict__ x, const float2* __restrict__ partial,
-                                float eps, const __half* __restrict__ gamma,
+                                const float2* __restrict__ stats, float eps,
+                                const __half* __restrict__ gamma,
                                 const __half* __restrict__ beta,
                                 const float* __restrict__ s_inv_p, const float* __restrict__ zp_p,
                                 int8_t* __restrict__ out_q, __half* __restrict__ out_h, GnGeom g) {
@@ -140,17 +148,21 @@ __global__ void gn_apply_kernel(const __half* __restrict__ x, const float2* __re
   const int jb = min(8, (g0 + 1) * g.cg - 8 * o);
   const Half8 gm = *reinterpret_cast<const Half8*>(gamma + 8 * o);
   const Half8 bt = *reinterpret_cast<const Half8*>(beta + 8 * o);
-  // mean / rstd of this image's groups from the statistics partials (<= 64 per group: one per
-  // lane, then the fixed butterfly): every block does this small reduction itself, which costs
-  // less than the kernel boundary a separate finalize launch would add
-  {
+  float2 st0, st1;
+  if (stats == nullptr) {
+    // at most 64 partials per group (batch >= 8): every block reduces its image's partials itself
+    // (one per lane, then the fixed butterfly) -- cheaper than the kernel boundary of a separate
+    // finalize launch; with more partials per group the finalize kernel ran first (stats != null)
     const int nfull = (int)blockDim.x >> 6, wave = t >> 6;   // complete waves only
     if (wave < nfull)
       for (int grp = wave; grp < g.G; grp += nfull) gn_finalize_group(partial, s_stats, g, eps, grp, n, t & 63);
     __syncthreads();
+    st0 = s_stats[g0];
+    st1 = s_stats[min(g0 + 1, g.G - 1)];
+  } else {
+    st0 = stats[(int64_t)n * g.G + g0];
+    st1 = stats[(int64_t)n * g.G + min(g0 + 1, g.G - 1)];
   }
-  const float2 st0 = s_stats[g0];
-  const float2 st1 = s_stats[min(g0 + 1, g.G - 1)];
   float a[8], b[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
@@ -189,19 +201,15 @@ inline bool make_gn_geom(int N, int64_t HW, int C, int G, GnGeom& g) {
     if ((8 * o + 7) / g.cg - (8 * o) / g.cg > 1) return false;
   g.PP = g.OC >= 256 ? 1 : 256 / g.OC;
   if (G > g.OC * g.PP) return false;              // the block reduces with G threads
-  // Statistics blocks per image: about 512 blocks in total but at most 64 per image (every apply
-  // block reduces an image's partials itself, one per lane), a whole number of block-iterations
-  // each.  (Fixed rule: the oracle restates it, because it fixes the summation order.)
-  const int64_t target_apply = (512 + N - 1) / N;
-  const int64_t target = target_apply < 64 ? target_apply : 64;
+  // Blocks per image: about 512 blocks in total, a whole number of block-iterations each.
+  // (Fixed rule: the oracle restates it, because it fixes the summation order.)
+  const int64_t target = (512 + N - 1) / N;
   int64_t ppb = (HW + target - 1) / target;
   ppb = ((ppb + g.PP - 1) / g.PP) * g.PP;
   g.ppb = (int)ppb;
   g.nchunk = (int)((HW + ppb - 1) / ppb);
-  int64_t ppa = (HW + target_apply - 1) / target_apply;
-  ppa = ((ppa + g.PP - 1) / g.PP) * g.PP;
-  g.ppb_apply = (int)ppa;
-  g.nchunk_apply = (int)((HW + ppa - 1) / ppa);
+  g.ppb_apply = g.ppb;
+  g.nchunk_apply = g.nchunk;
   return true;
 }
 
@@ -334,7 +342,7 @@ using namespace mixdq;
 extern "C" size_t mixdq_groupnorm_workspace_bytes(int N, int64_t HW, int C, int G) {
   GnGeom g;
   if (!make_gn_geom(N, HW, C, G, g)) return 0;
-  return (size_t)N * g.nchunk * G * sizeof(float2);
+  return ((size_t)N * g.nchunk * G + (size_t)N * G) * sizeof(float2);
 }
 
 extern "C" int mixdq_groupnorm_silu_quantize(const void* x_nhwc, const void* gamma,
@@ -356,12 +364,17 @@ extern "C" int mixdq_groupnorm_silu_quantize(const void* x_nhwc, const void* gam
   const int threads = g.OC * g.PP;
   gn_stats_kernel<<<dim3(g.nchunk, N), threads, threads * 4 * sizeof(float), stream>>>(
       (const __half*)x_nhwc, partial, g);
+  float2* stats = nullptr;          // null: the apply blocks finalize themselves (<= 64 partials)
+  if (g.nchunk > 64) {
+    stats = partial + (size_t)N * g.nchunk * G;
+    gn_finalize_kernel<<<dim3(G, N), 64, 0, stream>>>(partial, stats, g, eps);
+  }
   const dim3 grid(g.nchunk_apply, N);
   const bool unfused = flags & MIXDQ_FLAG_UNFUSED;
 #define GN_APPLY(S, U)                                                                          \
   gn_apply_kernel<S, U><<<grid, threads, 0, stream>>>(                                          \
-      (const __half*)x_nhwc, partial, eps, (const __half*)gamma, (const __half*)beta, scale_inv, \
-      zero_point, out_q_or_null, (__half*)out_f16_or_null, g)
+      (const __half*)x_nhwc, partial, stats, eps, (const __half*)gamma, (const __half*)beta,    \
+      scale_inv, zero_point, out_q_or_null, (__half*)out_f16_or_null, g)
   if (apply_silu) { if (unfused) GN_APPLY(true, true); else GN_APPLY(true, false); }
   else            { if (unfused) GN_APPLY(false, true); else GN_APPLY(false, false); }
 #undef GN_APPLY

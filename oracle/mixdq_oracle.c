@@ -277,7 +277,6 @@ static int gn_geom(int N, int64_t HW, int C, int G, int* cg, int* OC, int* PP, i
   *PP = *OC >= 256 ? 1 : 256 / *OC;
   if (G > *OC * *PP) return 0;
   int64_t target = (512 + N - 1) / N;
-  if (target > 64) target = 64;            /* at most 64 statistics blocks per image */
   int64_t p = (HW + target - 1) / target;
   p = ((p + *PP - 1) / *PP) * *PP;
   *ppb = (int)p;
