@@ -216,3 +216,69 @@ def test_fakequant_restatement_matches_reference_quantlayer(modules_golden, fake
     assert torch.equal(ck("act_quantizer", "delta_list"), r.entry()["delta_list"].float())
     assert torch.equal(ck("act_quantizer", "zero_point_list"),
                        r.entry()["zero_point_list"].float())
+
+
+# ----------------------------------------------------------- producer fusions / attention (f-1)
+def _ulp16(ref: torch.Tensor) -> torch.Tensor:
+    a = ref.float().abs().clamp(min=2.0 ** -14)
+    return 2.0 ** (torch.floor(torch.log2(a)) - 10)
+
+
+def test_layernorm_restatement_matches_torch_fp32_reference(oracle):
+    """oracle.layernorm_quantize (the kernels' bit-level specification) against PyTorch's FP32
+    LayerNorm rounded to FP16: within one FP16 ulp; each INT8 output is quantize() of that FP16."""
+    x = dd.normal_f16(301, (37, 640), 1.7)
+    gamma = (dd.normal_f16(302, (640,), 0.3).astype(np.float32) + 1).astype(np.float16)
+    beta = dd.normal_f16(303, (640,), 0.2)
+    qp = [(25.0, -3.0), (40.0, 11.0)]
+    outs, h = oracle.layernorm_quantize(x, gamma, beta, 1e-5, qp)
+    ref = torch.nn.functional.layer_norm(torch.from_numpy(x).float(), (640,),
+                                         torch.from_numpy(gamma).float(),
+                                         torch.from_numpy(beta).float(), 1e-5)
+    got = torch.from_numpy(h).float()
+    assert bool(((got - ref).abs() <= 1.001 * _ulp16(ref)).all())
+    for (si, zp), q in zip(qp, outs):
+        assert np.array_equal(q, oracle.quantize(h, si, zp))
+
+
+def test_groupnorm_silu_restatement_matches_torch_fp32_reference(oracle):
+    x = (dd.normal_f16(311, (2, 6, 5, 64), 1.5).astype(np.float32) +
+         dd.normal_f16(312, (1, 1, 1, 64), 0.7).astype(np.float32)).astype(np.float16)   # NHWC
+    gamma = (dd.normal_f16(313, (64,), 0.3).astype(np.float32) + 1).astype(np.float16)
+    beta = dd.normal_f16(314, (64,), 0.2)
+    q, h = oracle.groupnorm_silu_quantize(x, gamma, beta, 1e-5, 8, False, 30.0, -20.0)
+    xt = torch.from_numpy(x).float().permute(0, 3, 1, 2)
+    ref = torch.nn.functional.group_norm(xt, 8, torch.from_numpy(gamma).float(),
+                                         torch.from_numpy(beta).float(), 1e-5).permute(0, 2, 3, 1)
+    got = torch.from_numpy(h).float()
+    assert bool(((got - ref).abs() <= 1.001 * _ulp16(ref) + 1e-6).all())
+    assert np.array_equal(q, oracle.quantize(h, 30.0, -20.0))
+    # + SiLU: SiLU of the restatement's own FP16 normalised value, one more rounding
+    _, hs = oracle.groupnorm_silu_quantize(x, gamma, beta, 1e-5, 8, True, 30.0, -20.0)
+    ref_s = torch.nn.functional.silu(got)
+    assert bool(((torch.from_numpy(hs).float() - ref_s).abs() <= 1.001 * _ulp16(ref_s) + 1e-7).all())
+
+
+def test_geglu_restatement_matches_torch_fp32_reference(oracle):
+    hin = dd.normal_f16(321, (19, 2 * 96), 2.0)
+    q, o = oracle.geglu_quantize(hin, 20.0, -100.0)
+    t = torch.from_numpy(hin).float()
+    ref = (t[:, :96] * torch.nn.functional.gelu(t[:, 96:]).half().float()).half().float()
+    got = torch.from_numpy(o).float()
+    atol = 4e-7 * t[:, :96].abs() * t[:, 96:].abs().clamp(min=1.0)     # erf cancellation, gate << 0
+    assert bool(((got - ref).abs() <= 2.001 * _ulp16(ref) + atol).all())
+    assert np.array_equal(q, oracle.quantize(o, 20.0, -100.0))
+
+
+def test_attention_restatement_matches_torch(oracle):
+    q = dd.normal_f16(331, (2, 50, 128), 1.2)
+    k = dd.normal_f16(332, (2, 77, 128), 1.2)
+    v = dd.normal_f16(333, (2, 77, 128), 1.2)
+    o16, o64 = oracle.attention_f16(q, k, v, 2)
+
+    def heads(a):
+        return torch.from_numpy(a).double().unflatten(-1, (2, 64)).transpose(1, 2)
+    ref = torch.nn.functional.scaled_dot_product_attention(heads(q), heads(k), heads(v))
+    ref = ref.transpose(1, 2).reshape(2, 50, 128).numpy()
+    assert np.abs(o64 - ref).max() < 1e-12
+    assert np.array_equal(o16.view(np.uint16), ref.astype(np.float16).view(np.uint16))
