@@ -577,6 +577,28 @@ class SDXLUNet(nn.Module):
             shared = []                       # [(representative layer, int8 context)]
             for blk in blocks:
                 outs = []
+                pack = self._kv_pack(blk, context)
+                if pack is not None:        # to_k | to_v as ONE GEMM against [2C, K] (cf. _qkv_fused)
+                    from mixdq_amd.op.qlinear import qlinear
+                    lk = blk.attn2.to_k
+                    x_int = self._shared_context_int8(lk, context, shared)
+                    B, T = context.shape[0], context.shape[1]
+                    key = (B, T, context.device, lk.bos_pre_computed._version,
+                           blk.attn2.to_v.bos_pre_computed._version)
+                    if pack.get("key") != key:
+                        o = torch.empty((B, T, 2 * pack["C"]), dtype=torch.float16,
+                                        device=context.device)
+                        o[:, :1, :] = torch.cat([lk.bos_pre_computed,
+                                                 blk.attn2.to_v.bos_pre_computed], dim=-1)
+                        pack["key"], pack["out"] = key, o
+                    o = pack["out"]
+                    qlinear(x_int, pack["w"], pack["wscale"], lk.act_scales, lk.act_zero_points,
+                            pack["wsum"], pack["scale"], pack["bias0"], None, _out=o,
+                            _row_map=(T - 1, T, 1), _w4=pack["w4"])
+                    ready = torch.cuda.Event()
+                    ready.record(side)
+                    blk._kv = (o[..., :pack["C"]], o[..., pack["C"]:], ready)
+                    continue
                 for layer in (blk.attn2.to_k, blk.attn2.to_v):
                     bos_w8a8 = (getattr(layer, "valid_for_acceleration", False)
                                 and getattr(layer, "bos", False)
@@ -584,21 +606,7 @@ class SDXLUNet(nn.Module):
                     if not bos_w8a8:
                         outs.append(layer(context))
                         continue
-                    x_int = None
-                    key = getattr(layer, "_ctx_group", None)
-                    if key is not None and key < len(shared):
-                        x_int = shared[key][1]
-                    else:
-                        for gi, (rep, xi) in enumerate(shared):
-                            if _same_qparams(rep, layer):
-                                layer._ctx_group, x_int = gi, xi
-                                break
-                    if x_int is None:
-                        from mixdq_amd.nn.Linear import quant_op
-                        x_int = quant_op(context[:, 1:, :], layer.act_scales_inv,
-                                         layer.act_zero_points)
-                        layer._ctx_group = len(shared)
-                        shared.append((layer, x_int))
+                    x_int = self._shared_context_int8(layer, context, shared)
                     # persistent K / V buffer per layer, BOS row written once (it is a constant):
                     # 140 copy kernels fewer per step; consumed by this forward's attention only
                     key = (context.shape[0], context.shape[1], context.device,
@@ -615,6 +623,57 @@ class SDXLUNet(nn.Module):
                 ready.record(side)
                 blk._kv = (outs[0], outs[1], ready)
         context.record_stream(side)
+
+    @staticmethod
+    def _shared_context_int8(layer, context, shared):
+        """INT8 copy of context tokens 1.. for `layer`, shared with every layer already seen in this
+        forward whose activation quantizer is identical (`shared`: [(representative, int8)])."""
+        key = getattr(layer, "_ctx_group", None)
+        if key is not None and key < len(shared):
+            return shared[key][1]
+        for gi, (rep, xi) in enumerate(shared):
+            if _same_qparams(rep, layer):
+                layer._ctx_group = gi
+                return xi
+        from mixdq_amd.nn.Linear import quant_op
+        x_int = quant_op(context[:, 1:, :], layer.act_scales_inv, layer.act_zero_points)
+        layer._ctx_group = len(shared)
+        shared.append((layer, x_int))
+        return x_int
+
+    @staticmethod
+    def _kv_pack(blk, context):
+        """Cross-attention to_k / to_v read the same tokens; when both are W8A8 BOS layers with the
+        same activation quantizer and no bias, one GEMM against the row-concatenated weights
+        replaces two (per-channel scale / bias0 concatenate: every output element is computed
+        exactly as before).  The concatenated weight is the storage; the layers keep views."""
+        cached = blk.__dict__.get("_kvpack")
+        if cached is not None:
+            return cached or None
+        lk, lv = blk.attn2.to_k, blk.attn2.to_v
+        ok = (context.dtype == torch.float16 and context.shape[1] > 1
+              and all(getattr(m, "valid_for_acceleration", False) and getattr(m, "bos", False)
+                      and m.bias is None for m in (lk, lv))
+              and bool(lk.w_packed4) == bool(lv.w_packed4)
+              and lk.out_features == lv.out_features and _same_qparams(lk, lv))
+        if not ok:
+            blk.__dict__["_kvpack"] = False
+            return None
+        w4 = bool(lk.w_packed4)
+        attr = "weight_int4" if w4 else "weight_int"
+        with torch.no_grad():
+            w = torch.cat([getattr(lk, attr), getattr(lv, attr)], dim=0).contiguous()
+            C = lk.out_features
+            setattr(lk, attr, w[:C])
+            setattr(lv, attr, w[C:])
+            pack = dict(w=w, C=C, w4=w4,
+                        wscale=torch.cat([lk.weight_scales, lv.weight_scales]),
+                        wsum=torch.cat([lk.weight_sum_by_input_channels,
+                                        lv.weight_sum_by_input_channels]),
+                        scale=torch.cat([lk.scale, lv.scale]).contiguous(),
+                        bias0=torch.cat([lk.bias0, lv.bias0]).contiguous())
+        blk.__dict__["_kvpack"] = pack
+        return pack
 
     def _project_temb_ahead(self, emb):
         """Every ResnetBlock2D adds time_emb_proj(silu(emb)): 22 M = batch GEMMs (plus their SiLU
