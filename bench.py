@@ -59,7 +59,20 @@ def parse_args():
     ap.add_argument("--sweep-reps", type=int, default=5)
     ap.add_argument("--tiny", action="store_true",
                     help="small UNet config (tests of the harness itself; not a benchmark)")
-    return ap.parse_args()
+    ap.add_argument("--baseline-config", type=int, default=None, choices=[1, 2, 3, 4],
+                    help="shorthand for BASELINE.json configs[i]: 1 = W8A8 1024 px batch 1 (the "
+                         "default), 2 = W4A8 mixed batch 1 on the W4 kernels, 3 = batch 64 over 8 "
+                         "GPUs (batch 8 per GPU; launch with --gpus 8), 4 = SDXL-base shape of work: "
+                         "batch 8 with classifier-free guidance = UNet batch 16 (same UNet shapes; "
+                         "a 'step' stays one UNet forward)")
+    args = ap.parse_args()
+    if args.baseline_config == 2:
+        args.w_config, args.a_config, args.w4_kernel = "weight/weight_4.00", "act/act_7.77", True
+    elif args.baseline_config == 3:
+        args.batch = 8
+    elif args.baseline_config == 4:
+        args.batch = 16
+    return args
 
 
 class Cfg:
