@@ -702,7 +702,8 @@ int launch_tile(IgemmParams& p, hipStream_t stream) {
   X(22, 64, 64, 128, 5, 2, 2)      \
   X(23, 64, 64, 256, 2, 2, 2)      \
   X(24, 64, 128, 256, 2, 2, 2)     \
-  X(25, 128, 320, 128, 2, 4, 2)
+  X(25, 128, 320, 128, 2, 4, 2)    \
+  X(35, 128, 128, 64, 3, 4, 2)
 
 struct TileCfg { int id, bm, bn, bk, stages, wm, wn; };
 constexpr TileCfg kTileCfgs[] = {
@@ -724,7 +725,9 @@ inline int select_cfg(int64_t M, int N, int Ktot) {
   if (N % 320 == 0 && Ktot % 128 == 0 && (b320 == kNumCU || b320 == 2 * kNumCU)) return 25;
   if (blocks(256, 128) >= 2 * kNumCU)
     return (Ktot >= 4096 && blocks(256, 256) >= kNumCU) ? 20 : 13;
-  if (blocks(128, 128) >= kNumCU) return 3;    // 128x128x64, 2 stages
+  if (blocks(128, 128) >= kNumCU) return 35;   // 128x128x64, 3 stages, 8 waves of 32x64 (more
+                                               // waves per tile shorten the per-K-tile chain: -6..-10 %
+                                               // vs the 4-wave 64x64 wave tiles of cfg 3)
   if (blocks(64, 128) >= kNumCU) return 6;     // 64x128x128, 3 stages
   return 4;                                    // 64x64x128, 3 stages
 }
