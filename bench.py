@@ -148,7 +148,8 @@ def roofline_sweep(unet, shapes, device, reps):
             x = rnd(shp)
             M, N, K = layer_work(mod, shp)
             bm, bn, bk, st = C.igemm_select(M, N, K)
-            calls.append((f"igemm_kernel<{bm},{bn},{bk},{st},linear>", 2.0 * M * N * K,
+            cid = C.igemm_select_id(M, N, K)
+            calls.append((f"igemm_kernel<{bm},{bn},{bk},{st},linear>#cfg{cid}", 2.0 * M * N * K,
                           lambda mod=mod, x=x: mod._gemm(x)))
         else:
             halves = [("", shp[1])] if mod.split == 0 else [("", mod.split), ("_0", shp[1] - mod.split)]
@@ -159,7 +160,8 @@ def roofline_sweep(unet, shapes, device, reps):
                 Q = (shp[3] + 2 * mod.padding[0] - S) // mod.stride[0] + 1
                 M, N, K = shp[0] * P * Q, mod.out_channels, R * S * cin
                 bm, bn, bk, st = C.igemm_select(M, N, cin, K)
-                calls.append((f"igemm_kernel<{bm},{bn},{bk},{st},conv>", 2.0 * M * N * K,
+                cid = C.igemm_select_id(M, N, cin, K)
+                calls.append((f"igemm_kernel<{bm},{bn},{bk},{st},conv>#cfg{cid}", 2.0 * M * N * K,
                               lambda mod=mod, x=x, sfx=sfx: mod._conv(x, sfx, None)))
     # Group the launches by kernel instantiation, capture each group (model order) in a hipGraph so
     # no host gap sits between launches, and bracket `reps` replays with HIP events recorded on
@@ -371,7 +373,7 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # from rocprofv3 --pmc passes
         if os.path.exists(pmc) and args.px == 1024 and B == 1:       # (tools/pmc_probe.py)
             with open(pmc) as f:
-                traffic = json.load(f).get(dom, {}).get("hbm_bytes_per_launch")
+                traffic = json.load(f).get(dom.split("#")[0], {}).get("hbm_bytes_per_launch")
         out["roofline"] = {
             "bound": "mfma", "kernel": dom, "achieved": achieved, "peak": INT8_MFMA_PEAK_TOPS,
             "unit": "TFLOP/s", "frac": achieved / INT8_MFMA_PEAK_TOPS, "traffic": traffic,

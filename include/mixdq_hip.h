@@ -248,6 +248,10 @@ int mixdq_attention_f16(const void* q_f16, const void* k_f16, const void* v_f16,
  * query, used by bench.py to attribute measured time to kernel names.  No reference counterpart. */
 int mixdq_igemm_select(int64_t M, int N, int k_align, int k_total, int* bm, int* bn, int* bk,
                        int* stages);
+/* The configuration id behind mixdq_igemm_select (the ids of MIXDQ_IGEMM_CONFIGS in csrc/igemm.hip,
+ * which bits 8..15 of `flags` can force; 0 = the small-alignment generic kernel, -1 = invalid):
+ * two ids may share a tile shape and differ in the number of waves working on it. */
+int mixdq_igemm_select_id(int64_t M, int N, int k_align, int k_total);
 
 #ifdef __cplusplus
 }

@@ -100,10 +100,15 @@ __device__ __forceinline__ uint32_t add_f16x2(uint32_t a, uint32_t b) {
 //     lo = (w << 4) & 0xF0F0F0F0   -> int8 values 16 * q[8g+4 .. 8g+7]
 // i.e. the MFMA runs on 16*q (still int8, |16 q| <= 128) and the epilogue uses bias0 * 16 and
 // scale / 16 -- power-of-two factors, so every FP32 rounding is that of the unscaled arithmetic.
-template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool CONV, bool FAST, bool W4>
-__global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p) {
+// KSPLIT = 2 (64x64 tiles only): two groups of WM x WN waves share the tile and split every K-tile's
+// k-steps between them; group 1's accumulators are added to group 0's through LDS before the
+// epilogue (int32: exact, order-free).  Twice the waves for the same tile halves the per-K-tile
+// instruction chain each wave runs -- the thing that bounds the small GEMMs.
+template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool CONV, bool FAST, bool W4,
+          int KSPLIT = 1>
+__global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const IgemmParams p) {
   static_assert(!(CONV && FAST), "the fast staging path is for Linear");
-  constexpr int NWAVES = WM * WN, NTHREADS = 64 * NWAVES;
+  constexpr int NWAVES = WM * WN * KSPLIT, NTHREADS = 64 * NWAVES;
   constexpr int WTM = BM / WM, WTN = BN / WN;     // wave tile (WM x WN waves)
   constexpr int TM = WTM / 32, TN = WTN / 32;     // 32x32 MFMA tiles per wave
   constexpr int WB = W4 ? 2 : 1;                  // weights per stored byte
@@ -123,7 +128,8 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wid / WN, wn = wid % WN;
+  const int kg = wid / (WM * WN);                 // k-split group (0 when KSPLIT == 1)
+  const int wm = (wid % (WM * WN)) / WN, wn = wid % WN;
 
   // ---- XCD- and L2-aware tile map.  Blocks are dealt round-robin over the 8 XCDs (bid % 8), each
   //      with its own 4 MiB L2: give every XCD a contiguous run of the tile sequence (bijective
@@ -262,23 +268,28 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
   // ---- fragment read offsets (loop invariant; the LDS buffer base is a compile-time constant
   //      after the K loop is unrolled by STAGES, so each ds_read_b128 needs no address arithmetic)
   const int lrow = lane & 31, lhalf = lane >> 5;
-  constexpr int KS = BK / 32;
+  constexpr int KS = BK / 32 / KSPLIT;               // k-steps of a K-tile this wave computes
+  static_assert(KSPLIT == 1 || (TM * TN == 1 && !W4 && (BK / 32) % KSPLIT == 0), "k-split: 64x64 W8 tiles");
   int a_rd[TM][KS], b_rd[TN][KS];
 #pragma unroll
   for (int t = 0; t < TM; ++t) {
     const int row = wm * WTM + t * 32 + lrow;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) a_rd[t][ks] = row * BK + (((ks * 2 + lhalf) ^ swz<BK>(row)) << 4);
+    for (int i = 0; i < KS; ++i) {
+      const int ks = kg * KS + i;
+      a_rd[t][i] = row * BK + (((ks * 2 + lhalf) ^ swz<BK>(row)) << 4);
+    }
   }
 #pragma unroll
   for (int t = 0; t < TN; ++t) {
     const int row = wn * WTN + t * 32 + lrow;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
+    for (int i = 0; i < KS; ++i) {
+      const int ks = kg * KS + i;
       if constexpr (!W4)
-        b_rd[t][ks] = A_STAGE + row * BK + (((ks * 2 + lhalf) ^ swz<BK>(row)) << 4);
+        b_rd[t][i] = A_STAGE + row * BK + (((ks * 2 + lhalf) ^ swz<BK>(row)) << 4);
       else   // packed piece of (row, ks), this lane's half (8 bytes = 16 k-values)
-        b_rd[t][ks] = A_STAGE + row * (KS * 16) + ((ks ^ ((row >> 3) & (KS - 1))) << 4) + lhalf * 8;
+        b_rd[t][i] = A_STAGE + row * (KS * 16) + ((ks ^ ((row >> 3) & (KS - 1))) << 4) + lhalf * 8;
     }
   }
 
@@ -379,11 +390,25 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm_kernel(const IgemmParams p
 
   // ---- epilogue: registers -> f16 tile in LDS -> whole-row 16-byte stores --------------------
   __syncthreads();   // every wave is done reading the stage buffers
+  if constexpr (KSPLIT == 2) {
+    // group 1 parks its partial accumulators (behind the fp16 tile's area), group 0 adds them
+    int* part = reinterpret_cast<int*>(smem + BM * CS_STRIDE) + ((wid % (WM * WN)) * 16 * 64 + lane);
+    if (kg == 1) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) part[e * 64] = acc[0][0][e];
+    }
+    __syncthreads();
+    if (kg == 0) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[0][0][e] += part[e * 64];
+    }
+  }
   char* Cs = smem;
   const bool unfused = p.unfused != 0;
   const float zpv = use_table ? *p.zp : 0.f;
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
+    if (KSPLIT == 2 && kg != 0) break;            // group 0 holds the sums
     const int ml = wm * WTM + tm * 32 + lrow;
     // table mode: border class of this output pixel = its valid tap rectangle [rlo,rhi]x[slo,shi];
     // interior pixels (the full window) use the row staged in LDS, border pixels read theirs.
@@ -632,13 +657,15 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const __half* __restrict_
   }
 }
 
-template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool CONV, bool FAST, bool W4 = false>
+template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool CONV, bool FAST, bool W4 = false,
+          int KSPLIT = 1>
 int launch_kernel(IgemmParams& p, hipStream_t stream) {
   constexpr int SMEM = igemm_smem_bytes<BM, BN, BK, STAGES>();
   static_assert(SMEM <= 160 * 1024, "LDS is 160 KiB per CU");
   if constexpr (SMEM > 64 * 1024) {   // opt in to > 64 KiB of dynamic LDS, once per instantiation
     static const hipError_t attr = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&igemm_kernel<BM, BN, BK, STAGES, WM, WN, CONV, FAST, W4>),
+        reinterpret_cast<const void*>(
+            &igemm_kernel<BM, BN, BK, STAGES, WM, WN, CONV, FAST, W4, KSPLIT>),
         hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (attr != hipSuccess) return MIXDQ_ERR_LAUNCH;
   }
@@ -646,8 +673,8 @@ int launch_kernel(IgemmParams& p, hipStream_t stream) {
   p.tiles_n = (p.N + BN - 1) / BN;
   const int64_t grid = (int64_t)p.tiles_m * p.tiles_n;
   if (grid <= 0 || grid > 0x7fffffff) return MIXDQ_ERR_INVALID_ARG;
-  igemm_kernel<BM, BN, BK, STAGES, WM, WN, CONV, FAST, W4>
-      <<<(int)grid, 64 * WM * WN, SMEM, stream>>>(p);
+  igemm_kernel<BM, BN, BK, STAGES, WM, WN, CONV, FAST, W4, KSPLIT>
+      <<<(int)grid, 64 * WM * WN * KSPLIT, SMEM, stream>>>(p);
   return launch_status();
 }
 
@@ -663,15 +690,15 @@ int launch_tile_w4(IgemmParams& p, hipStream_t stream) {
   return launch_kernel<BM, BN, BK, STAGES, WM, WN, CONV, false, true>(p, stream);
 }
 
-template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool CONV>
+template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool CONV, int KSPLIT = 1>
 int launch_tile(IgemmParams& p, hipStream_t stream) {
   if constexpr (!CONV) {
     const bool fits32 = (uint64_t)p.M * (uint64_t)p.Ktot < (1ull << 32) &&
                         (uint64_t)p.N * (uint64_t)p.Ktot < (1ull << 32);
     if (p.Ktot % BK == 0 && fits32)
-      return launch_kernel<BM, BN, BK, STAGES, WM, WN, false, true>(p, stream);
+      return launch_kernel<BM, BN, BK, STAGES, WM, WN, false, true, false, KSPLIT>(p, stream);
   }
-  return launch_kernel<BM, BN, BK, STAGES, WM, WN, CONV, false>(p, stream);
+  return launch_kernel<BM, BN, BK, STAGES, WM, WN, CONV, false, false, KSPLIT>(p, stream);
 }
 
 // Kernel configurations.  id 0 = automatic choice; ids 1.. can be forced through bits 8..15 of
@@ -710,6 +737,7 @@ constexpr TileCfg kTileCfgs[] = {
 #define X(ID, BM, BN, BK, ST, WM, WN) {ID, BM, BN, BK, ST, WM, WN},
     MIXDQ_IGEMM_CONFIGS(X)
 #undef X
+    {37, 64, 64, 128, 3, 2, 2},    // + 2 k-split groups: 8 waves (dispatched explicitly below)
 };
 
 // Automatic choice (tools/bench_gemm.py on MI355X): the largest tile that still fills the chip.
@@ -725,11 +753,12 @@ inline int select_cfg(int64_t M, int N, int Ktot) {
   if (N % 320 == 0 && Ktot % 128 == 0 && (b320 == kNumCU || b320 == 2 * kNumCU)) return 25;
   if (blocks(256, 128) >= 2 * kNumCU)
     return (Ktot >= 4096 && blocks(256, 256) >= kNumCU) ? 20 : 13;
-  if (blocks(128, 128) >= kNumCU) return 35;   // 128x128x64, 3 stages, 8 waves of 32x64 (more
-                                               // waves per tile shorten the per-K-tile chain: -6..-10 %
-                                               // vs the 4-wave 64x64 wave tiles of cfg 3)
-  if (blocks(64, 128) >= kNumCU) return 6;     // 64x128x128, 3 stages
-  return 4;                                    // 64x64x128, 3 stages
+  // 128x128 with 8 waves of 32x64 from ~0.8 workgroups per CU on (measured on the UNet's shapes:
+  // tools/bench_gemm.py); below that 64x64 tiles: with 8 waves that split each K-tile's k-steps
+  // (cfg 37) when K is long or M tiny -- the chain per K-tile is what bounds these launches --
+  // and the plain 4-wave tile (cfg 4) for the short-K GEMMs that put two workgroups on some CUs.
+  if (blocks(128, 128) >= 200) return 35;
+  return (Ktot >= 2048 || M <= 256) ? 37 : 4;
 }
 
 inline int select_cfg_w4(int64_t M, int N, int Ktot) {
@@ -785,6 +814,7 @@ int dispatch(IgemmParams& p, hipStream_t stream, int forced_cfg) {
   case ID: return launch_tile<BM, BN, BK, ST, WM, WN, CONV>(p, stream);
     MIXDQ_IGEMM_CONFIGS(X)
 #undef X
+    case 37: return launch_tile<64, 64, 128, 3, 2, 2, CONV, 2>(p, stream);   // 8 waves, k-split
     default: return MIXDQ_ERR_INVALID_ARG;
   }
 }
@@ -956,6 +986,12 @@ extern "C" const char* mixdq_status_string(int status) {
 }
 
 extern "C" int mixdq_abi_version(void) { return MIXDQ_ABI_VERSION; }
+
+extern "C" int mixdq_igemm_select_id(int64_t M, int N, int k_align, int k_total) {
+  if (M <= 0 || N <= 0 || k_align % 4 != 0 || N % 4 != 0) return -1;
+  if (k_align % 16 != 0) return 0;   // generic kernel
+  return select_cfg(M, N, k_total);
+}
 
 extern "C" int mixdq_igemm_select(int64_t M, int N, int k_align, int k_total, int* bm, int* bn,
                                   int* bk, int* stages) {

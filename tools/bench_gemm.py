@@ -19,6 +19,7 @@ LINEAR = [  # (count per 1024px image, M per image, N, K)
     (372, 1024, 1280, 1280), (60, 1024, 10240, 1280), (60, 1024, 1280, 5120),
     (70, 4096, 640, 640), (10, 4096, 5120, 640), (10, 4096, 640, 2560),
     (120, 77, 1280, 2048), (20, 77, 640, 2048), (17, 1, 1280, 1280),
+    (60, 1024, 3840, 1280), (10, 4096, 1920, 640), (60, 77, 2560, 2048),   # fused q|k|v, k|v
 ]
 CONV = [  # (count, H=W, Cin, Cout, ksize, stride)
     (10, 32, 1280, 1280, 3, 1), (7, 128, 320, 320, 3, 1), (6, 64, 640, 640, 3, 1),
