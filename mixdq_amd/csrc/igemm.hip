@@ -390,17 +390,22 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const Igem
 
   // ---- epilogue: registers -> f16 tile in LDS -> whole-row 16-byte stores --------------------
   __syncthreads();   // every wave is done reading the stage buffers
-  if constexpr (KSPLIT == 2) {
-    // group 1 parks its partial accumulators (behind the fp16 tile's area), group 0 adds them
+  if constexpr (KSPLIT > 1) {
+    // groups 1.. park their partial accumulators (behind the fp16 tile's area), group 0 adds them
+    static_assert(BM * CS_STRIDE + (KSPLIT - 1) * WM * WN * 16 * 64 * 4 <=
+                      igemm_main_bytes<BM, BN, BK, STAGES>(), "partials fit the stage buffers");
     int* part = reinterpret_cast<int*>(smem + BM * CS_STRIDE) + ((wid % (WM * WN)) * 16 * 64 + lane);
-    if (kg == 1) {
+    constexpr int GROUP_INTS = WM * WN * 16 * 64;
+    if (kg != 0) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) part[e * 64] = acc[0][0][e];
+      for (int e = 0; e < 16; ++e) part[(kg - 1) * GROUP_INTS + e * 64] = acc[0][0][e];
     }
     __syncthreads();
     if (kg == 0) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[0][0][e] += part[e * 64];
+      for (int g = 0; g < KSPLIT - 1; ++g)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[0][0][e] += part[g * GROUP_INTS + e * 64];
     }
   }
   char* Cs = smem;
@@ -408,7 +413,7 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const Igem
   const float zpv = use_table ? *p.zp : 0.f;
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
-    if (KSPLIT == 2 && kg != 0) break;            // group 0 holds the sums
+    if (KSPLIT > 1 && kg != 0) break;             // group 0 holds the sums
     const int ml = wm * WTM + tm * 32 + lrow;
     // table mode: border class of this output pixel = its valid tap rectangle [rlo,rhi]x[slo,shi];
     // interior pixels (the full window) use the row staged in LDS, border pixels read theirs.
