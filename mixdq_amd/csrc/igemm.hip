@@ -755,7 +755,8 @@ inline int select_cfg(int64_t M, int N, int Ktot) {
   // exactly one (or two) 128x320 workgroups per CU: no tail round, the fewest L2->LDS bytes per MAC
   // among the tiles that still use every CU (M = 8192, N = 1280: 26.0 vs 28.2 us, K = 5120: 66 vs 78)
   const int64_t b320 = blocks(128, 320);
-  if (N % 320 == 0 && Ktot % 128 == 0 && (b320 == kNumCU || b320 == 2 * kNumCU)) return 25;
+  if (N % 320 == 0 && Ktot % 128 == 0 && Ktot >= 1024 && (b320 == kNumCU || b320 == 2 * kNumCU))
+    return 25;   // (K = 640: its two 128-byte-deep stages are too shallow, 128x128 wins)
   if (blocks(256, 128) >= 2 * kNumCU)
     return (Ktot >= 4096 && blocks(256, 256) >= kNumCU) ? 20 : 13;
   // 128x128 with 8 waves of 32x64 from ~0.8 workgroups per CU on (measured on the UNet's shapes:
