@@ -86,7 +86,7 @@ IGEMM_CONFIGS = {1: (64, 64, 64, 2), 2: (64, 128, 64, 2), 3: (128, 128, 64, 2),
                  16: (256, 128, 64, 2), 17: (256, 256, 64, 2), 18: (256, 128, 128, 2),
                  19: (128, 128, 64, 3), 20: (256, 256, 128, 2), 21: (64, 64, 128, 6),
                  22: (64, 64, 128, 5), 23: (64, 64, 256, 2), 24: (64, 128, 256, 2),
-                 25: (128, 320, 128, 2), 35: (128, 128, 64, 3), 37: (64, 64, 128, 3)}
+                 25: (128, 320, 128, 2), 35: (128, 128, 64, 3), 37: (64, 64, 128, 3), 41: (64, 128, 128, 3)}
 
 FLAG_W4 = 2   # MIXDQ_FLAG_W4: the weight tensor holds packed signed 4-bit values
 

@@ -735,7 +735,8 @@ int launch_tile(IgemmParams& p, hipStream_t stream) {
   X(23, 64, 64, 256, 2, 2, 2)      \
   X(24, 64, 128, 256, 2, 2, 2)     \
   X(25, 128, 320, 128, 2, 4, 2)    \
-  X(35, 128, 128, 64, 3, 4, 2)
+  X(35, 128, 128, 64, 3, 4, 2)     \
+  X(41, 64, 128, 128, 3, 2, 4)
 
 struct TileCfg { int id, bm, bn, bk, stages, wm, wn; };
 constexpr TileCfg kTileCfgs[] = {
@@ -764,7 +765,11 @@ inline int select_cfg(int64_t M, int N, int Ktot) {
   // (cfg 37) when K is long or M tiny -- the chain per K-tile is what bounds these launches --
   // and the plain 4-wave tile (cfg 4) for the short-K GEMMs that put two workgroups on some CUs.
   if (blocks(128, 128) >= 200) return 35;
-  return (Ktot >= 2048 || M <= 256) ? 37 : 4;
+  if (M <= 256) return 37;
+  // 1..2 workgroups of 64x64 per CU (M = 1024, N = 1280): 64x128 tiles with 8 waves of 32x32 leave
+  // no second round and halve each wave's chain (7.0 vs 7.5 us, K = 5120: 17.6 vs 18.8)
+  if (blocks(64, 64) < 2 * kNumCU && Ktot <= 6144 && N % 128 == 0) return 41;
+  return Ktot >= 2048 ? 37 : 4;
 }
 
 inline int select_cfg_w4(int64_t M, int N, int Ktot) {
