@@ -183,3 +183,23 @@ def test_qlinear_geglu_argument_checks(C):
     v = torch.zeros(96, dtype=torch.float32, device=DEV)
     with pytest.raises(RuntimeError):
         C.qlinear_geglu(a, w, v, v, None, scal(1), scal(0))
+
+
+@pytest.mark.parametrize("M,D,K,cfg", [(200, 160, 128, 0), (96, 64, 64, 4), (300, 128, 256, 3)])
+def test_qlinear_geglu_w4_equals_oracle_chain_on_unpacked_weights(C, oracle, M, D, K, cfg):
+    """Packed-W4 weights through the fused GEMM + GEGLU + quantize launch: the oracle's W8 qlinear on
+    oracle.unpack_w4(packed), then its geglu_quantize, bit for bit."""
+    from mixdq_amd.nn.utils import pack_w4
+    a = dd.int8(61, (M, K))
+    q4 = dd.int8(62, (2 * D, K), -8, 8)
+    scale = dd.f32(63, (2 * D,), 2e-3, 9e-3)
+    bias0 = dd.f32(64, (2 * D,), -30, 30).astype(np.float32)
+    s_inv, zp = float(np.float32(1) / np.float32(0.02)), -60.0
+    packed = pack_w4(torch.from_numpy(q4))
+    assert np.array_equal(oracle.unpack_w4(packed.numpy()), q4)
+    h = oracle.qlinear(a, q4, bias0, scale, None, C.FLAGS & 1)
+    q_ref, _ = oracle.geglu_quantize(h, s_inv, zp, C.FLAGS & 1)
+    perm = C.geglu_row_order(D, DEV)
+    got = C.qlinear_geglu(t(a), packed.to(DEV)[perm].contiguous(), t(scale)[perm].contiguous(),
+                          t(bias0)[perm].contiguous(), None, scal(s_inv), scal(zp), _cfg=cfg, _w4=True)
+    assert np.array_equal(got.cpu().numpy(), q_ref)
