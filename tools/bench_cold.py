@@ -25,8 +25,10 @@ def main():
     zero = torch.zeros((), device=DEV)
     side = torch.cuda.Stream()
 
+    cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+
     def gemm(w):
-        return C.qlinear_w8_a8_ohalf(a, w, sc, zero, zero, b0, sc, b0, None)
+        return C.qlinear_w8_a8_ohalf(a, w, sc, zero, zero, b0, sc, b0, None, _cfg=cfg)
 
     def build(mode):
         gr = torch.cuda.CUDAGraph()
@@ -50,7 +52,7 @@ def main():
             gr.replay()
         e1.record()
         torch.cuda.synchronize()
-        print(mode, round(e0.elapsed_time(e1) * 1e3 / (5 * L), 2), "us per GEMM")
+        print("cfg", cfg, mode, round(e0.elapsed_time(e1) * 1e3 / (5 * L), 2), "us per GEMM")
 
 
 if __name__ == "__main__":
