@@ -7,16 +7,22 @@ kernels/README.md:94, quantize_sdxl.py:184-286).
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
 
 N = 1 workload: BASELINE.json configs[1] -- W8A8 SDXL-Turbo UNet, 1024x1024 (latent 128), batch 1,
-1 step, one MI355X.  N > 1: weak scaling, the same per-GPU batch on every rank (batch-sharded
-replicas, rank 0's quantized weights broadcast once over RCCL, no collective in the step loop).
+1 step, one MI355X.  N > 1 (default): weak scaling, the same per-GPU batch on every rank
+(batch-sharded replicas, rank 0's quantized weights broadcast once over RCCL, no collective in the
+step loop).  `--baseline-config 3` is BASELINE.json configs[3] as named: GLOBAL batch 64 sharded
+over the N ranks (64 / N per GPU), 4 UNet forwards per image -- strong scaling.
 
 Prints ONE JSON line (rank 0).  Extra objects:
-  roofline      dominant kernel (an igemm_kernel<BM,BN,BK,CONV> instantiation): algorithmic int8
-                ops of its launches / their summed duration, each launch bracketed by HIP events
-                on the launch stream, vs the dense INT8 MFMA peak (MI355X_MICROARCH.md);
+  roofline      dominant kernel (an igemm_kernel<BM,BN,BK,CONV> instantiation): the launches of ONE
+                forward of the graph that was timed are recorded (mixdq_amd._C.RECORD), replayed
+                per kernel instantiation from a hipGraph and bracketed by HIP events on the launch
+                stream; algorithmic int8 ops / duration vs the dense INT8 MFMA peak
+                (MI355X_MICROARCH.md);
   cpu_baseline  the reference's CPU-runnable path (qdiff fake-quant, Path A) restated in
                 oracle/fakequant.py, timed on this box's host cores on a bounded sample;
-  fp16          the same UNet graph with nn.Linear / nn.Conv2d in FP16 on the same GPU.
+  fp16          the same UNet graph with nn.Linear / nn.Conv2d in FP16 on the same GPU;
+  memory        static / dynamic / peak MB of the W8A8 and the FP16 network, measured as the
+                reference's run() does (quantize_sdxl.py:337-338,453-456).
 """
 import argparse
 import json
@@ -61,15 +67,24 @@ def parse_args():
                     help="small UNet config (tests of the harness itself; not a benchmark)")
     ap.add_argument("--baseline-config", type=int, default=None, choices=[1, 2, 3, 4],
                     help="shorthand for BASELINE.json configs[i]: 1 = W8A8 1024 px batch 1 (the "
-                         "default), 2 = W4A8 mixed batch 1 on the W4 kernels, 3 = batch 64 over 8 "
-                         "GPUs (batch 8 per GPU; launch with --gpus 8), 4 = SDXL-base shape of work: "
-                         "batch 8 with classifier-free guidance = UNet batch 16 (same UNet shapes; "
-                         "a 'step' stays one UNet forward)")
+                         "default), 2 = W4A8 mixed batch 1 on the W4 kernels, 3 = GLOBAL batch 64 "
+                         "sharded over --gpus N (64 / N per GPU), 4 UNet forwards per image: strong "
+                         "scaling, 4 = SDXL-base shape of work: batch 8 with classifier-free "
+                         "guidance = UNet batch 16 (same UNet shapes; a 'step' stays one UNet "
+                         "forward)")
+    ap.add_argument("--global-batch", type=int, default=None,
+                    help="strong scaling: this many images in total, split evenly over the ranks")
+    ap.add_argument("--forwards-per-image", type=int, default=1,
+                    help="UNet forwards one image needs (sampling steps); images/s = UNet-batch "
+                         "throughput / this")
+    ap.add_argument("--profile-ranges", action="store_true",
+                    help="after the timed region: 3 eager iterations with roctx ranges per block "
+                         "(quantize_sdxl.py:387-429), for rocprofv3 --marker-trace")
     args = ap.parse_args()
     if args.baseline_config == 2:
         args.w_config, args.a_config, args.w4_kernel = "weight/weight_4.00", "act/act_7.77", True
     elif args.baseline_config == 3:
-        args.batch = 8
+        args.global_batch, args.forwards_per_image = 64, 4
     elif args.baseline_config == 4:
         args.batch = 16
     return args
@@ -127,54 +142,38 @@ def layer_work(mod, in_shape):
     return B * P * Q, mod.out_channels, R * S * C
 
 
-def roofline_sweep(unet, shapes, device, reps):
-    """Launch only the INT8 GEMM / conv kernels of one UNet forward on pre-quantized random
-    inputs and time them per kernel instantiation with HIP events.  Returns per-kernel totals."""
+def roofline_sweep(run_eager, device, reps):
+    """Per-kernel timing of the INT8 GEMM / conv launches of the graph that was timed: ONE eager
+    forward runs with the launch recorder on (every igemm entry-point call with its real device
+    tensors: fused q|k|v, k|v, GEMM+GEGLU, residual epilogues, W4), then the recorded launches are
+    replayed per kernel instantiation.  Returns per-kernel totals."""
     import mixdq_amd._C as C
-    from mixdq_amd.nn import QuantizedConv2d, QuantizedLinear
-    calls = []   # (kernel name, ops, callable)
-    g = torch.Generator(device="cpu").manual_seed(7)
-
-    def rnd(shape):
-        return torch.randint(-128, 128, shape, generator=g, dtype=torch.int8).to(device)
-
-    for name, mod in unet.named_modules():
-        if not isinstance(mod, (QuantizedLinear, QuantizedConv2d)) or not mod.valid_for_acceleration:
-            continue
-        shp = shapes[name]
-        if isinstance(mod, QuantizedLinear):
-            if getattr(mod, "bos", False):
-                shp = (shp[0], shp[1] - 1, shp[2])
-            x = rnd(shp)
-            M, N, K = layer_work(mod, shp)
-            bm, bn, bk, st = C.igemm_select(M, N, K)
-            cid = C.igemm_select_id(M, N, K)
-            calls.append((f"igemm_kernel<{bm},{bn},{bk},{st},linear>#cfg{cid}", 2.0 * M * N * K,
-                          lambda mod=mod, x=x: mod._gemm(x)))
-        else:
-            halves = [("", shp[1])] if mod.split == 0 else [("", mod.split), ("_0", shp[1] - mod.split)]
-            for sfx, cin in halves:
-                x = rnd((shp[0], cin, shp[2], shp[3])).contiguous(memory_format=torch.channels_last)
-                R, S = mod.kernel_size
-                P = (shp[2] + 2 * mod.padding[0] - R) // mod.stride[0] + 1
-                Q = (shp[3] + 2 * mod.padding[0] - S) // mod.stride[0] + 1
-                M, N, K = shp[0] * P * Q, mod.out_channels, R * S * cin
-                bm, bn, bk, st = C.igemm_select(M, N, cin, K)
-                cid = C.igemm_select_id(M, N, cin, K)
-                calls.append((f"igemm_kernel<{bm},{bn},{bk},{st},conv>#cfg{cid}", 2.0 * M * N * K,
-                              lambda mod=mod, x=x, sfx=sfx: mod._conv(x, sfx, None)))
-    # Group the launches by kernel instantiation, capture each group (model order) in a hipGraph so
-    # no host gap sits between launches, and bracket `reps` replays with HIP events recorded on
-    # the launch stream (torch's current stream is the stream the kernels are launched on).
+    with torch.no_grad():
+        run_eager()                                   # builds cached tables / packs, unrecorded
+        torch.cuda.synchronize(device)
+        C.RECORD = []
+        try:
+            run_eager()
+        finally:
+            rec, C.RECORD = C.RECORD, None
+        torch.cuda.synchronize(device)
     groups = {}
-    for kname, ops, fn in calls:
-        g_ = groups.setdefault(kname, dict(fns=[], ops=0.0))
-        g_["fns"].append(fn)
-        g_["ops"] += ops
+    for kind, (M, N, K, k_align), w4, replay in rec:
+        cid = C.igemm_select_id(M, N, k_align, K, w4=w4)
+        bm, bn, bk, st = C.IGEMM_CONFIGS.get(cid, (0, 0, 0, 0))
+        kname = f"igemm_kernel<{bm},{bn},{bk},{st},{kind}{',w4' if w4 else ''}>#cfg{cid}"
+        g_ = groups.setdefault(kname, dict(fns=[], ops=0.0, bytes=0.0))
+        g_["fns"].append(replay)
+        g_["ops"] += 2.0 * M * N * K
+        out_bytes = M * (N // 2) if kind == "linear_geglu" else 2 * M * N
+        g_["bytes"] += M * K + N * K // (2 if w4 else 1) + out_bytes   # algorithmic: A + W + D
+    # Each group is captured (model order) in a hipGraph so no host gap sits between launches, and
+    # `reps` replays are bracketed with HIP events recorded on the launch stream (torch's current
+    # stream is the stream the kernels are launched on).
     stats = {}
     with torch.no_grad():
         for kname, g_ in groups.items():
-            for fn in g_["fns"]:      # warm-up (also builds the cached border tables)
+            for fn in g_["fns"]:
                 fn()
             torch.cuda.synchronize(device)
             graph = torch.cuda.CUDAGraph()
@@ -190,7 +189,7 @@ def roofline_sweep(unet, shapes, device, reps):
             e1.record()
             torch.cuda.synchronize(device)
             stats[kname] = dict(ms=e0.elapsed_time(e1), ops=g_["ops"] * reps,
-                                launches=len(g_["fns"]) * reps)
+                                bytes=g_["bytes"] * reps, launches=len(g_["fns"]) * reps)
             del graph
     return stats
 
@@ -265,11 +264,19 @@ def main():
     from mixdq_amd import cfgs
     from mixdq_amd.calib import calibrate, precompute_bos
     from mixdq_amd.nn import QuantizedConv2d, QuantizedLinear
-    from mixdq_amd.quantize_sdxl import example_inputs, hip_graph_opt, quantize_unet
+    from mixdq_amd.quantize_sdxl import (MemoryMeter, example_inputs, hip_graph_opt,
+                                         layers_roctx_annotate, quantize_unet)
     from mixdq_amd.unet import build_unet
 
     L = args.px // 8
-    B = args.batch
+    strong = args.global_batch is not None
+    if strong:      # fixed total work: this rank's contiguous share of the global batch
+        lo, hi = shard.shard_range(args.global_batch, rank, world)
+        B, global_batch = hi - lo, args.global_batch
+        assert B > 0, f"global batch {args.global_batch} leaves rank {rank} of {world} empty"
+    else:           # fixed per-GPU work
+        B, global_batch = args.batch, world * args.batch
+    fpi = max(1, args.forwards_per_image)
     t_setup = time.perf_counter()
     tiny_cfg = None
     if args.tiny:
@@ -278,21 +285,23 @@ def main():
                         time_embed_dim=128, addition_time_embed_dim=16,
                         projection_class_embeddings_input_dim=1280 + 96, norm_num_groups=8)
     unet = build_unet(device, cfg=tiny_cfg)
+    fp16_meter = MemoryMeter(device)              # static = the FP16 network, resident
     inputs = example_inputs(B, L, device, seed=42 + rank)
-    shapes = layer_shapes(unet, inputs)
     ckpt = calibrate(unet, [inputs], bos=not args.no_bos)
     bos_dict = precompute_bos(unet, inputs["encoder_hidden_states"])
 
     def run_once():
         return unet(**inputs)[0]
 
-    fp16 = None
+    fp16, memory = None, {}
     if not args.no_fp16:
         # (a) the reference's comparison point: the same graph, stock PyTorch FP16 ops throughout
         if not args.no_graph:
             hip_graph_opt(unet)
         dt = time_steps(run_once, args.steps, args.warmup, device)
-        fp16 = dict(ms_per_step=1e3 * dt / args.steps, images_per_s=world * B * args.steps / dt)
+        fp16 = dict(ms_per_step=1e3 * dt / args.steps,
+                    images_per_s=global_batch * args.steps / dt / fpi)
+        memory["fp16"] = fp16_meter.report()
         if not args.no_graph:
             unet.forward = unet.forward.__wrapped__   # drop the FP16 graph
         # (b) for transparency: FP16 GEMMs / convs by PyTorch, but with this repo's fused
@@ -317,39 +326,57 @@ def main():
         w_cfg, a_cfg = cfgs.load(args.w_config), cfgs.load(args.a_config)
     quantize_unet(unet, Cfg(w_cfg, a_cfg), ckpt, bos=not args.no_bos, bos_dict=bos_dict,
                   w4_kernel=args.w4_kernel)
+    del ckpt
     unet.set_fused(not args.no_fuse)
     bcast_bytes = shard.broadcast_module_state(unet, src=0)
     qmods = [m for m in unet.modules() if isinstance(m, (QuantizedLinear, QuantizedConv2d))]
     n_accel = sum(m.valid_for_acceleration for m in qmods)
     n_w4 = sum(m.valid_for_acceleration and getattr(m, "w_packed4", False) for m in qmods)
+    import gc
+    gc.collect()
     torch.cuda.empty_cache()
     weight_bytes = sum(b.numel() * b.element_size() for b in unet.buffers()) + sum(
         p.numel() * p.element_size() for p in unet.parameters())
-
-    roof_stats = None
-    if not args.no_roofline and rank == 0:
-        roof_stats = roofline_sweep(unet, shapes, device, args.sweep_reps)
+    q_meter = MemoryMeter(device)                 # static = the quantized network, resident
     shard.barrier()
 
+    eager_forward = unet.forward
     if not args.no_graph:
         hip_graph_opt(unet)
     setup_s = time.perf_counter() - t_setup
     dt = time_steps(run_once, args.steps, args.warmup, device)
     ms = 1e3 * dt / args.steps
-    value = world * B * args.steps / dt
+    value = global_batch * args.steps / dt / fpi
+    memory["w4a8_mixed" if args.w4_kernel else "w8a8"] = q_meter.report()
+
+    roof_stats = None
+    if not args.no_roofline and rank == 0:
+        roof_stats = roofline_sweep(lambda: eager_forward(**inputs), device, args.sweep_reps)
+    if args.profile_ranges and rank == 0:
+        unet.forward = eager_forward
+        layers_roctx_annotate(unet)
+        with torch.no_grad():
+            for it in range(3):
+                torch.cuda.nvtx.range_push(f"iter_{it}")
+                run_once()
+                torch.cuda.nvtx.range_pop()
+        torch.cuda.synchronize(device)
+    shard.barrier()
 
     if rank != 0:
         return
+    kind = "w4a8_mixed" if args.w4_kernel else "w8a8"
     out = {
-        "metric": "sdxl_turbo_unet_w8a8_images_per_sec" if not args.w4_kernel
-        else "sdxl_turbo_unet_w4a8_mixed_images_per_sec",
+        "metric": f"sdxl_turbo_unet_{kind}_images_per_sec",
         "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+        "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "int8", "data": "synthetic",
         "config": {
-            "workload": f"sdxl_turbo_unet_{'w4a8_mixed' if args.w4_kernel else 'w8a8'}"
-                        f"_{args.px}px_bs{B}_1step",
-            "global_batch": world * B, "per_gpu_batch": B, "px": args.px, "latent": L,
+            "workload": f"sdxl_turbo_unet_{kind}_{args.px}px_bs{global_batch if strong else B}"
+                        f"_{fpi}step" + ("_sharded" if strong else ""),
+            "global_batch": global_batch, "per_gpu_batch": B, "px": args.px, "latent": L,
+            "unet_forwards_per_image": fpi,
             "w_config": args.w_config, "a_config": args.a_config, "bos": not args.no_bos,
             "parallelism": f"dp{world} (batch-sharded replicas, no step-loop collective)",
             "hip_graph": not args.no_graph, "producer_fusions": not args.no_fuse,
@@ -359,6 +386,7 @@ def main():
         },
         "unet_step_latency_ms": ms,
         "weights_mb": weight_bytes / 2 ** 20,
+        "memory": memory,
         "weight_broadcast_bytes": bcast_bytes,
         "setup_s": setup_s,
     }
@@ -367,6 +395,10 @@ def main():
         out["speedup_vs_fp16"] = fp16["ms_per_step"] / ms
         if "fused_glue_ms_per_step" in fp16:
             out["speedup_vs_fp16_with_fused_glue"] = fp16["fused_glue_ms_per_step"] / ms
+        if "fp16" in memory:
+            q = memory[kind]
+            out["memory"]["saving_vs_fp16"] = {
+                k: memory["fp16"][k] / q[k] for k in ("static_mb", "dynamic_mb", "peak_mb") if q[k]}
     if roof_stats:
         dom = max(roof_stats, key=lambda k: roof_stats[k]["ms"])
         s = roof_stats[dom]
@@ -377,15 +409,20 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # from rocprofv3 --pmc passes
         if os.path.exists(pmc) and args.px == 1024 and B == 1:       # (tools/pmc_probe.py)
             with open(pmc) as f:
-                traffic = json.load(f).get(dom.split("#")[0], {}).get("hbm_bytes_per_launch")
+                key = dom.split("#")[0].replace(",linear_geglu>", ",linear>")
+                traffic = json.load(f).get(key, {}).get("hbm_bytes_per_launch")
         out["roofline"] = {
             "bound": "mfma", "kernel": dom, "achieved": achieved, "peak": INT8_MFMA_PEAK_TOPS,
             "unit": "TFLOP/s", "frac": achieved / INT8_MFMA_PEAK_TOPS, "traffic": traffic,
             "launches_per_step": s["launches"] // args.sweep_reps,
             "avg_launch_us": 1e3 * s["ms"] / s["launches"],
             "ops_per_launch": s["ops"] / s["launches"],
+            "algorithmic_bytes_per_launch": s["bytes"] / s["launches"],
+            "hbm_frac_of_8TBs": s["bytes"] / (s["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "all_igemm": {"tops": tot_ops / (tot_ms * 1e-3) / 1e12,
                           "ms_per_step": tot_ms / args.sweep_reps,
+                          "launches_per_step": sum(v["launches"] for v in roof_stats.values())
+                          // args.sweep_reps,
                           "int8_ops_per_step": tot_ops / args.sweep_reps},
             "per_kernel": {k: {"ms_per_step": v["ms"] / args.sweep_reps,
                                "launches": v["launches"] // args.sweep_reps,

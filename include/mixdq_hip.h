@@ -39,7 +39,15 @@ enum mixdq_status {
   MIXDQ_ERR_ALIGNMENT = 2,       /* "Int8 kernel with input or output alignment not to 4 is not
                                     supported." (qlinear.cc:131-134, qconv2d.cc:200-203)          */
   MIXDQ_ERR_UNSUPPORTED = 3,     /* dilation != 1 (op/qconv2d.py:120 "dilation has bugs")         */
-  MIXDQ_ERR_LAUNCH = 4           /* hipGetLastError() != hipSuccess ("CUTLASS kernel failed")    */
+  MIXDQ_ERR_LAUNCH = 4,          /* hipGetLastError() != hipSuccess ("CUTLASS kernel failed")    */
+  /* codes 5.. have no reference counterpart: limits of entry points the reference does not have */
+  MIXDQ_ERR_W4_SHAPE = 5,        /* MIXDQ_FLAG_W4: K % 32 != 0 (conv: C % 32) or an operand pointer
+                                    not 16-byte aligned                                           */
+  MIXDQ_ERR_GEGLU_SHAPE = 6,     /* mixdq_qlinear_w8a8_geglu: N % 64, K % 16 or pointer alignment */
+  MIXDQ_ERR_PADDING = 7,         /* conv: padding >= kernel size (a window with no in-image tap)  */
+  MIXDQ_ERR_ROWMAP_RESIDUAL = 8, /* output row map and residual in one call                       */
+  MIXDQ_ERR_SHAPE = 9            /* shape outside a fused kernel's range (head_dim != 64, GroupNorm
+                                    geometry, LayerNorm width, tensor rank)                       */
 };
 
 /* Bit flags accepted by the compute entry points. */
@@ -184,7 +192,7 @@ int mixdq_gemm_f16(const void* A_f16, const void* B_f16_kn, void* D_f16,
  * GroupNorm (+SiLU) + quantize on an NHWC tensor x [N, HW, C] (fp16), G groups, gamma/beta fp16 [C].
  * Writes int8 [N, HW, C] (if out_q != null) and/or the fp16 activation (if out_f16 != null).
  * Needs C % 8 == 0 and groups that an 8-channel run straddles at most once
- * (MIXDQ_ERR_UNSUPPORTED otherwise).  `workspace`: mixdq_groupnorm_workspace_bytes() bytes. */
+ * (MIXDQ_ERR_SHAPE otherwise).  `workspace`: mixdq_groupnorm_workspace_bytes() bytes. */
 size_t mixdq_groupnorm_workspace_bytes(int N, int64_t HW, int C, int G);
 int mixdq_groupnorm_silu_quantize(const void* x_nhwc_f16, const void* gamma_f16,
                                   const void* beta_f16, float eps, int apply_silu,
@@ -215,7 +223,7 @@ int mixdq_geglu_quantize(const void* h_f16, int64_t M, int D,
  * out[m, d] = sat8(rint(y * scale_inv + zero_point)), y = f16(f16(v) * f16(gelu(f16(g)))) -- every
  * rounding point of GEMM -> fp16 -> mixdq_geglu_quantize is kept, so the int8 [M, D] result is
  * bit-identical to that two-launch chain (diffusers GEGLU: hidden, gate = proj(x).chunk(2);
- * hidden * gelu(gate)).  N % 64 == 0, K % 16 == 0 (MIXDQ_ERR_UNSUPPORTED otherwise). */
+ * hidden * gelu(gate)).  N % 64 == 0, K % 16 == 0 (MIXDQ_ERR_GEGLU_SHAPE otherwise). */
 int mixdq_qlinear_w8a8_geglu(const int8_t* A, const int8_t* W_interleaved, const float* bias0,
                              const float* scale, const void* bias_f16_or_null, int8_t* out_i8,
                              int64_t M, int N, int K, const float* out_scale_inv,
@@ -252,6 +260,8 @@ int mixdq_igemm_select(int64_t M, int N, int k_align, int k_total, int* bm, int*
  * which bits 8..15 of `flags` can force; 0 = the small-alignment generic kernel, -1 = invalid):
  * two ids may share a tile shape and differ in the number of waves working on it. */
 int mixdq_igemm_select_id(int64_t M, int N, int k_align, int k_total);
+/* The same for a packed-W4 weight operand (MIXDQ_FLAG_W4); -1 = invalid (k_align % 32 != 0). */
+int mixdq_igemm_select_id_w4(int64_t M, int N, int k_align, int k_total);
 
 #ifdef __cplusplus
 }

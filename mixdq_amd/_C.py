@@ -60,10 +60,15 @@ ABI_VERSION = _lib.mixdq_abi_version()
 
 _lib.mixdq_igemm_select_id.argtypes = [_i64, _i32, _i32, _i32]
 _lib.mixdq_igemm_select_id.restype = _i32
+_lib.mixdq_igemm_select_id_w4.argtypes = [_i64, _i32, _i32, _i32]
+_lib.mixdq_igemm_select_id_w4.restype = _i32
 
 
-def igemm_select_id(M: int, N: int, k_align: int, k_total: int = 0) -> int:
-    """Configuration id (IGEMM_CONFIGS key) the automatic choice makes for this problem."""
+def igemm_select_id(M: int, N: int, k_align: int, k_total: int = 0, w4: bool = False) -> int:
+    """Configuration id (IGEMM_CONFIGS key) the automatic choice makes for this problem
+    (`w4`: for packed 4-bit weights, MIXDQ_FLAG_W4)."""
+    if w4:
+        return int(_lib.mixdq_igemm_select_id_w4(M, N, k_align, k_total or k_align))
     return int(_lib.mixdq_igemm_select_id(M, N, k_align, k_total or k_align))
 
 
@@ -93,6 +98,25 @@ FLAG_W4 = 2   # MIXDQ_FLAG_W4: the weight tensor holds packed signed 4-bit value
 # Rounding variant of the fused multiply-adds: "A" (default) = FMA,
 # "B" = separate multiply and add.  Read once at import; no other global state.
 FLAGS = 1 if os.environ.get("MIXDQ_EPILOGUE_VARIANT", "A").upper() == "B" else 0
+
+
+# Launch recorder (measurement only: bench.py's roofline leg, tools/).  While `RECORD` is a list,
+# every INT8 GEMM / conv entry point appends (name, (M, N, K, k_align), w4, replay) to it, where
+# replay() re-issues the very same launch on the same device tensors.  None = off (the default).
+RECORD = None
+
+
+def _record(name, M, N, K, k_align, w4, fn, args, kwargs):
+    if RECORD is None:
+        return
+    def replay():
+        global RECORD
+        saved, RECORD = RECORD, None
+        try:
+            return fn(*args, **kwargs)
+        finally:
+            RECORD = saved
+    RECORD.append((name, (int(M), int(N), int(K), int(k_align)), bool(w4), replay))
 
 
 def _check(cond: bool, msg: str):
@@ -213,6 +237,11 @@ def qlinear_w8_a8_ohalf(input_int8, weight_int8, weight_scale, input_scale, inpu
         _check(_residual.dtype == torch.float16 and _residual.is_contiguous()
                and _residual.numel() == (M // _residual_div) * N,
                "residual should be contiguous fp16 of M / residual_div rows")
+    _record("linear", M, N, K, K, _w4, qlinear_w8_a8_ohalf,
+            (input_int8, weight_int8, weight_scale, input_scale, input_zero_point,
+             weight_sum_by_input_channels, scale, bias0, bias),
+            dict(_out=_out, _row_map=_row_map, _cfg=_cfg, _residual=_residual,
+                 _residual_div=_residual_div, _w4=_w4))
     with torch.cuda.device(dev):
         code = _lib.mixdq_qlinear_w8a8_rows(a.data_ptr(), w.data_ptr(), b0.data_ptr(),
                                             sc.data_ptr(), _ptr(bs), D.data_ptr(), M, N, K,
@@ -248,6 +277,9 @@ def qlinear_geglu(input_int8, weight_int8, scale, bias0, bias, out_scale_inv, ou
     out = torch.empty(list(input_int8.shape[:-1]) + [N // 2], dtype=torch.int8, device=a.device)
     sc, b0 = _f32vec(scale), _f32vec(bias0)
     bs = None if bias is None else bias.contiguous()
+    _record("linear_geglu", M, N, K, K, _w4, qlinear_geglu,
+            (input_int8, weight_int8, scale, bias0, bias, out_scale_inv, out_zero_point),
+            dict(_cfg=_cfg, _w4=_w4))
     with torch.cuda.device(a.device):
         code = _lib.mixdq_qlinear_w8a8_geglu(a.data_ptr(), w.data_ptr(), b0.data_ptr(),
                                              sc.data_ptr(), _ptr(bs), out.data_ptr(), M, N, K,
@@ -325,6 +357,11 @@ def qconv2d_w8_a8_ohalf(input_int8, weight_int8, weight_scale, input_scale, inpu
                     memory_format=torch.channels_last)
     sc = _f32vec(scale)
     bs = None if bias is None else bias.contiguous()
+    _record("conv", N * P * Q, K, R * S * C, C, _w4, qconv2d_w8_a8_ohalf,
+            (input_int8, weight_int8, weight_scale, input_scale, input_zero_point, scale,
+             weight_sum_by_input_channels, bias0, bias, stride, padding, dilation),
+            dict(_table=_table, _cfg=_cfg, _residual=_residual,
+                 _residual_per_image=_residual_per_image, _w4=_w4))
     with torch.cuda.device(dev):
         res_ptr, res_div = None, 1
         if _residual is not None:
@@ -360,14 +397,19 @@ def qconv2d_w8_a8_ohalf(input_int8, weight_int8, weight_scale, input_scale, inpu
     return D
 
 
-def conv_border_table(weight_sum_by_input_channels):
+def conv_border_table(weight_sum_by_input_channels, out=None):
     """Tap-rectangle sums of wsum [K,1,R,S] -> [(R*R*S*S), K] f32 (include/mixdq_hip.h,
-    mixdq_conv_border_table).  Depends only on the weights: QuantizedConv2d caches it."""
+    mixdq_conv_border_table).  Depends only on the weights: QuantizedConv2d caches it (`out`: an
+    existing table to rebuild in place)."""
     wsum = weight_sum_by_input_channels.contiguous()
     _check(wsum.is_cuda and wsum.dtype == torch.float32 and wsum.dim() == 4,
            "weight_sum_by_input_channels should be a float32 [K,1,R,S] GPU tensor")
     K, _, R, S = wsum.shape
-    table = torch.empty((R * R * S * S, K), dtype=torch.float32, device=wsum.device)
+    table = out
+    if table is None:
+        table = torch.empty((R * R * S * S, K), dtype=torch.float32, device=wsum.device)
+    _check(tuple(table.shape) == (R * R * S * S, K) and table.dtype == torch.float32
+           and table.is_contiguous() and table.device == wsum.device, "border table shape")
     with torch.cuda.device(wsum.device):
         code = _lib.mixdq_conv_border_table(wsum.data_ptr(), table.data_ptr(), K, R, S, _stream())
     _status(code, "conv_border_table")

@@ -606,7 +606,7 @@ extern "C" int mixdq_attention_f16(const void* q, const void* k, const void* v, 
   hipStream_t stream = (hipStream_t)stream_;
   if (batch < 0 || heads <= 0 || tq < 0 || tkv <= 0) return MIXDQ_ERR_INVALID_ARG;
   if ((out_scale_inv == nullptr) != (out_zero_point == nullptr)) return MIXDQ_ERR_INVALID_ARG;
-  if (head_dim != kHeadDim) return MIXDQ_ERR_UNSUPPORTED;
+  if (head_dim != kHeadDim) return MIXDQ_ERR_SHAPE;
   if (batch == 0 || tq == 0) return MIXDQ_OK;       // nothing to write (pointers may be null)
   if (!q || !k || !v || !out) return MIXDQ_ERR_INVALID_ARG;
   const bool quant = out_scale_inv != nullptr;
@@ -617,7 +617,7 @@ extern "C" int mixdq_attention_f16(const void* q, const void* k, const void* v, 
     if (s % 8) return MIXDQ_ERR_ALIGNMENT;
   // key-row offsets are formed in 32 bits
   if ((int64_t)tkv * k_row_stride >= (1ll << 31) || (int64_t)tkv * v_row_stride >= (1ll << 31))
-    return MIXDQ_ERR_UNSUPPORTED;
+    return MIXDQ_ERR_SHAPE;
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15) return MIXDQ_ERR_ALIGNMENT;
   if ((uintptr_t)out & (quant ? 7 : 15)) return MIXDQ_ERR_ALIGNMENT;
 

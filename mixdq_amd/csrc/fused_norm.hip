@@ -352,7 +352,7 @@ extern "C" int mixdq_groupnorm_silu_quantize(const void* x_nhwc, const void* gam
                                              void* workspace, int N, int64_t HW, int C, int G,
                                              int flags, mixdq_stream_t stream_) {
   GnGeom g;
-  if (!make_gn_geom(N, HW, C, G, g)) return MIXDQ_ERR_UNSUPPORTED;
+  if (!make_gn_geom(N, HW, C, G, g)) return MIXDQ_ERR_SHAPE;
   if (!x_nhwc || !gamma || !beta || !workspace || (!out_q_or_null && !out_f16_or_null))
     return MIXDQ_ERR_INVALID_ARG;
   if (out_q_or_null && (!scale_inv || !zero_point)) return MIXDQ_ERR_INVALID_ARG;
@@ -387,7 +387,7 @@ extern "C" int mixdq_layernorm_quantize(const void* x, const void* gamma, const 
                                         const float* const* zero_point, int8_t* const* out_q,
                                         void* out_f16_or_null, int flags, mixdq_stream_t stream_) {
   if (M < 0 || C <= 0 || n_out < 0 || n_out > 3) return MIXDQ_ERR_INVALID_ARG;
-  if (C % 8 != 0 || C / 8 > 64 * kLnMaxChunks) return MIXDQ_ERR_UNSUPPORTED;
+  if (C % 8 != 0 || C / 8 > 64 * kLnMaxChunks) return MIXDQ_ERR_SHAPE;
   if (M == 0) return MIXDQ_OK;
   if (!x || !gamma || !beta || (n_out == 0 && !out_f16_or_null)) return MIXDQ_ERR_INVALID_ARG;
   const float* si[3] = {nullptr, nullptr, nullptr};
@@ -418,7 +418,7 @@ extern "C" int mixdq_geglu_quantize(const void* h, int64_t M, int D, const float
                                     const float* zero_point, int8_t* out_q_or_null,
                                     void* out_f16_or_null, int flags, mixdq_stream_t stream_) {
   if (M < 0 || D <= 0) return MIXDQ_ERR_INVALID_ARG;
-  if (D % 8 != 0) return MIXDQ_ERR_UNSUPPORTED;
+  if (D % 8 != 0) return MIXDQ_ERR_SHAPE;
   if (M == 0) return MIXDQ_OK;
   if (!h || (!out_q_or_null && !out_f16_or_null)) return MIXDQ_ERR_INVALID_ARG;
   if (out_q_or_null && (!scale_inv || !zero_point)) return MIXDQ_ERR_INVALID_ARG;

@@ -15,7 +15,8 @@
 //   * LDS tiles are [rows][BK bytes] with the 16-byte chunk index XOR-swizzled by the row
 //     (ds_read_b128 conflict-free); because LDS-DMA writes lane-linear, the swizzle is applied to
 //     the source address and to the fragment read (both-sides rule).
-//   * 2 LDS stages; the next K-tile's DMA is in flight while the current one is multiplied.
+//   * STAGES (2-4) LDS buffers, STAGES-1 K-tiles of DMA in flight behind one counted vmcnt wait
+//     and one raw s_barrier per K-tile.
 //   * padded convs: per-pixel bias0 = zp * (sum of in-bounds taps of wsum) is looked up from a
 //     (R*R*S*S) x K table of tap-rectangle sums indexed by the pixel's border class, instead of
 //     materialising an [N,P,Q,K] f32 tensor per call as the reference does.
@@ -792,7 +793,7 @@ int dispatch_w4(IgemmParams& p, hipStream_t stream, int forced_cfg) {
                       ((uintptr_t)p.D % 16 == 0) && ((uintptr_t)p.scale % 16 == 0) &&
                       ((uintptr_t)p.bias0 % 16 == 0) && ((uintptr_t)p.table % 16 == 0) &&
                       ((uintptr_t)p.bias % 8 == 0) && ((uintptr_t)p.res % 16 == 0);
-  if (align_k % 32 != 0 || !ptr_ok) return MIXDQ_ERR_UNSUPPORTED;   // packed pieces span 32 k
+  if (align_k % 32 != 0 || !ptr_ok) return MIXDQ_ERR_W4_SHAPE;   // packed pieces span 32 k
   const int cfg = forced_cfg > 0 ? forced_cfg : select_cfg_w4(p.M, p.N, p.Ktot);
   switch (cfg) {
     case 3: return launch_tile_w4<128, 128, 64, 2, 2, 2, CONV>(p, stream);
@@ -853,7 +854,7 @@ extern "C" int mixdq_qlinear_w8a8_rows(const int8_t* A, const int8_t* W, const f
   p.grp_rows = group_rows; p.grp_stride = group_stride; p.grp_off = group_offset;
   p.res = (const __half*)residual_f16_or_null;
   p.res_div = residual_row_div > 0 ? residual_row_div : 1;
-  if (p.res && group_rows > 0) return MIXDQ_ERR_UNSUPPORTED;   // residual rows follow m, not D_row
+  if (p.res && group_rows > 0) return MIXDQ_ERR_ROWMAP_RESIDUAL;   // residual rows follow m, not D_row
   p.unfused = (flags & MIXDQ_FLAG_UNFUSED) ? 1 : 0;
   if (flags & MIXDQ_FLAG_W4) return dispatch_w4<false>(p, (hipStream_t)stream, (flags >> 8) & 0xff);
   return dispatch<false>(p, (hipStream_t)stream, (flags >> 8) & 0xff);
@@ -869,10 +870,10 @@ extern "C" int mixdq_qlinear_w8a8_geglu(const int8_t* A, const int8_t* W, const 
   if (!A || !W || !bias0 || !scale || !out_i8 || !out_scale_inv || !out_zero_point)
     return MIXDQ_ERR_INVALID_ARG;
   // whole value/gate groups per tile, the LDS-DMA kernels only, 8-byte output stores
-  if (N % 64 != 0 || K % 16 != 0 || ((uintptr_t)out_i8 & 7)) return MIXDQ_ERR_UNSUPPORTED;
+  if (N % 64 != 0 || K % 16 != 0 || ((uintptr_t)out_i8 & 7)) return MIXDQ_ERR_GEGLU_SHAPE;
   if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)scale | (uintptr_t)bias0) & 15)
-    return MIXDQ_ERR_UNSUPPORTED;
-  if ((uintptr_t)bias_f16_or_null & 7) return MIXDQ_ERR_UNSUPPORTED;
+    return MIXDQ_ERR_GEGLU_SHAPE;
+  if ((uintptr_t)bias_f16_or_null & 7) return MIXDQ_ERR_GEGLU_SHAPE;
   IgemmParams p{};
   p.A = A; p.Wt = W; p.bias0 = bias0; p.scale = scale; p.bias = (const __half*)bias_f16_or_null;
   p.D = nullptr; p.Dq = out_i8; p.g_sinv = out_scale_inv; p.g_zp = out_zero_point;
@@ -918,7 +919,7 @@ extern "C" int mixdq_qconv2d_w8a8_table(const int8_t* X, const int8_t* Wt, const
   if (!X || !Wt || !scale || !D) return MIXDQ_ERR_INVALID_ARG;
   if (pad > 0 ? (!table_or_null || !zero_point) : !bias0_or_null) return MIXDQ_ERR_INVALID_ARG;
   // every output pixel's window must overlap the image (border classes are non-empty rectangles)
-  if (pad >= R || pad >= S) return MIXDQ_ERR_UNSUPPORTED;
+  if (pad >= R || pad >= S) return MIXDQ_ERR_PADDING;
   const int P = (H + 2 * pad - (R - 1) - 1) / stride + 1;
   const int Q = (W + 2 * pad - (S - 1) - 1) / stride + 1;
   if (P <= 0 || Q <= 0 || N == 0) return MIXDQ_OK;
@@ -993,6 +994,18 @@ extern "C" const char* mixdq_status_string(int status) {
       return "Int8 kernel with input or output alignment not to 4 is not supported.";
     case MIXDQ_ERR_UNSUPPORTED: return "unsupported configuration (dilation must be 1)";
     case MIXDQ_ERR_LAUNCH: return "HIP kernel launch failed";
+    case MIXDQ_ERR_W4_SHAPE:
+      return "unsupported configuration (packed 4-bit weights need K % 32 == 0 -- conv: C % 32 == 0 "
+             "-- and 16-byte aligned operands)";
+    case MIXDQ_ERR_GEGLU_SHAPE:
+      return "unsupported configuration (GEMM+GEGLU needs N % 64 == 0, K % 16 == 0, 16-byte aligned "
+             "operands and an 8-byte aligned output)";
+    case MIXDQ_ERR_PADDING:
+      return "unsupported configuration (padding must be smaller than the kernel size)";
+    case MIXDQ_ERR_ROWMAP_RESIDUAL:
+      return "unsupported configuration (an output row map and a residual cannot be combined)";
+    case MIXDQ_ERR_SHAPE:
+      return "unsupported configuration (shape outside this fused kernel's range)";
     default: return "unknown status";
   }
 }
@@ -1003,6 +1016,11 @@ extern "C" int mixdq_igemm_select_id(int64_t M, int N, int k_align, int k_total)
   if (M <= 0 || N <= 0 || k_align % 4 != 0 || N % 4 != 0) return -1;
   if (k_align % 16 != 0) return 0;   // generic kernel
   return select_cfg(M, N, k_total);
+}
+
+extern "C" int mixdq_igemm_select_id_w4(int64_t M, int N, int k_align, int k_total) {
+  if (M <= 0 || N <= 0 || k_align % 32 != 0 || N % 4 != 0) return -1;
+  return select_cfg_w4(M, N, k_total);
 }
 
 extern "C" int mixdq_igemm_select(int64_t M, int N, int k_align, int k_total, int* bm, int* bn,

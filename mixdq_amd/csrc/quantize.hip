@@ -173,7 +173,7 @@ extern "C" int mixdq_quantize_f16_i8(const void* x_f16, int8_t* out, const int64
     }
   }
   if (m == 0) { sz[0] = 1; xs[0] = 1; os[0] = 1; m = 1; }
-  if (m > 4) return MIXDQ_ERR_UNSUPPORTED;
+  if (m > 4) return MIXDQ_ERR_SHAPE;
   const __half* x = (const __half*)x_f16;
   const bool aligned = ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 8 == 0);
 

@@ -39,6 +39,10 @@ def _w8a8_ok(w, a, w4_kernel=False) -> bool:
         and torch.all(w.zero_points == 0.0).item())
 
 
+def _refresh_after_load(mod, _incompatible_keys):
+    mod.refresh_derived_()
+
+
 class QuantizedConv2d(nn.Module):
     w4_kernel = False   # W4A8 kernel path, see QuantizedLinear.w4_kernel
 
@@ -79,6 +83,7 @@ class QuantizedConv2d(nn.Module):
             self._register_qparams("", w_qparams, a_qparams, device)
             if split != 0:
                 self._register_qparams("_0", w_qparams_0, a_qparams_0, device)
+            self.register_load_state_dict_post_hook(_refresh_after_load)
 
     def _register_qparams(self, sfx, w, a, device):
         self.register_buffer("weight_scales" + sfx, w.scales.to(device).float())
@@ -91,8 +96,9 @@ class QuantizedConv2d(nn.Module):
         scales = getattr(self, "weight_scales" + sfx)
         azp = getattr(self, "act_zero_points" + sfx)
         if self.w_packed4:   # the Path A integers, packed along C in [K, R, S, C] order
+            lim = 2 ** (self.w_bit - 1)          # 2-bit layers: [-2, 1] in 4-bit storage
             weight_int = torch.clamp(torch.round(weight.float() / scales[:, None, None, None]),
-                                     -8, 7).to(torch.int8)
+                                     -lim, lim - 1).to(torch.int8)
             packed = pack_w4(weight_int.permute(0, 2, 3, 1).contiguous())      # [K, R, S, C/2]
             self.register_buffer("weight_int4" + sfx, packed.permute(0, 3, 1, 2))
         else:
@@ -135,6 +141,7 @@ class QuantizedConv2d(nn.Module):
                       w_qparams_0=w_qparams_0, a_qparams=a_qparams, a_qparams_0=a_qparams_0,
                       module_name=float_mod.module_name, split=split,
                       w4_kernel=getattr(float_mod, "w4_kernel", cls.w4_kernel))
+        new_mod.w_bit = int(getattr(float_mod, "w_bit", 8))
         weight = float_mod.weight.detach()
         pad = float_mod.padding[0]
         if new_mod.valid_for_acceleration:
@@ -175,17 +182,28 @@ class QuantizedConv2d(nn.Module):
                 + F.conv2d(x[:, self.split:], deq("_0"), None, *args))
 
     def _border_table(self, sfx):
-        """Cached tap-rectangle sums for padded convs (weights only => computed once)."""
+        """Cached tap-rectangle sums for padded convs.  Derived from the weights only, so it is
+        built once -- and rebuilt IN PLACE (same address: captured graphs keep reading it) when
+        weight_sum_by_input_channels is replaced or updated in place (load_state_dict, broadcast)."""
         if self.padding[0] == 0:
             return None
         wsum = getattr(self, "weight_sum_by_input_channels" + sfx)
         cache = self.__dict__.setdefault("_tables", {})
-        key = (sfx, wsum.data_ptr(), wsum.device)
-        if key not in cache:
-            if len(cache) > 4:   # buffers were moved / replaced: drop stale tables
-                cache.clear()
-            cache[key] = _C.conv_border_table(wsum)
-        return cache[key]
+        e = cache.get(sfx)
+        if e is not None and e[0] is wsum and e[1] == wsum._version:
+            return e[2]
+        out = None
+        if e is not None and e[2].device == wsum.device and e[2].shape[1] == wsum.shape[0]:
+            out = e[2]
+        table = _C.conv_border_table(wsum, out=out)
+        cache[sfx] = (wsum, wsum._version, table)
+        return table
+
+    def refresh_derived_(self):
+        """Re-derive cached state from the buffers after they were written in place."""
+        if self.valid_for_acceleration and self.padding[0] > 0 and self.scale.is_cuda:
+            for sfx in ("", "_0") if self.split else ("",):
+                self._border_table(sfx)
 
     def forward_quantized(self, x_int, residual=None, residual_per_image=False):
         """The conv half of forward() for an input already quantized with this layer's activation

@@ -102,9 +102,11 @@ class QuantizedLinear(nn.Module):
             new_mod.bos = float_mod.bos
             new_mod.register_buffer("bos_pre_computed", float_mod.bos_pre_computed)
         if new_mod.valid_for_acceleration and new_mod.w_packed4:
-            # the Path A integers (base_quantizer.py:119-127, sym, n_levels = 7)
+            # the Path A integers (base_quantizer.py:119-127: sym, clamp to the layer's own bit
+            # width -- a 2-bit layer loads the 2-bit delta and clamps to [-2, 1]; storage is 4-bit)
+            lim = 2 ** (int(getattr(float_mod, "w_bit", 4)) - 1)
             weight_int = torch.clamp(torch.round(weight.float() / new_mod.weight_scales[:, None]),
-                                     -8, 7).to(torch.int8)
+                                     -lim, lim - 1).to(torch.int8)
             new_mod.register_buffer("weight_int4", pack_w4(weight_int))
         elif new_mod.valid_for_acceleration:
             weight_int = torch.quantize_per_channel(

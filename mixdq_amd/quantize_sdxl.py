@@ -3,8 +3,10 @@
     register_qconfig_from_input_files(unet, args, bos, bos_dict)    quantize_sdxl.py:39-139
     convert_to_quantized(unet, ckpt)                                 quantize_sdxl.py:142-150
     quantize_unet(unet, args, ckpt, bos, bos_dict)                   quantize_sdxl.py:154-156
-    hip_graph_opt(unet)   (reference name cuda_graph_opt kept as alias)  quantize_sdxl.py:184-286
+    hip_graph_opt(unet, args=None)  (reference name cuda_graph_opt kept)  quantize_sdxl.py:184-286
     example_inputs(...)                                              quantize_sdxl.py:350-373
+    run(unet, args)  static / dynamic / peak memory + timing harness  quantize_sdxl.py:331-484
+    layers_roctx_annotate(unet)  profiler ranges per block            quantize_sdxl.py:14-29,387-429
 
 `unet` is any nn.Module whose Linear/Conv2d sub-module names match the yaml keys: a diffusers
 UNet2DConditionModel (where diffusers exists) or mixdq_amd.unet.SDXLUNet (this repo).
@@ -148,10 +150,15 @@ def _copy_into(dst, src):
             _copy_into(dst[k], s)
 
 
-def hip_graph_opt(unet, warmup: int = 3):
+def hip_graph_opt(unet, args=None, warmup: int = 3):
     """Replace unet.forward by capture-once / copy-inputs / replay, keyed by argument shapes and
     dtypes.  The operators are capture-safe: asynchronous launches on the current stream, scalars
-    read on the device, all memory from torch's allocator."""
+    read on the device, all memory from torch's allocator.
+
+    Signature of the reference's `cuda_graph_opt(unet, args)` (quantize_sdxl.py:184): `args` (the
+    script's argparse namespace) is accepted and, as in the reference, not used."""
+    if isinstance(args, int) and not isinstance(args, bool):    # hip_graph_opt(unet, 5): warm-up count
+        args, warmup = None, args
     lock = threading.Lock()
     cache = {}
     wrapped = unet.forward
@@ -208,3 +215,126 @@ def example_inputs(batch_size: int, sample_size: int, device, in_channels: int =
                                   device=device).repeat(batch_size, 1),
             text_embeds=rand(batch_size, 1280)),
     )
+
+
+# ---------------------------------------------------------------------------------------------
+# run harness: memory report and profiler ranges (quantize_sdxl.py:331-484)
+# ---------------------------------------------------------------------------------------------
+def make_memory_friendly(n_bytes: int) -> str:
+    return f"{n_bytes / 2 ** 20:.1f} MB"
+
+
+class MemoryMeter:
+    """The reference's three numbers (quantize_sdxl.py:337-338,453-456; kernels/README.md:82-91):
+    static = torch.cuda.memory_allocated() once the network is resident, peak =
+    max_memory_allocated() after the (graph-captured) runs, dynamic = peak - static."""
+
+    def __init__(self, device=None):
+        self.device = device
+        torch.cuda.synchronize(device)
+        torch.cuda.reset_peak_memory_stats(device)
+        self.static = torch.cuda.memory_allocated(device)
+
+    def report(self) -> dict:
+        torch.cuda.synchronize(self.device)
+        peak = torch.cuda.max_memory_allocated(self.device)
+        mb = 2 ** 20
+        return dict(static_mb=self.static / mb, dynamic_mb=(peak - self.static) / mb,
+                    peak_mb=peak / mb)
+
+
+def _range_wrap(forward, name):
+    @functools.wraps(forward)
+    def wrapper(*args, **kwargs):
+        torch.cuda.nvtx.range_push(name)        # roctx on ROCm: visible to rocprofv3 --marker-trace
+        try:
+            return forward(*args, **kwargs)
+        finally:
+            torch.cuda.nvtx.range_pop()
+    wrapper._mixdq_range = name
+    return wrapper
+
+
+def layers_roctx_annotate(unet, every_layer: bool = False):
+    """Profiler ranges around the UNet's blocks and a few representative layers -- the reference's
+    `layers_nvtx_annotate` (quantize_sdxl.py:387-429) with its names; `torch.cuda.nvtx` emits roctx
+    ranges on ROCm.  Ranges are host-side: annotate for EAGER profiling runs, not under a captured
+    graph.  Returns the list of range names."""
+    mods = {}
+
+    def add(name, getter):
+        try:
+            mods[name] = getter()
+        except (AttributeError, IndexError):
+            pass
+
+    add("conv_320_320", lambda: unet.down_blocks[0].resnets[0].conv1)
+    add("conv_1280_1280", lambda: unet.down_blocks[2].resnets[0].conv2)
+    add("conv_2560_1280", lambda: unet.up_blocks[0].resnets[0].conv1)
+    add("linear_640_640", lambda: unet.down_blocks[1].attentions[0].transformer_blocks[0].attn1.to_q)
+    add("linear_1280_1280",
+        lambda: unet.down_blocks[2].attentions[0].transformer_blocks[0].attn1.to_q)
+    add("linear_2048_1280",
+        lambda: unet.down_blocks[2].attentions[0].transformer_blocks[0].attn2.to_k)
+    for i, blk in enumerate(unet.down_blocks):
+        for j, r in enumerate(blk.resnets):
+            mods[f"down_block_{i}_resnet_{j}"] = r
+        for j, t in enumerate(getattr(blk, "attentions", None) or []):
+            mods[f"down_block_{i}_transformers_{j}"] = t
+    for i, blk in enumerate(unet.up_blocks):
+        for j, r in enumerate(blk.resnets):
+            mods[f"up_block_{i}_resnet_{j}"] = r
+        for j, t in enumerate(getattr(blk, "attentions", None) or []):
+            mods[f"up_block_{i}_transformers_{j}"] = t
+    for j, r in enumerate(unet.mid_block.resnets):
+        mods[f"mid_block_resnet_{j}"] = r
+    for j, t in enumerate(unet.mid_block.attentions[0].transformer_blocks):
+        mods[f"mid_block_transformers_{j}"] = t
+    if every_layer:
+        for name, m in unet.named_modules():
+            if name and not any(True for _ in m.children()):
+                mods.setdefault(name, m)
+    for name, m in mods.items():
+        if not hasattr(m.forward, "_mixdq_range"):
+            m.forward = _range_wrap(m.forward, name)
+    return list(mods)
+
+
+def run(unet, args=None, batch_size: int = 1, sample_size: int = 128, cuda_graph_only: bool = True,
+        profile: bool = False, device="cuda", out=print):
+    """The UNet-only leg of the reference's `run(pipeline, args)` (quantize_sdxl.py:331-484): move
+    the network to the GPU, report static memory, two eager runs, optional graph capture and two
+    replays, dynamic and peak memory, optional 3 range-annotated iterations for the profiler.
+    `args` may carry batch_size / cuda_graph_only / profile (the reference's flag names)."""
+    batch_size = getattr(args, "batch_size", batch_size)
+    cuda_graph_only = getattr(args, "cuda_graph_only", cuda_graph_only)
+    profile = getattr(args, "profile", profile)
+    unet.to(device)
+    meter = MemoryMeter(device)
+    out("Static (weights) memory usage: " + make_memory_friendly(meter.static))
+    inputs = example_inputs(batch_size, sample_size, device)
+
+    def run_once():
+        with torch.no_grad():
+            return unet(**inputs)[0]
+
+    latents = run_once()
+    latents = run_once()
+    if cuda_graph_only:
+        hip_graph_opt(unet, args)
+        latents = run_once()
+        latents = run_once()
+    rep = meter.report()
+    out("Dynamic (acts) memory usage: " + make_memory_friendly(int(rep["dynamic_mb"] * 2 ** 20)))
+    out("Peak (total) memory usage: " + make_memory_friendly(int(rep["peak_mb"] * 2 ** 20)))
+    if profile:
+        graphed = getattr(unet.forward, "__wrapped__", None)
+        if graphed is not None:
+            unet.forward = graphed                    # ranges are host-side: profile eagerly
+        layers_roctx_annotate(unet)
+        for it in range(3):
+            torch.cuda.nvtx.range_push(f"iter_{it}")
+            run_once()
+            torch.cuda.nvtx.range_pop()
+        torch.cuda.synchronize()
+    return latents, rep

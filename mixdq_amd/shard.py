@@ -90,6 +90,13 @@ def broadcast_module_state(module: torch.nn.Module, src: int = 0, bucket_bytes: 
                 off += b.numel()
             total += size
             bucket, size = ([t], t.numel() * t.element_size()) if t is not None else ([], 0)
+    # the buffers were written in place: state derived from them (conv border tables, BOS rows of
+    # persistent K/V buffers) is re-derived at its existing addresses
+    for m in module.modules():
+        if hasattr(m, "refresh_derived_"):
+            m.refresh_derived_()
+            if m is module:
+                break          # a root-level refresh (SDXLUNet) already walks its sub-modules
     return total
 
 

@@ -52,6 +52,84 @@ def _fusable_f16(x) -> bool:
     return x.is_cuda and x.dtype == torch.float16
 
 
+# ---------------------------------------------------------------------------------------------
+# Derived state of the fused graph (packed GEMM operands, quantizer groupings) is cached on the
+# modules.  Two rules keep the caches honest:
+#   * a cached DECISION (do these layers share one activation quantizer?) is valid only for the
+#     very tensors it was taken on, at their current in-place `_version` -- module swaps
+#     (quantize_unet after an FP16 run), `.to()` and load_state_dict / broadcast all invalidate it;
+#   * cached DATA never goes stale because it is not a copy: the row-concatenated tensors of a
+#     packed GEMM become the storage and the layers' own buffers become views of them, so in-place
+#     updates reach the packed launch -- and every captured graph -- by construction.
+# ---------------------------------------------------------------------------------------------
+def _quantizer_groups(holder: dict, key, layers):
+    """Group id per layer: equal activation qparams <=> equal id.  One device->host copy (a sync:
+    only ever taken in the eager warm-up that precedes graph capture), memoised in `holder[key]`
+    against the identity and in-place version of the qparam tensors."""
+    src = [t for m in layers for t in (m.act_scales_inv, m.act_zero_points)]
+    ver = tuple(t._version for t in src)
+    e = holder.get(key)
+    if (e is not None and len(e[0]) == len(src) and all(a is b for a, b in zip(e[0], src))
+            and e[1] == ver):
+        return e[2]
+    ids = []
+    if layers:
+        vals = torch.stack([t.detach().reshape(-1)[0].float() for t in src]).cpu().tolist()
+        seen = {}
+        for i in range(len(layers)):
+            ids.append(seen.setdefault((vals[2 * i], vals[2 * i + 1]), len(seen)))
+    holder[key] = (src, ver, ids)
+    return ids
+
+
+def _memo(mod) -> dict:
+    return mod.__dict__.setdefault("_mixdq_memo", {})
+
+
+_PACK_VECS = (("wscale", "weight_scales"), ("wsum", "weight_sum_by_input_channels"),
+              ("scale", "scale"), ("bias0", "bias0"))
+
+
+def _pack_rows(layers):
+    """Row-concatenate the weights and per-channel epilogue vectors of Linear layers that read the
+    same INT8 operand: one GEMM against [sum N_i, K] computes every output element exactly as the
+    separate launches do.  The concatenated tensors are the storage; the layers keep views."""
+    w4 = bool(layers[0].w_packed4)
+    names = (("w", "weight_int4" if w4 else "weight_int"),) + _PACK_VECS
+    pack = dict(w4=w4, C=layers[0].out_features, layers=tuple(layers), names=names)
+    with torch.no_grad():
+        for key, name in names:
+            cat = torch.cat([getattr(m, name) for m in layers], dim=0).contiguous()
+            off = 0
+            for m in layers:
+                n = getattr(m, name).shape[0]
+                setattr(m, name, cat[off:off + n])        # registered buffer -> view of the pack
+                off += n
+            pack[key] = cat
+    return pack
+
+
+def _pack_valid(pack, layers) -> bool:
+    """The layers' buffers still alias the pack (false after a module swap, `.to()`, deepcopy...)."""
+    if pack is None or len(pack["layers"]) != len(layers) or any(
+            a is not b for a, b in zip(pack["layers"], layers)):
+        return False
+    for key, name in pack["names"]:
+        cat, off = pack[key], 0
+        row = cat.stride(0) * cat.element_size()
+        for m in layers:
+            t = getattr(m, name, None)
+            if (not torch.is_tensor(t) or t.device != cat.device
+                    or t.data_ptr() != cat.data_ptr() + off * row):
+                return False
+            off += t.shape[0]
+    return True
+
+
+def _refresh_after_load(mod, _incompatible_keys):
+    mod.refresh_derived_()
+
+
 def _gn_feed(norm: nn.GroupNorm, x, consumer, silu: bool):
     """GroupNorm(+SiLU) of a channels-last fp16 x for `consumer`: returns (tensor, quantized?)."""
     from mixdq_amd import _C
@@ -88,23 +166,22 @@ def _ln_feed(norm: nn.LayerNorm, x, consumers):
     if not (_fusable_f16(x) and x.is_contiguous() and C % 8 == 0 and C <= 2048):
         h = norm(x)
         return [(h, False)] * len(consumers)
-    plan = getattr(norm, "_mixdq_plan", None)
-    if plan is None or plan[0] != tuple(id(c) for c in consumers):
-        groups, slot = [], []          # distinct quantizers among the accelerated consumers
+    acc = [c for c in consumers if _accel(c)]
+    ids = _quantizer_groups(_memo(norm), "ln", acc)
+    plan = norm.__dict__.get("_mixdq_plan")
+    if (plan is None or len(plan[0]) != len(consumers)
+            or any(a is not b for a, b in zip(plan[0], consumers)) or plan[3] is not ids):
+        groups, slot, it = {}, [], iter(ids)   # distinct quantizers among the accelerated consumers
         for c in consumers:
             if not _accel(c):
                 slot.append(-1)
                 continue
-            for gi, rep in enumerate(groups):
-                if _same_qparams(rep, c):
-                    slot.append(gi)
-                    break
-            else:
-                groups.append(c)
-                slot.append(len(groups) - 1)
-        plan = (tuple(id(c) for c in consumers), groups, slot)
-        norm._mixdq_plan = plan
-    _, groups, slot = plan
+            gi = next(it)
+            groups.setdefault(gi, c)
+            slot.append(gi)
+        plan = norm.__dict__["_mixdq_plan"] = (tuple(consumers), [groups[g] for g in sorted(groups)],
+                                               slot, ids)
+    _, groups, slot, _ = plan
     want_f16 = any(s < 0 for s in slot)
     outs, h = _C.layernorm_quantize(x, norm.weight, norm.bias, norm.eps, [_qp(g) for g in groups],
                                     want_f16=want_f16)
@@ -341,33 +418,19 @@ class BasicTransformerBlock(nn.Module):
         """Self-attention to_q / to_k / to_v read the same normalised tensor; when all three are
         W8A8 with the SAME activation quantizer (they are calibrated on the same data) and carry no
         bias, one GEMM against the row-concatenated weights [3C, C] replaces three: per-channel
-        scale / bias0 simply concatenate, so every output element is computed exactly as before.
-        The concatenated weight is the storage; the three layers' weight_int become views of it."""
-        cached = self.__dict__.get("_qkv")
-        if cached is not None:
-            return cached or None
+        scale / bias0 simply concatenate, so every output element is computed exactly as before
+        (`_pack_rows`).  Nothing negative is cached: the decision is re-taken whenever the layers
+        or their quantizer tensors change (e.g. quantize_unet after an FP16 run of this graph)."""
         a = self.attn1
         layers = [a.to_q, a.to_k, a.to_v]
-        ok = (all(_accel(m) and m.bias is None for m in layers)
-              and len({bool(m.w_packed4) for m in layers}) == 1
-              and _same_qparams(layers[0], layers[1]) and _same_qparams(layers[0], layers[2]))
-        if not ok:
-            self.__dict__["_qkv"] = False
+        if not (all(_accel(m) and m.bias is None for m in layers)
+                and len({bool(m.w_packed4) for m in layers}) == 1):
             return None
-        w4 = bool(layers[0].w_packed4)
-        attr = "weight_int4" if w4 else "weight_int"     # packed rows concatenate the same way
-        with torch.no_grad():
-            w = torch.cat([getattr(m, attr) for m in layers], dim=0).contiguous()
-            C = layers[0].out_features
-            for i, m in enumerate(layers):
-                setattr(m, attr, w[i * C:(i + 1) * C])
-            pack = dict(
-                w=w, C=C, w4=w4,
-                wscale=torch.cat([m.weight_scales for m in layers]),
-                wsum=torch.cat([m.weight_sum_by_input_channels for m in layers]),
-                scale=torch.cat([m.scale for m in layers]).contiguous(),
-                bias0=torch.cat([m.bias0 for m in layers]).contiguous())
-        self.__dict__["_qkv"] = pack
+        if len(set(_quantizer_groups(_memo(self), "qkv", layers))) != 1:
+            return None
+        pack = self.__dict__.get("_qkv")
+        if not _pack_valid(pack, layers):
+            pack = self.__dict__["_qkv"] = _pack_rows(layers)
         return pack
 
     def forward_fused(self, x, context):
@@ -556,6 +619,7 @@ class SDXLUNet(nn.Module):
             prev = cout
         self.conv_norm_out = nn.GroupNorm(cfg["norm_num_groups"], boc[0], eps=1e-5)
         self.conv_out = nn.Conv2d(boc[0], cfg["out_channels"], 3, 1, 1)
+        self.register_load_state_dict_post_hook(_refresh_after_load)
 
     fused = False
 
@@ -570,26 +634,47 @@ class SDXLUNet(nn.Module):
             return
         if getattr(self, "_kv_stream", None) is None:
             self._kv_stream = torch.cuda.Stream(device=context.device)
+        f16_tail = context.dtype == torch.float16 and context.shape[1] > 1
+
+        def bos_w8a8(layer):
+            return bool(getattr(layer, "valid_for_acceleration", False)
+                        and getattr(layer, "bos", False) and f16_tail)
+
+        # quantizer grouping of every BOS W8A8 K/V layer, taken once (memoised; no host
+        # comparison ever runs inside the forward proper, so the loop below is capture-safe)
+        kv_layers = [l for blk in blocks for l in (blk.attn2.to_k, blk.attn2.to_v) if bos_w8a8(l)]
+        gid = dict(zip(map(id, kv_layers), _quantizer_groups(_memo(self), "ctx", kv_layers)))
         main = torch.cuda.current_stream()
         side = self._kv_stream
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            shared = []                       # [(representative layer, int8 context)]
+            shared = {}                       # quantizer group -> int8 context (tokens 1..)
+
+            def ctx_int8(layer):
+                g = gid[id(layer)]
+                if g not in shared:
+                    from mixdq_amd.nn.Linear import quant_op
+                    shared[g] = quant_op(context[:, 1:, :], layer.act_scales_inv,
+                                         layer.act_zero_points)
+                return shared[g]
+
             for blk in blocks:
-                outs = []
-                pack = self._kv_pack(blk, context)
+                lk, lv = blk.attn2.to_k, blk.attn2.to_v
+                B, T = context.shape[0], context.shape[1]
+                pack = None
+                if bos_w8a8(lk) and bos_w8a8(lv) and gid[id(lk)] == gid[id(lv)]:
+                    pack = self._kv_pack(blk, context)
                 if pack is not None:        # to_k | to_v as ONE GEMM against [2C, K] (cf. _qkv_fused)
                     from mixdq_amd.op.qlinear import qlinear
-                    lk = blk.attn2.to_k
-                    x_int = self._shared_context_int8(lk, context, shared)
-                    B, T = context.shape[0], context.shape[1]
-                    key = (B, T, context.device, lk.bos_pre_computed._version,
-                           blk.attn2.to_v.bos_pre_computed._version)
+                    x_int = ctx_int8(lk)
+                    # persistent [B, T, 2C] buffer, BOS row written once (it is a constant)
+                    key = (B, T, context.device, lk.bos_pre_computed.data_ptr(),
+                           lk.bos_pre_computed._version, lv.bos_pre_computed.data_ptr(),
+                           lv.bos_pre_computed._version)
                     if pack.get("key") != key:
                         o = torch.empty((B, T, 2 * pack["C"]), dtype=torch.float16,
                                         device=context.device)
-                        o[:, :1, :] = torch.cat([lk.bos_pre_computed,
-                                                 blk.attn2.to_v.bos_pre_computed], dim=-1)
+                        o[:, :1, :] = torch.cat([lk.bos_pre_computed, lv.bos_pre_computed], dim=-1)
                         pack["key"], pack["out"] = key, o
                     o = pack["out"]
                     qlinear(x_int, pack["w"], pack["wscale"], lk.act_scales, lk.act_zero_points,
@@ -599,80 +684,46 @@ class SDXLUNet(nn.Module):
                     ready.record(side)
                     blk._kv = (o[..., :pack["C"]], o[..., pack["C"]:], ready)
                     continue
-                for layer in (blk.attn2.to_k, blk.attn2.to_v):
-                    bos_w8a8 = (getattr(layer, "valid_for_acceleration", False)
-                                and getattr(layer, "bos", False)
-                                and context.dtype == torch.float16 and context.shape[1] > 1)
-                    if not bos_w8a8:
+                outs = []
+                for layer in (lk, lv):
+                    if not bos_w8a8(layer):
                         outs.append(layer(context))
                         continue
-                    x_int = self._shared_context_int8(layer, context, shared)
-                    # persistent K / V buffer per layer, BOS row written once (it is a constant):
-                    # 140 copy kernels fewer per step; consumed by this forward's attention only
-                    key = (context.shape[0], context.shape[1], context.device,
+                    # persistent K / V buffer per layer, BOS row written once: 140 copy kernels
+                    # fewer per step; consumed by this forward's attention only
+                    key = (B, T, context.device, layer.bos_pre_computed.data_ptr(),
                            layer.bos_pre_computed._version)
                     buf = layer.__dict__.get("_kv_buf")
                     if buf is None or buf[0] != key:
-                        o = torch.empty((context.shape[0], context.shape[1], layer.out_features),
-                                        dtype=torch.float16, device=context.device)
+                        o = torch.empty((B, T, layer.out_features), dtype=torch.float16,
+                                        device=context.device)
                         o[:, :1, :] = layer.bos_pre_computed
                         buf = layer.__dict__["_kv_buf"] = (key, o)
-                    outs.append(layer.forward_bos_quantized(x_int, context.shape[0],
-                                                            context.shape[1], out=buf[1]))
+                    outs.append(layer.forward_bos_quantized(ctx_int8(layer), B, T, out=buf[1]))
                 ready = torch.cuda.Event()
                 ready.record(side)
                 blk._kv = (outs[0], outs[1], ready)
         context.record_stream(side)
 
     @staticmethod
-    def _shared_context_int8(layer, context, shared):
-        """INT8 copy of context tokens 1.. for `layer`, shared with every layer already seen in this
-        forward whose activation quantizer is identical (`shared`: [(representative, int8)])."""
-        key = getattr(layer, "_ctx_group", None)
-        if key is not None and key < len(shared):
-            return shared[key][1]
-        for gi, (rep, xi) in enumerate(shared):
-            if _same_qparams(rep, layer):
-                layer._ctx_group = gi
-                return xi
-        from mixdq_amd.nn.Linear import quant_op
-        x_int = quant_op(context[:, 1:, :], layer.act_scales_inv, layer.act_zero_points)
-        layer._ctx_group = len(shared)
-        shared.append((layer, x_int))
-        return x_int
-
-    @staticmethod
-    def _kv_pack(blk, context):
+    def _kv_pack(blk, context=None):
         """Cross-attention to_k / to_v read the same tokens; when both are W8A8 BOS layers with the
         same activation quantizer and no bias, one GEMM against the row-concatenated weights
-        replaces two (per-channel scale / bias0 concatenate: every output element is computed
-        exactly as before).  The concatenated weight is the storage; the layers keep views."""
-        cached = blk.__dict__.get("_kvpack")
-        if cached is not None:
-            return cached or None
+        replaces two (`_pack_rows`: every output element is computed exactly as before)."""
         lk, lv = blk.attn2.to_k, blk.attn2.to_v
-        ok = (context.dtype == torch.float16 and context.shape[1] > 1
-              and all(getattr(m, "valid_for_acceleration", False) and getattr(m, "bos", False)
-                      and m.bias is None for m in (lk, lv))
-              and bool(lk.w_packed4) == bool(lv.w_packed4)
-              and lk.out_features == lv.out_features and _same_qparams(lk, lv))
-        if not ok:
-            blk.__dict__["_kvpack"] = False
+        layers = [lk, lv]
+        if not (all(getattr(m, "valid_for_acceleration", False) and getattr(m, "bos", False)
+                    and m.bias is None for m in layers)
+                and bool(lk.w_packed4) == bool(lv.w_packed4)
+                and lk.out_features == lv.out_features):
             return None
-        w4 = bool(lk.w_packed4)
-        attr = "weight_int4" if w4 else "weight_int"
-        with torch.no_grad():
-            w = torch.cat([getattr(lk, attr), getattr(lv, attr)], dim=0).contiguous()
-            C = lk.out_features
-            setattr(lk, attr, w[:C])
-            setattr(lv, attr, w[C:])
-            pack = dict(w=w, C=C, w4=w4,
-                        wscale=torch.cat([lk.weight_scales, lv.weight_scales]),
-                        wsum=torch.cat([lk.weight_sum_by_input_channels,
-                                        lv.weight_sum_by_input_channels]),
-                        scale=torch.cat([lk.scale, lv.scale]).contiguous(),
-                        bias0=torch.cat([lk.bias0, lv.bias0]).contiguous())
-        blk.__dict__["_kvpack"] = pack
+        if context is not None and not (context.dtype == torch.float16 and context.shape[1] > 1):
+            return None
+        if len(set(_quantizer_groups(_memo(blk), "kv", layers))) != 1:
+            return None
+        pack = blk.__dict__.get("_kvpack")
+        if not _pack_valid(pack, layers):
+            pack = blk.__dict__["_kvpack"] = _pack_rows(layers)
         return pack
 
     def _project_temb_ahead(self, emb):
@@ -685,36 +736,48 @@ class SDXLUNet(nn.Module):
             return
         if getattr(self, "_kv_stream", None) is None:
             self._kv_stream = torch.cuda.Stream(device=emb.device)
+        acc = [r.time_emb_proj for r in resnets if _accel(r.time_emb_proj)]
+        gid = dict(zip(map(id, acc), _quantizer_groups(_memo(self), "temb", acc)))
         main = torch.cuda.current_stream()
         side = self._kv_stream
         side.wait_stream(main)
         with torch.cuda.stream(side):
             s = F.silu(emb)
-            shared = []
+            shared = {}
             for res in resnets:
                 layer = res.time_emb_proj
                 if _accel(layer) and _fusable_f16(s):
-                    x_int = None
-                    key = getattr(layer, "_t_group", None)
-                    if key is not None and key < len(shared):
-                        x_int = shared[key][1]
-                    else:
-                        for gi, (rep, xi) in enumerate(shared):
-                            if _same_qparams(rep, layer):
-                                layer._t_group, x_int = gi, xi
-                                break
-                    if x_int is None:
+                    g = gid[id(layer)]
+                    if g not in shared:
                         from mixdq_amd.nn.Linear import quant_op
-                        x_int = quant_op(s, *_qp(layer))
-                        layer._t_group = len(shared)
-                        shared.append((layer, x_int))
-                    t = layer.forward_quantized(x_int)
+                        shared[g] = quant_op(s, *_qp(layer))
+                    t = layer.forward_quantized(shared[g])
                 else:
                     t = layer(s)
                 ready = torch.cuda.Event()
                 ready.record(side)
                 res._t = (t, ready)
         emb.record_stream(side)
+
+    def refresh_derived_(self):
+        """After buffers were written IN PLACE (load_state_dict, shard.broadcast_module_state):
+        re-derive, at their existing addresses, the cached tensors that are computed from buffers
+        rather than views of them -- the conv border tables and the BOS row of the persistent
+        K / V buffers -- so that captured graphs see the new values too.  (Packed GEMM operands
+        are views and need nothing.)"""
+        with torch.no_grad():
+            for m in self.modules():
+                if m is not self and hasattr(m, "refresh_derived_"):
+                    m.refresh_derived_()
+                buf = m.__dict__.get("_kv_buf")
+                if buf is not None and torch.is_tensor(getattr(m, "bos_pre_computed", None)):
+                    buf[1][:, :1, :] = m.bos_pre_computed
+                pack = m.__dict__.get("_kvpack")
+                if pack is not None and pack.get("out") is not None:
+                    lk, lv = pack["layers"]
+                    pack["out"][:, :1, :] = torch.cat([lk.bos_pre_computed, lv.bos_pre_computed],
+                                                      dim=-1)
+        return self
 
     def set_fused(self, enabled: bool = True):
         """Switch the producer fusions on or off for the whole graph (see the top of this file)."""

@@ -16,6 +16,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+# Collection order of the GPU suite: the bit-exact operator parity tests first (seconds, the heart
+# of the path: a1-a4), then the module layer, the fused producers, attention, and the UNet-level
+# tolerance tests last -- under the driver's `-x` a failure late in the list cannot hide the
+# operator evidence.  Within a file the definition order is kept.
+_FILE_ORDER = ["test_ops_gpu.py", "test_large_gpu.py", "test_modules_gpu.py", "test_fused_gpu.py",
+               "test_f16_gpu.py", "test_attention_gpu.py", "test_unet_gpu.py"]
+
+
+def pytest_collection_modifyitems(config, items):
+    def rank(item):
+        name = os.path.basename(str(item.fspath))
+        return _FILE_ORDER.index(name) if name in _FILE_ORDER else len(_FILE_ORDER)
+    items.sort(key=rank)          # stable: keeps the order inside each file
+
+
 @pytest.fixture(scope="session")
 def ops_golden():
     with open(os.path.join(GOLDEN, "ops.json")) as f:

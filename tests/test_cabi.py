@@ -40,6 +40,10 @@ def test_library_loads_and_exports_every_declared_symbol():
     lib.mixdq_status_string.restype = ctypes.c_char_p
     assert lib.mixdq_status_string(0) == b"ok"
     assert b"alignment not to 4" in lib.mixdq_status_string(2)
+    # one message per cause of "unsupported" (dilation is the only one the reference has)
+    msgs = [lib.mixdq_status_string(c) for c in (3, 5, 6, 7, 8, 9)]
+    assert b"dilation must be 1" in msgs[0] and len(set(msgs)) == 6
+    assert b"K % 32" in msgs[1] and b"N % 64" in msgs[2] and b"padding" in msgs[3]
     lib.mixdq_qconv2d_workspace_bytes.restype = ctypes.c_size_t
     assert lib.mixdq_qconv2d_workspace_bytes(1280, 3, 3, 1) == 81 * 1280 * 4
     assert lib.mixdq_qconv2d_workspace_bytes(1280, 1, 1, 0) == 0

@@ -71,3 +71,12 @@ def test_shard_range_is_a_partition():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_named_multi_gpu_config_shards_batch_64_evenly():
+    """BASELINE.json configs[3]: global batch 64 over 1 / 2 / 4 / 8 ranks = 64 / 32 / 16 / 8 per GPU
+    (bench.py --baseline-config 3: strong scaling)."""
+    from mixdq_amd.shard import shard_range
+    for world in (1, 2, 4, 8):
+        sizes = [hi - lo for lo, hi in (shard_range(64, r, world) for r in range(world))]
+        assert sizes == [64 // world] * world

@@ -415,3 +415,103 @@ def test_w4_forward_tracks_path_a_4bit(modules_golden, fakequant_golden, oracle_
     # vs the reference QuantLayer's own output (fp32 scales; the fp16 rounding of a 4-bit step can
     # move a weight by one LSB = delta, hence the wider bound on isolated elements)
     assert (y - ref).abs().mean().item() <= 2e-3 * ref.abs().max().item() + 1e-3
+
+
+def test_w2_layers_clamp_to_their_own_range_in_4bit_storage(modules_golden):
+    """weight_4.00.yaml has 209 two-bit layers: Path A clamps them to [-2, 1] with the 2-bit delta
+    (base_quantizer.py:119-129); the packed-W4 storage must hold exactly those integers."""
+    from mixdq_amd.nn import QuantizedConv2d, QuantizedLinear
+    from mixdq_amd.nn.utils import unpack_w4
+    for c in (MODULE_CASES[0], next(c for c in MODULE_CASES if c["kind"] == "conv"
+                                    and c["cin"] % 32 == 0 and not c.get("split"))):
+        cls = QuantizedLinear if c["kind"] == "linear" else QuantizedConv2d
+        ck = module_ckpt(c, modules_golden)
+        fm = prepared(c, modules_golden, w_bit=2)
+        fm.w4_kernel = True
+        qm = cls.from_float(fm, ckpt=ck)
+        assert qm.valid_for_acceleration and qm.w_packed4
+        w = make_float_module(c).half().weight.detach().float()
+        d2 = ck[c["name"] + ".weight_quantizer"]["delta_list"][0].float()
+        d2 = d2.reshape(-1, *([1] * (w.dim() - 1)))
+        want = torch.clamp(torch.round(w / d2), -2, 1).to(torch.int8)
+        got = qm._weight_values()
+        assert torch.equal(got, want)
+        assert int(got.min()) >= -2 and int(got.max()) <= 1
+
+
+# ----------------------------------------------------------------------------- fused-graph caches
+def test_packed_qkv_is_storage_not_a_copy_and_is_retaken_after_a_module_swap():
+    """(1) nothing negative is cached -- a fused FP16 forward before quantize_unet must
+    not pin the unfused launches; (2) the packed operands are the storage (layers keep views), so
+    load_state_dict / broadcast reach the packed GEMM; (3) swapping a layer invalidates the pack."""
+    import mixdq_amd.unet as U
+    from mixdq_amd.nn import QuantizedLinear
+    unet, inp, _, _ = tiny_quantized()
+    blk = next(m for m in unet.modules() if isinstance(m, U.BasicTransformerBlock))
+    pack = blk._qkv_fused()
+    assert pack is not None and blk._qkv_fused() is pack
+    a = blk.attn1
+    C = a.to_q.out_features
+    for i, m in enumerate((a.to_q, a.to_k, a.to_v)):
+        for key, name in pack["names"]:
+            t = getattr(m, name)
+            assert t.data_ptr() == pack[key][i * C:(i + 1) * C].data_ptr()
+            assert name in dict(m.named_buffers())          # still a registered buffer
+    # (2) in-place update of a layer's buffer is seen through the pack
+    with torch.no_grad():
+        a.to_k.scale.mul_(2.0)
+        sd = unet.state_dict()
+        sd = {k: (v * 0 + 3 if k.endswith("attn1.to_v.bias0") and "down_blocks.1.attentions.0."
+                  "transformer_blocks.0." in k else v) for k, v in sd.items()}
+        unet.load_state_dict(sd)
+    assert torch.equal(pack["scale"][C:2 * C], a.to_k.scale)
+    assert bool((pack["bias0"][2 * C:] == 3).all())
+    assert blk._qkv_fused() is pack
+    # (3) a swapped layer (new module object, new tensors) => a new pack
+    fresh = QuantizedLinear.__new__(QuantizedLinear)
+    nn.Module.__init__(fresh)
+    fresh.__dict__.update({k: v for k, v in a.to_q.__dict__.items() if not k.startswith("_")})
+    for n, b in a.to_q.named_buffers():
+        fresh.register_buffer(n, b.clone())
+    fresh.bias = None
+    a.to_q = fresh
+    pack2 = blk._qkv_fused()
+    assert pack2 is not None and pack2 is not pack
+    assert a.to_q.scale.data_ptr() == pack2["scale"].data_ptr()
+    # different activation quantizer => not packable, and that answer is not sticky
+    with torch.no_grad():
+        a.to_v.act_zero_points.add_(1.0)
+    assert blk._qkv_fused() is None
+    with torch.no_grad():
+        a.to_v.act_zero_points.sub_(1.0)
+    assert blk._qkv_fused() is not None
+
+
+def test_fused_flags_on_plain_float_network_do_not_stick():
+    import mixdq_amd.unet as U
+    unet = tiny_unet()
+    unet.set_fused(True)
+    blk = next(m for m in unet.modules() if isinstance(m, U.BasicTransformerBlock))
+    assert blk._qkv_fused() is None and U.SDXLUNet._kv_pack(blk) is None   # nn.Linear: no pack
+    unet.set_fused(False)
+    unet2, _, _, _ = tiny_quantized()
+    blk2 = next(m for m in unet2.modules() if isinstance(m, U.BasicTransformerBlock))
+    assert blk2._qkv_fused() is not None and U.SDXLUNet._kv_pack(blk2) is not None
+
+
+def test_quantizer_groups_memo_follows_identity_and_version():
+    import mixdq_amd.unet as U
+
+    class L:
+        def __init__(self, s, z):
+            self.act_scales_inv, self.act_zero_points = torch.tensor([s]), torch.tensor([z])
+    a, b, c = L(2.0, 1.0), L(2.0, 1.0), L(2.0, 3.0)
+    h = {}
+    assert U._quantizer_groups(h, "k", [a, b, c]) == [0, 0, 1]
+    first = h["k"][2]
+    assert U._quantizer_groups(h, "k", [a, b, c]) is first        # memo hit
+    c.act_zero_points.fill_(1.0)                                    # in-place update
+    assert U._quantizer_groups(h, "k", [a, b, c]) == [0, 0, 0]
+    b.act_scales_inv = torch.tensor([4.0])                          # replaced tensor
+    assert U._quantizer_groups(h, "k", [a, b, c]) == [0, 1, 0]
+    assert U._quantizer_groups(h, "k", []) == []

@@ -14,6 +14,17 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+@pytest.fixture(autouse=True, params=["A", "B"], ids=["fma", "mul_add"])
+def epilogue_variant(request, monkeypatch):
+    """Every test of this file runs under both roundings of the multiply-adds (SURVEY.md Appendix
+    B): A = one FMA (what nvcc -fmad=true makes of the reference's mul + add; the default), B =
+    multiply, round, add (MIXDQ_FLAG_UNFUSED; `MIXDQ_EPILOGUE_VARIANT=B`).  Which of the two the
+    reference's CUDA binary used cannot be observed here, so both stay pinned to the oracle."""
+    import mixdq_amd._C as C_
+    monkeypatch.setattr(C_, "FLAGS", 1 if request.param == "B" else 0)
+    return request.param
+
+
 def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
@@ -56,9 +67,9 @@ def test_quantize_activation_ranges(C, oracle, ops_golden, i):
     case = next(c for c in ops_golden["quantize"] if c["name"] == f"q_act{i}")
     x = dd.normal_f16(case["seed"], tuple(case["shape"]), std=case["std"])
     q = C.quantize_per_tensor_to_int8(t(x), scal(case["scale_inv"]), scal(case["zp"]))
-    want = oracle.quantize(x, case["scale_inv"], case["zp"], 0)
+    want = oracle.quantize(x, case["scale_inv"], case["zp"], C.FLAGS & 1)
     assert_bits_equal(q.cpu().numpy(), want, case["name"])
-    assert sha(q.cpu().numpy()) == case["sha_A"]
+    assert sha(q.cpu().numpy()) == case["sha_B" if C.FLAGS & 1 and "sha_B" in case else "sha_A"]
 
 
 @pytest.mark.parametrize("name", ["q_edge_pow2", "q_edge_pow2_zp", "q_edge_half"])
