@@ -18,6 +18,7 @@ Weights are synthetic (no network, no checkpoints): randn * 0.02, seeded per lay
 from __future__ import annotations
 
 import math
+import weakref
 from collections import OrderedDict
 
 import torch
@@ -96,7 +97,8 @@ def _pack_rows(layers):
     separate launches do.  The concatenated tensors are the storage; the layers keep views."""
     w4 = bool(layers[0].w_packed4)
     names = (("w", "weight_int4" if w4 else "weight_int"),) + _PACK_VECS
-    pack = dict(w4=w4, C=layers[0].out_features, layers=tuple(layers), names=names)
+    pack = dict(w4=w4, C=layers[0].out_features, layers=tuple(weakref.ref(m) for m in layers),
+                names=names)
     with torch.no_grad():
         for key, name in names:
             cat = torch.cat([getattr(m, name) for m in layers], dim=0).contiguous()
@@ -112,7 +114,7 @@ def _pack_rows(layers):
 def _pack_valid(pack, layers) -> bool:
     """The layers' buffers still alias the pack (false after a module swap, `.to()`, deepcopy...)."""
     if pack is None or len(pack["layers"]) != len(layers) or any(
-            a is not b for a, b in zip(pack["layers"], layers)):
+            a() is not b for a, b in zip(pack["layers"], layers)):
         return False
     for key, name in pack["names"]:
         cat, off = pack[key], 0
@@ -170,7 +172,7 @@ def _ln_feed(norm: nn.LayerNorm, x, consumers):
     ids = _quantizer_groups(_memo(norm), "ln", acc)
     plan = norm.__dict__.get("_mixdq_plan")
     if (plan is None or len(plan[0]) != len(consumers)
-            or any(a is not b for a, b in zip(plan[0], consumers)) or plan[3] is not ids):
+            or any(a() is not b for a, b in zip(plan[0], consumers)) or plan[3] is not ids):
         groups, slot, it = {}, [], iter(ids)   # distinct quantizers among the accelerated consumers
         for c in consumers:
             if not _accel(c):
@@ -179,12 +181,13 @@ def _ln_feed(norm: nn.LayerNorm, x, consumers):
             gi = next(it)
             groups.setdefault(gi, c)
             slot.append(gi)
-        plan = norm.__dict__["_mixdq_plan"] = (tuple(consumers), [groups[g] for g in sorted(groups)],
-                                               slot, ids)
+        # weak references: a plan must not keep swapped-out float layers (and their FP16
+        # weights) alive until the next forward
+        plan = norm.__dict__["_mixdq_plan"] = (tuple(weakref.ref(c) for c in consumers),
+                                               [_qp(groups[g]) for g in sorted(groups)], slot, ids)
     _, groups, slot, _ = plan
     want_f16 = any(s < 0 for s in slot)
-    outs, h = _C.layernorm_quantize(x, norm.weight, norm.bias, norm.eps, [_qp(g) for g in groups],
-                                    want_f16=want_f16)
+    outs, h = _C.layernorm_quantize(x, norm.weight, norm.bias, norm.eps, groups, want_f16=want_f16)
     return [((outs[s], True) if s >= 0 else (h, False)) for s in slot]
 
 
@@ -774,7 +777,9 @@ class SDXLUNet(nn.Module):
                     buf[1][:, :1, :] = m.bos_pre_computed
                 pack = m.__dict__.get("_kvpack")
                 if pack is not None and pack.get("out") is not None:
-                    lk, lv = pack["layers"]
+                    lk, lv = (r() for r in pack["layers"])
+                    if lk is None or lv is None:
+                        continue
                     pack["out"][:, :1, :] = torch.cat([lk.bos_pre_computed, lv.bos_pre_computed],
                                                       dim=-1)
         return self
