@@ -332,6 +332,9 @@ def main():
     qmods = [m for m in unet.modules() if isinstance(m, (QuantizedLinear, QuantizedConv2d))]
     n_accel = sum(m.valid_for_acceleration for m in qmods)
     n_w4 = sum(m.valid_for_acceleration and getattr(m, "w_packed4", False) for m in qmods)
+    with torch.no_grad():
+        run_once()          # one eager forward: packed q|k|v / k|v operands, conv border tables and
+    torch.cuda.synchronize(device)   # persistent K/V buffers are static data, built before the meter
     import gc
     gc.collect()
     torch.cuda.empty_cache()

@@ -249,6 +249,24 @@ int mixdq_attention_f16(const void* q_f16, const void* k_f16, const void* v_f16,
                         float softmax_scale, const float* out_scale_inv_or_null,
                         const float* out_zero_point_or_null, int flags, mixdq_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * FP16 layers.  Replaces the reference's FP fallback for layers without an activation quantizer
+ * or with unsupported weight bits -- F.linear / F.conv2d on the FP16 weight (nn/Linear.py:155-156,
+ * nn/Conv2d.py:306-309), i.e. cuBLAS / cuDNN there -- with the same LDS-DMA / MFMA kernel family
+ * on FP16 operands (v_mfma_f32_32x32x16_f16, FP32 accumulation), so the captured step contains no
+ * vendor-library kernel.  Floating point: a tolerance oracle (FP32 reference), not bit parity.
+ *   D[m,n] = f16( sum_k f32(A[m,k]) * f32(W[n,k]) + f32(bias[n]) )  [+ residual, as above]
+ * A [M,K], W [N,K], D [M,N] row-major fp16; conv: X [N,H,W,C], Wt [K,R,S,C], D [N,P,Q,K].
+ * K % 8 == 0 (conv: C % 8 == 0) and N % 4 == 0 run on MFMA tiles, anything else (conv_in: C = 4)
+ * on a one-output-per-thread kernel.  flags: bits 8..15 force a tile configuration. */
+int mixdq_linear_f16(const void* A_f16, const void* W_f16, const void* bias_f16_or_null,
+                     void* D_f16, int64_t M, int N, int K, const void* residual_f16_or_null,
+                     int64_t residual_row_div, int flags, mixdq_stream_t stream);
+int mixdq_conv2d_f16(const void* X_f16, const void* Wt_f16, const void* bias_f16_or_null,
+                     void* D_f16, int N, int H, int W, int C, int K, int R, int S, int stride,
+                     int pad, const void* residual_f16_or_null, int64_t residual_row_div,
+                     int flags, mixdq_stream_t stream);
+
 /* Which kernel instantiation mixdq_qlinear_w8a8 / mixdq_qconv2d_w8a8 will launch for a problem of
  * M rows x N output channels (k_align = K for Linear, C for Conv2d; k_total = K or R*S*C): the block tile BM x BN x BK
  * and LDS stage count of `igemm_kernel<BM,BN,BK,STAGES,CONV>`, or zeros for the small-alignment

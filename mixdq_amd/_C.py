@@ -83,15 +83,20 @@ def igemm_select(M: int, N: int, k_align: int, k_total: int = 0):
 
 # Kernel configurations of the INT8 GEMM / conv family (csrc/igemm.hip MIXDQ_IGEMM_CONFIGS):
 # id -> (BM, BN, BK, STAGES).  `_cfg=id` forces one (tuning and tests); 0 = automatic.
-IGEMM_CONFIGS = {1: (64, 64, 64, 2), 2: (64, 128, 64, 2), 3: (128, 128, 64, 2),
-                 4: (64, 64, 128, 3), 5: (64, 64, 128, 4), 6: (64, 128, 128, 3),
-                 7: (128, 128, 128, 3), 8: (128, 128, 64, 4), 9: (64, 64, 64, 4),
-                 10: (128, 64, 128, 3), 11: (64, 128, 128, 4), 12: (128, 128, 128, 4),
-                 13: (256, 128, 64, 3), 14: (256, 256, 64, 3), 15: (128, 256, 64, 3),
-                 16: (256, 128, 64, 2), 17: (256, 256, 64, 2), 18: (256, 128, 128, 2),
-                 19: (128, 128, 64, 3), 20: (256, 256, 128, 2), 21: (64, 64, 128, 6),
-                 22: (64, 64, 128, 5), 23: (64, 64, 256, 2), 24: (64, 128, 256, 2),
-                 25: (128, 320, 128, 2), 35: (128, 128, 64, 3), 37: (64, 64, 128, 3), 41: (64, 128, 128, 3)}
+IGEMM_CONFIGS = {1: (64, 64, 64, 2), 2: (64, 128, 64, 2), 3: (128, 128, 64, 2), 4: (64, 64, 128, 3),
+                 6: (64, 128, 128, 3), 7: (128, 128, 128, 3), 13: (256, 128, 64, 3),
+                 14: (256, 256, 64, 3), 15: (128, 256, 64, 3), 18: (256, 128, 128, 2),
+                 20: (256, 256, 128, 2), 25: (128, 320, 128, 2), 35: (128, 128, 64, 3),
+                 37: (64, 64, 128, 3), 41: (64, 128, 128, 3),
+                 # 16x16x64-MFMA tiles (exactly one workgroup per CU on the UNet's M = 1024 / 4096
+                 # layers) and the 4-stage 128x320 tile
+                 42: (64, 80, 128, 3), 43: (64, 240, 128, 3), 44: (128, 80, 128, 3),
+                 45: (64, 80, 128, 4), 46: (128, 320, 64, 4), 47: (64, 80, 128, 3),
+                 48: (64, 160, 128, 3),
+                 # deep pipelines (one workgroup per CU: LDS is free for K-tiles in flight)
+                 49: (64, 80, 128, 8), 50: (64, 128, 128, 6), 51: (64, 64, 128, 8),
+                 52: (64, 240, 128, 4), 53: (128, 80, 128, 6), 54: (128, 320, 64, 5),
+                 55: (128, 128, 64, 6), 56: (64, 80, 128, 6)}
 
 FLAG_W4 = 2   # MIXDQ_FLAG_W4: the weight tensor holds packed signed 4-bit values
 
@@ -452,6 +457,82 @@ def qlinear_fp_reference(input, weight, bias=None):
         code = _lib.mixdq_gemm_f16(a.data_ptr(), b.data_ptr(), D.data_ptr(), M, N, K, _stream())
     _status(code, "qlinear_fp_reference")
     return D
+
+
+# ---------------------------------------------------------------------------------------------
+# FP16 layers (include/mixdq_hip.h: mixdq_linear_f16 / mixdq_conv2d_f16): the reference's FP fallback
+# (F.linear / F.conv2d on the FP16 weight) on this repo's own MFMA kernels.
+# ---------------------------------------------------------------------------------------------
+_lib.mixdq_linear_f16.argtypes = [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp]
+_lib.mixdq_linear_f16.restype = _i32
+_lib.mixdq_conv2d_f16.argtypes = [_vp] * 4 + [_i32] * 9 + [_vp, _i64, _i32, _vp]
+_lib.mixdq_conv2d_f16.restype = _i32
+
+
+def linear_f16(input, weight, bias=None, *, _residual=None, _cfg=0):
+    """F.linear(input, weight, bias) for fp16 GPU tensors: input [..., K], weight [N, K] -> [..., N],
+    FP32 accumulation, bias added in FP32, one rounding to fp16; `_residual` (fp16, the output's
+    shape) is added after that rounding as a following torch half add would."""
+    _check(input.is_cuda and input.dtype == torch.float16, "input should be an fp16 GPU tensor")
+    _check(weight.dtype == torch.float16 and weight.device == input.device and weight.dim() == 2,
+           "weight should be an fp16 [N, K] tensor on the input's device")
+    N, K = weight.shape
+    _check(input.size(-1) == K, "The last dimension of input and weight should match")
+    if bias is not None:
+        _check(bias.dtype == torch.float16 and bias.numel() == N, "bias should be fp16 [N]")
+    a, w = input.contiguous(), weight.contiguous()
+    M = a.numel() // K if K else 0
+    D = torch.empty(list(input.shape[:-1]) + [N], dtype=torch.float16, device=a.device)
+    if _residual is not None:
+        _check(_residual.dtype == torch.float16 and _residual.is_contiguous()
+               and _residual.numel() == M * N, "residual should be contiguous fp16 [M, N]")
+    bs = None if bias is None else bias.contiguous()
+    with torch.cuda.device(a.device):
+        code = _lib.mixdq_linear_f16(a.data_ptr(), w.data_ptr(), _ptr(bs), D.data_ptr(), M, N, K,
+                                     _ptr(_residual), 1, int(_cfg) << 8, _stream())
+    _status(code, "linear_f16")
+    return D
+
+
+def conv2d_f16(input, weight, bias=None, stride=1, padding=0, *, _residual=None,
+               _residual_per_image=False, _cfg=0):
+    """F.conv2d(input, weight, bias, stride, padding) for fp16 GPU tensors (square stride / padding,
+    dilation 1, groups 1): input [N, C, H, W] and weight [K, C, R, S] are read in channels-last
+    memory (converted if they are not), the result is channels-last [N, K, P, Q]."""
+    _check(input.is_cuda and input.dtype == torch.float16 and input.dim() == 4,
+           "input should be a 4-D fp16 GPU tensor")
+    _check(weight.dtype == torch.float16 and weight.device == input.device and weight.dim() == 4,
+           "weight should be a 4-D fp16 tensor on the input's device")
+    stride, padding = int(stride), int(padding)
+    N, C, H, W, K, R, S, P, Q = _conv_geometry(input, weight, stride, padding, 1)
+    _check(weight.size(1) == C, "input and weight channel counts should match")
+    if bias is not None:
+        _check(bias.dtype == torch.float16 and bias.numel() == K, "bias should be fp16 [K]")
+    x = input.contiguous(memory_format=torch.channels_last)
+    w = weight.contiguous(memory_format=torch.channels_last)
+    D = torch.empty((N, K, P, Q), dtype=torch.float16, device=x.device,
+                    memory_format=torch.channels_last)
+    res_ptr, res_div = None, 1
+    if _residual is not None:
+        _check(_residual.dtype == torch.float16, "residual should be fp16")
+        if _residual_per_image:
+            _check(_residual.is_contiguous() and _residual.numel() == N * K,
+                   "per-image residual should be contiguous [N, K]")
+            res_div = P * Q
+        else:
+            _check(tuple(_residual.shape) == (N, K, P, Q) and _residual.is_contiguous(
+                memory_format=torch.channels_last), "residual should be channels-last [N,K,P,Q]")
+        res_ptr = _residual.data_ptr()
+    bs = None if bias is None else bias.contiguous()
+    with torch.cuda.device(x.device):
+        code = _lib.mixdq_conv2d_f16(x.data_ptr(), w.data_ptr(), _ptr(bs), D.data_ptr(), N, H, W, C,
+                                     K, R, S, stride, padding, res_ptr, res_div, int(_cfg) << 8,
+                                     _stream())
+    _status(code, "conv2d_f16")
+    return D
+
+
+F16_CONFIGS = (4, 13, 20, 25, 35, 37, 41, 44, 45, 56)   # csrc/igemm.hip MIXDQ_F16_CONFIGS
 
 
 # ---------------------------------------------------------------------------------------------

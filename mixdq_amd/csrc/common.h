@@ -11,6 +11,8 @@ namespace mixdq {
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+typedef _Float16 v8h __attribute__((ext_vector_type(8)));
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef _Float16 v2h __attribute__((ext_vector_type(2)));
 typedef _Float16 v4h __attribute__((ext_vector_type(4)));

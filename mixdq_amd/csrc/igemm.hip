@@ -21,6 +21,11 @@
 //     (R*R*S*S) x K table of tap-rectangle sums indexed by the pixel's border class, instead of
 //     materialising an [N,P,Q,K] f32 tensor per call as the reference does.
 //   * blockIdx -> tile map is XCD-aware (blocks that share a weight panel share an L2).
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+#include <vector>
+
 #include "common.h"
 #include "../../include/mixdq_math.h"
 
@@ -105,25 +110,45 @@ __device__ __forceinline__ uint32_t add_f16x2(uint32_t a, uint32_t b) {
 // k-steps between them; group 1's accumulators are added to group 0's through LDS before the
 // epilogue (int32: exact, order-free).  Twice the waves for the same tile halves the per-K-tile
 // instruction chain each wave runs -- the thing that bounds the small GEMMs.
+// MT: the MFMA shape -- 32 = v_mfma_i32_32x32x32_i8, 16 = v_mfma_i32_16x16x64_i8 (same int8 rate; wave
+// tiles in multiples of 16, so block tiles such as 64x80 / 64x240 / 128x80 that put EXACTLY one
+// workgroup on every CU for the UNet's N = 1280 / 3840 / 640 layers at M = 1024 / 4096).  These
+// launches are bound by what one CU can pull from L2 into LDS (~70-100 GB/s), i.e. by
+// (BM + BN) * K bytes per workgroup and the number of rounds; an exact-fit tile minimises both.
+//
+// F16: the same kernel on FP16 operands with FP32 accumulation (v_mfma_f32_32x32x16_f16 /
+// 16x16x32): a k-step is the same 32 / 64 BYTES per row and a lane's fragment the same 16 bytes,
+// so staging, swizzle and fragment reads are unchanged -- all sizes (K, C, BK) are in bytes.
+// Used for the layers the reference leaves in FP16 (no activation quantizer: conv_in / conv_out,
+// the act-protected ff.net.2 ..., nn/Linear.py:155-156): D = f16(acc + bias) [+ residual].
 template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool CONV, bool FAST, bool W4,
-          int KSPLIT = 1>
+          int KSPLIT = 1, int MT = 32, bool F16 = false>
 __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const IgemmParams p) {
   static_assert(!(CONV && FAST), "the fast staging path is for Linear");
+  static_assert(!(F16 && W4), "packed weights are an INT8-path format");
+  static_assert(MT == 32 || MT == 16, "MFMA shapes: 32x32x32 or 16x16x64");
   constexpr int NWAVES = WM * WN * KSPLIT, NTHREADS = 64 * NWAVES;
   constexpr int WTM = BM / WM, WTN = BN / WN;     // wave tile (WM x WN waves)
-  constexpr int TM = WTM / 32, TN = WTN / 32;     // 32x32 MFMA tiles per wave
+  constexpr int TM = WTM / MT, TN = WTN / MT;     // MT x MT MFMA tiles per wave
+  constexpr int KSTEP = MT == 32 ? 32 : 64;       // k-values one MFMA consumes
+  constexpr int CPS = KSTEP / 16;                 // 16-byte fragment chunks per k-step
+  constexpr int ACC = MT == 32 ? 16 : 4;          // accumulator registers per MFMA tile
   constexpr int WB = W4 ? 2 : 1;                  // weights per stored byte
   constexpr int A_STAGE = BM * BK, B_STAGE = BN * BK / WB, STAGE = A_STAGE + B_STAGE;
-  constexpr int A_NI = A_STAGE / 1024 / NWAVES;   // LDS-DMA instructions per wave per stage
-  constexpr int B_NI = B_STAGE / 1024 / NWAVES;
+  // LDS-DMA pieces (1 KiB = one wave-instruction).  Activations: the same count on every wave.
+  // Weights: piece q goes to wave q % NWAVES, so any piece count works (BN = 80, 240, 320; packed
+  // W4 stages of half the bytes); waves below PB % NWAVES issue one more and wait for one more.
+  constexpr int A_NI = A_STAGE / 1024 / NWAVES;
+  constexpr int PB = B_STAGE / 1024;
+  constexpr int B_LO = PB / NWAVES, B_REM = PB % NWAVES, B_NI = B_LO + (B_REM ? 1 : 0);
   constexpr int CS_STRIDE = BN * 2 + 16;          // epilogue tile row stride (bytes)
-  constexpr int NI = A_NI + B_NI;                 // ... in total: the unit of the vmcnt count
   constexpr int PRE = STAGES - 1;                 // K-tiles in flight ahead of the one computed
-  static_assert(A_NI >= 1 && B_NI >= 1 && A_NI * 1024 * NWAVES == A_STAGE &&
-                    B_NI * 1024 * NWAVES == B_STAGE,
-                "each wave must stage a whole number of 1-KiB DMA pieces per operand");
-  static_assert(TM >= 1 && TN >= 1, "wave tile must hold a 32x32 MFMA tile");
-  static_assert(STAGES >= 2 && (PRE - 1) * NI <= 63, "vmcnt is a 6-bit counter");
+  static_assert(A_NI >= 1 && A_NI * 1024 * NWAVES == A_STAGE && PB >= 1 && PB * 1024 == B_STAGE,
+                "whole 1-KiB DMA pieces; the activation pieces divide evenly over the waves");
+  static_assert(TM >= 1 && TN >= 1 && TM * MT * WM == BM && TN * MT * WN == BN,
+                "wave tiles are whole MFMA tiles");
+  static_assert(STAGES >= 2 && (PRE - 1) * (A_NI + B_NI) <= 63, "vmcnt is a 6-bit counter");
+  static_assert(MT == 32 || BK == 128, "the 16x16x64 fragment reads are laid out for 128-byte rows");
   extern __shared__ __attribute__((aligned(16))) char smem[];   // igemm_smem_bytes<...>()
 
   const int tid = threadIdx.x;
@@ -194,7 +219,9 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const Igem
   uint32_t a_off32[A_NI], b_off32[B_NI];   // FAST: constant per-lane byte offsets
 #pragma unroll
   for (int j = 0; j < B_NI; ++j) {
-    const int byte = (wid * B_NI + j) * 1024 + lane * 16;
+    // piece wid + NWAVES * j of the weight stage (the last j may fall past the stage on some
+    // waves: its state is computed on clamped rows and never used)
+    const int byte = (wid + NWAVES * j) * 1024 + lane * 16;
     int row, koff, boff;          // tile row; first k of this lane's 16-byte piece; its byte offset
     if constexpr (!W4) {
       row = byte / BK;
@@ -235,7 +262,8 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const Igem
 #pragma unroll
       for (int j = 0; j < A_NI; ++j) glds16(a_u + a_off32[j], As + (wid * A_NI + j) * 1024);
 #pragma unroll
-      for (int j = 0; j < B_NI; ++j) glds16(b_u + b_off32[j], Bs + (wid * B_NI + j) * 1024);
+      for (int j = 0; j < B_NI; ++j)
+        if (j < B_LO || wid < B_REM) glds16(b_u + b_off32[j], Bs + (wid + NWAVES * j) * 1024);
       return;
     }
 #pragma unroll
@@ -260,47 +288,92 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const Igem
     }
 #pragma unroll
     for (int j = 0; j < B_NI; ++j) {
+      if (j >= B_LO && wid >= B_REM) continue;   // wave-uniform: this wave has no such piece
       const bool ok = b_ok[j] && (kk + b_k[j] < Ktot);
       const void* src = ok ? (const void*)(b_base[j] + kk / WB) : (const void*)zero;
-      glds16(src, Bs + (wid * B_NI + j) * 1024);
+      glds16(src, Bs + (wid + NWAVES * j) * 1024);
+    }
+  };
+  // counted wait for this wave's pieces of the oldest K-tile in flight, then the block barrier
+  auto wait_tile = [&]() {
+    if constexpr (B_REM == 0) {
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((PRE - 1) * (A_NI + B_LO)) : "memory");
+    } else {
+      if (wid < B_REM)
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((PRE - 1) * (A_NI + B_NI)) : "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((PRE - 1) * (A_NI + B_LO)) : "memory");
     }
   };
 
   // ---- fragment read offsets (loop invariant; the LDS buffer base is a compile-time constant
   //      after the K loop is unrolled by STAGES, so each ds_read_b128 needs no address arithmetic)
-  const int lrow = lane & 31, lhalf = lane >> 5;
-  constexpr int KS = BK / 32 / KSPLIT;               // k-steps of a K-tile this wave computes
-  static_assert(KSPLIT == 1 || (TM * TN == 1 && !W4 && (BK / 32) % KSPLIT == 0), "k-split: 64x64 W8 tiles");
+  // lane -> (tile row, 16-byte k-chunk of the k-step): 32x32x32 has the row on lane & 31 and two
+  // chunks (lane >> 5), 16x16x64 the row on lane & 15 and four chunks (lane >> 4)
+  const int lrow = MT == 32 ? (lane & 31) : (lane & 15);
+  const int lkq = MT == 32 ? (lane >> 5) : (lane >> 4);
+  constexpr int KS = BK / KSTEP / KSPLIT;            // k-steps of a K-tile this wave computes
+  static_assert((BK / KSTEP) % KSPLIT == 0 && KS >= 1, "k-split groups take whole k-steps");
   int a_rd[TM][KS], b_rd[TN][KS];
 #pragma unroll
   for (int t = 0; t < TM; ++t) {
-    const int row = wm * WTM + t * 32 + lrow;
+    const int row = wm * WTM + t * MT + lrow;
 #pragma unroll
     for (int i = 0; i < KS; ++i) {
       const int ks = kg * KS + i;
-      a_rd[t][i] = row * BK + (((ks * 2 + lhalf) ^ swz<BK>(row)) << 4);
+      a_rd[t][i] = row * BK + (((ks * CPS + lkq) ^ swz<BK>(row)) << 4);
     }
   }
 #pragma unroll
   for (int t = 0; t < TN; ++t) {
-    const int row = wn * WTN + t * 32 + lrow;
+    const int row = wn * WTN + t * MT + lrow;
 #pragma unroll
     for (int i = 0; i < KS; ++i) {
       const int ks = kg * KS + i;
-      if constexpr (!W4)
-        b_rd[t][i] = A_STAGE + row * BK + (((ks * 2 + lhalf) ^ swz<BK>(row)) << 4);
-      else   // packed piece of (row, ks), this lane's half (8 bytes = 16 k-values)
-        b_rd[t][i] = A_STAGE + row * (KS * 16) + ((ks ^ ((row >> 3) & (KS - 1))) << 4) + lhalf * 8;
+      const int c = ks * CPS + lkq;   // this lane's 16-k chunk of the K-tile
+      if constexpr (!W4) {
+        b_rd[t][i] = A_STAGE + row * BK + ((c ^ swz<BK>(row)) << 4);
+      } else {   // packed: 16 k-values = 8 bytes, half (c & 1) of the 32-k piece c >> 1
+        constexpr int KSP = BK / 32;
+        b_rd[t][i] = A_STAGE + row * (BK / 2) + (((c >> 1) ^ ((row >> 3) & (KSP - 1))) << 4) +
+                     (c & 1) * 8;
+      }
     }
   }
 
-  v16i acc[TN][TM];
+  using acc_i = typename std::conditional<MT == 32, v16i, v4i>::type;
+  using acc_f = typename std::conditional<MT == 32, v16f, v4f>::type;
+  using acc_t = typename std::conditional<F16, acc_f, acc_i>::type;
+  auto mfma = [](const v4i& w, const v4i& x, acc_t c) -> acc_t {
+    if constexpr (F16) {
+      const v8h wh = __builtin_bit_cast(v8h, w), xh = __builtin_bit_cast(v8h, x);
+      if constexpr (MT == 32) return __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh, c, 0, 0, 0);
+      else return __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, c, 0, 0, 0);
+    } else {
+      if constexpr (MT == 32) return __builtin_amdgcn_mfma_i32_32x32x32_i8(w, x, c, 0, 0, 0);
+      else return __builtin_amdgcn_mfma_i32_16x16x64_i8(w, x, c, 0, 0, 0);
+    }
+  };
+  auto load_w = [&](const char* S0, int off) -> v4i {
+    if constexpr (!W4) {
+      return *reinterpret_cast<const v4i*>(S0 + off);
+    } else {
+      const uint2 w = *reinterpret_cast<const uint2*>(S0 + off);
+      v4i r;
+      r[0] = (int)(w.x & 0xF0F0F0F0u);
+      r[1] = (int)((w.x << 4) & 0xF0F0F0F0u);
+      r[2] = (int)(w.y & 0xF0F0F0F0u);
+      r[3] = (int)((w.y << 4) & 0xF0F0F0F0u);
+      return r;
+    }
+  };
+  acc_t acc[TN][TM];
 #pragma unroll
   for (int a = 0; a < TN; ++a)
 #pragma unroll
     for (int b = 0; b < TM; ++b)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0;
+      for (int e = 0; e < ACC; ++e) acc[a][b][e] = 0;
 
   // ---- main loop: STAGES LDS buffers, STAGES-1 K-tiles of LDS-DMA in flight.  Per K-tile ONE
   //      counted wait (never vmcnt(0)) + ONE raw s_barrier: the wait retires this wave's DMA
@@ -326,9 +399,11 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const Igem
     v4f b0 = {0.f, 0.f, 0.f, 0.f}, sc = {0.f, 0.f, 0.f, 0.f};
     uint2 bs = make_uint2(0u, 0u);
     if (n < p.N) {
-      const float* b0src = use_table ? p.table + (int64_t)full_cls * p.N : p.bias0;
-      b0 = *reinterpret_cast<const v4f*>(b0src + n);
-      sc = *reinterpret_cast<const v4f*>(p.scale + n);
+      if constexpr (!F16) {
+        const float* b0src = use_table ? p.table + (int64_t)full_cls * p.N : p.bias0;
+        b0 = *reinterpret_cast<const v4f*>(b0src + n);
+        sc = *reinterpret_cast<const v4f*>(p.scale + n);
+      }
       if (has_bias) bs = *reinterpret_cast<const uint2*>(p.bias + n);
     }
     *reinterpret_cast<v4f*>(P_B0 + tid * 4) = b0;
@@ -341,22 +416,28 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const Igem
     for (int s = 0; s < STAGES; ++s) {      // tile kt0 + s lives in buffer s (compile-time)
       const int kt = kt0 + s;
       if (kt < nk) {
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((PRE - 1) * NI) : "memory");
+        wait_tile();
         const char* S0 = smem + s * STAGE;
-        if constexpr (TM * TN == 1 && !W4) {
-          // 64x64 tiles run one wave per SIMD and are latency-bound: put every fragment read of
-          // the K-tile in flight FIRST, issue the next stage's DMAs (address arithmetic) under
-          // the LDS latency, then the MFMAs
-          v4i af[KS], bf[KS];
+        if constexpr (KS * (TM + TN) <= 16) {
+          // small wave tiles are latency-bound: put every fragment read of the K-tile in flight
+          // FIRST, issue the next stage's DMAs (address arithmetic) under the LDS latency, then
+          // the MFMAs
+          v4i af[KS][TM], bf[KS][TN];
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks) {
-            af[ks] = *reinterpret_cast<const v4i*>(S0 + a_rd[0][ks]);
-            bf[ks] = *reinterpret_cast<const v4i*>(S0 + b_rd[0][ks]);
+#pragma unroll
+            for (int t = 0; t < TM; ++t)
+              af[ks][t] = *reinterpret_cast<const v4i*>(S0 + a_rd[t][ks]);
+#pragma unroll
+            for (int t = 0; t < TN; ++t) bf[ks][t] = load_w(S0, b_rd[t][ks]);
           }
           stage((s + PRE) % STAGES, (kt + PRE) * BK);
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks)
-            acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[ks], af[ks], acc[0][0], 0, 0, 0);
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+              for (int b = 0; b < TM; ++b) acc[a][b] = mfma(bf[ks][a], af[ks][b], acc[a][b]);
           continue;
         }
         stage((s + PRE) % STAGES, (kt + PRE) * BK);
@@ -366,22 +447,11 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const Igem
 #pragma unroll
           for (int t = 0; t < TM; ++t) af[t] = *reinterpret_cast<const v4i*>(S0 + a_rd[t][ks]);
 #pragma unroll
-          for (int t = 0; t < TN; ++t) {
-            if constexpr (!W4) {
-              bf[t] = *reinterpret_cast<const v4i*>(S0 + b_rd[t][ks]);
-            } else {
-              const uint2 w = *reinterpret_cast<const uint2*>(S0 + b_rd[t][ks]);
-              bf[t][0] = (int)(w.x & 0xF0F0F0F0u);
-              bf[t][1] = (int)((w.x << 4) & 0xF0F0F0F0u);
-              bf[t][2] = (int)(w.y & 0xF0F0F0F0u);
-              bf[t][3] = (int)((w.y << 4) & 0xF0F0F0F0u);
-            }
-          }
+          for (int t = 0; t < TN; ++t) bf[t] = load_w(S0, b_rd[t][ks]);
 #pragma unroll
           for (int a = 0; a < TN; ++a)
 #pragma unroll
-            for (int b = 0; b < TM; ++b)
-              acc[a][b] = __builtin_amdgcn_mfma_i32_32x32x32_i8(bf[a], af[b], acc[a][b], 0, 0, 0);
+            for (int b = 0; b < TM; ++b) acc[a][b] = mfma(bf[a], af[b], acc[a][b]);
         }
       }
     }
@@ -393,20 +463,32 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const Igem
   __syncthreads();   // every wave is done reading the stage buffers
   if constexpr (KSPLIT > 1) {
     // groups 1.. park their partial accumulators (behind the fp16 tile's area), group 0 adds them
-    static_assert(BM * CS_STRIDE + (KSPLIT - 1) * WM * WN * 16 * 64 * 4 <=
+    constexpr int WREGS = TN * TM * ACC;          // accumulator registers of one wave
+    static_assert(BM * CS_STRIDE + (KSPLIT - 1) * WM * WN * WREGS * 64 * 4 <=
                       igemm_main_bytes<BM, BN, BK, STAGES>(), "partials fit the stage buffers");
-    int* part = reinterpret_cast<int*>(smem + BM * CS_STRIDE) + ((wid % (WM * WN)) * 16 * 64 + lane);
-    constexpr int GROUP_INTS = WM * WN * 16 * 64;
+    using part_t = typename std::conditional<F16, float, int>::type;   // F16: fixed-order fp32 adds
+    part_t* part = reinterpret_cast<part_t*>(smem + BM * CS_STRIDE) + ((wid % (WM * WN)) * WREGS * 64 + lane);
+    constexpr int GROUP_INTS = WM * WN * WREGS * 64;
     if (kg != 0) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) part[(kg - 1) * GROUP_INTS + e * 64] = acc[0][0][e];
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b)
+#pragma unroll
+          for (int e = 0; e < ACC; ++e)
+            part[(kg - 1) * GROUP_INTS + ((a * TM + b) * ACC + e) * 64] = acc[a][b][e];
     }
     __syncthreads();
     if (kg == 0) {
 #pragma unroll
       for (int g = 0; g < KSPLIT - 1; ++g)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[0][0][e] += part[g * GROUP_INTS + e * 64];
+        for (int a = 0; a < TN; ++a)
+#pragma unroll
+          for (int b = 0; b < TM; ++b)
+#pragma unroll
+            for (int e = 0; e < ACC; ++e)
+              acc[a][b][e] += part[g * GROUP_INTS + ((a * TM + b) * ACC + e) * 64];
     }
   }
   char* Cs = smem;
@@ -415,7 +497,7 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const Igem
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     if (KSPLIT > 1 && kg != 0) break;             // group 0 holds the sums
-    const int ml = wm * WTM + tm * 32 + lrow;
+    const int ml = wm * WTM + tm * MT + lrow;
     // table mode: border class of this output pixel = its valid tap rectangle [rlo,rhi]x[slo,shi];
     // interior pixels (the full window) use the row staged in LDS, border pixels read theirs.
     const float* b0row = nullptr;
@@ -434,8 +516,8 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const Igem
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int nl = wn * WTN + tn * 32 + 8 * g + 4 * lhalf;
+      for (int g = 0; g < ACC / 4; ++g) {     // register quads: 4 consecutive output channels each
+        const int nl = wn * WTN + tn * MT + (MT == 32 ? 8 * g + 4 * lkq : 4 * lkq);
         const int n = n0 + nl;
         if (n < p.N) {   // N % 4 == 0: the quad is all-valid or all-invalid
           v4f b0 = *reinterpret_cast<const v4f*>(P_B0 + nl);
@@ -453,11 +535,15 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const Igem
             const v2f b0e = {b0[2 * e2], b0[2 * e2 + 1]};
             const v2f sce = {sc[2 * e2], sc[2 * e2 + 1]};
             const v2f bse = {bs[2 * e2], bs[2 * e2 + 1]};
-            x = x - b0e;
             v2f r;
+            if constexpr (F16) {
+              r = has_bias ? x + bse : x;                    // fp32 accumulator + bias, one rounding
+            } else {
+            x = x - b0e;
             if (!has_bias) r = x * sce;
             else if (unfused) r = x * sce + bse;             // -ffp-contract=off: mul, then add
             else r = __builtin_elementwise_fma(x, sce, bse);
+            }
             asm("" : "+v"(r));   // keep the FP32 rounding: no fold into a single-rounding fma_mix
             const v2h h = __builtin_convertvector(r, v2h);    // v_cvt_pk_f16_f32, RNE
             packed[e2] = *reinterpret_cast<const uint32_t*>(&h);
@@ -468,12 +554,11 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const Igem
     }
   }
   __syncthreads();
-  if (p.Dq != nullptr) {
+  if constexpr (BN % 64 == 0) if (p.Dq != nullptr) {
     // GEGLU + quantize on the staged fp16 tile: every rounding point of the unfused chain
     // (GEMM -> fp16, gelu -> fp16, product -> fp16, quantize) is kept, so the int8 tensor is the
     // one mixdq_geglu_quantize produces from this GEMM's fp16 output.
     constexpr int VCH = BN / 16;               // 8-column value chunks per tile row
-    static_assert(BN % 64 == 0, "geglu copy-out geometry");
     const float s_inv = *p.g_sinv, zpq = *p.g_zp;
     const int Dh = p.N >> 1;
     for (int idx = tid; idx < BM * VCH; idx += NTHREADS) {
@@ -663,15 +748,16 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const __half* __restrict_
   }
 }
 
-template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool CONV, bool FAST, bool W4 = false,
-          int KSPLIT = 1>
+template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool CONV, bool FAST, bool W4, int KSPLIT,
+          int MT, bool F16 = false>
 int launch_kernel(IgemmParams& p, hipStream_t stream) {
   constexpr int SMEM = igemm_smem_bytes<BM, BN, BK, STAGES>();
   static_assert(SMEM <= 160 * 1024, "LDS is 160 KiB per CU");
+  if (p.Dq != nullptr && BN % 64 != 0) return MIXDQ_ERR_GEGLU_SHAPE;   // whole value/gate groups per tile
   if constexpr (SMEM > 64 * 1024) {   // opt in to > 64 KiB of dynamic LDS, once per instantiation
     static const hipError_t attr = hipFuncSetAttribute(
         reinterpret_cast<const void*>(
-            &igemm_kernel<BM, BN, BK, STAGES, WM, WN, CONV, FAST, W4, KSPLIT>),
+            &igemm_kernel<BM, BN, BK, STAGES, WM, WN, CONV, FAST, W4, KSPLIT, MT, F16>),
         hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (attr != hipSuccess) return MIXDQ_ERR_LAUNCH;
   }
@@ -679,78 +765,91 @@ int launch_kernel(IgemmParams& p, hipStream_t stream) {
   p.tiles_n = (p.N + BN - 1) / BN;
   const int64_t grid = (int64_t)p.tiles_m * p.tiles_n;
   if (grid <= 0 || grid > 0x7fffffff) return MIXDQ_ERR_INVALID_ARG;
-  igemm_kernel<BM, BN, BK, STAGES, WM, WN, CONV, FAST, W4, KSPLIT>
+  igemm_kernel<BM, BN, BK, STAGES, WM, WN, CONV, FAST, W4, KSPLIT, MT, F16>
       <<<(int)grid, 64 * WM * WN * KSPLIT, SMEM, stream>>>(p);
   return launch_status();
 }
 
-// W4 instantiations: tiles whose packed weight stage is a whole number of 1-KiB pieces per wave.
-template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool CONV>
-int launch_tile_w4(IgemmParams& p, hipStream_t stream) {
-  if constexpr (!CONV) {
-    const bool fits32 = (uint64_t)p.M * (uint64_t)p.Ktot < (1ull << 32) &&
-                        (uint64_t)p.N * (uint64_t)p.Ktot < (1ull << 32);
-    if (p.Ktot % BK == 0 && fits32)
-      return launch_kernel<BM, BN, BK, STAGES, WM, WN, false, true, true>(p, stream);
-  }
-  return launch_kernel<BM, BN, BK, STAGES, WM, WN, CONV, false, true>(p, stream);
-}
-
-template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool CONV, int KSPLIT = 1>
+template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool CONV, bool W4, int KSPLIT, int MT,
+          bool F16 = false>
 int launch_tile(IgemmParams& p, hipStream_t stream) {
   if constexpr (!CONV) {
     const bool fits32 = (uint64_t)p.M * (uint64_t)p.Ktot < (1ull << 32) &&
                         (uint64_t)p.N * (uint64_t)p.Ktot < (1ull << 32);
     if (p.Ktot % BK == 0 && fits32)
-      return launch_kernel<BM, BN, BK, STAGES, WM, WN, false, true, false, KSPLIT>(p, stream);
+      return launch_kernel<BM, BN, BK, STAGES, WM, WN, false, true, W4, KSPLIT, MT, F16>(p, stream);
   }
-  return launch_kernel<BM, BN, BK, STAGES, WM, WN, CONV, false, false, KSPLIT>(p, stream);
+  return launch_kernel<BM, BN, BK, STAGES, WM, WN, CONV, false, W4, KSPLIT, MT, F16>(p, stream);
 }
 
 // Kernel configurations.  id 0 = automatic choice; ids 1.. can be forced through bits 8..15 of
 // the `flags` argument of the C entry points (tuning / tests only).
-// X(id, BM, BN, BK, STAGES, WM, WN): block tile, K-tile bytes, LDS stages, wave grid (m x n)
-#define MIXDQ_IGEMM_CONFIGS(X)     \
-  X(1, 64, 64, 64, 2, 2, 2)        \
-  X(2, 64, 128, 64, 2, 2, 2)       \
-  X(3, 128, 128, 64, 2, 2, 2)      \
-  X(4, 64, 64, 128, 3, 2, 2)       \
-  X(5, 64, 64, 128, 4, 2, 2)       \
-  X(6, 64, 128, 128, 3, 2, 2)      \
-  X(7, 128, 128, 128, 3, 2, 2)     \
-  X(8, 128, 128, 64, 4, 2, 2)      \
-  X(9, 64, 64, 64, 4, 2, 2)        \
-  X(10, 128, 64, 128, 3, 2, 2)     \
-  X(11, 64, 128, 128, 4, 2, 2)     \
-  X(12, 128, 128, 128, 4, 2, 2)    \
-  X(13, 256, 128, 64, 3, 4, 2)     \
-  X(14, 256, 256, 64, 3, 4, 2)     \
-  X(15, 128, 256, 64, 3, 2, 4)     \
-  X(16, 256, 128, 64, 2, 4, 2)     \
-  X(17, 256, 256, 64, 2, 4, 2)     \
-  X(18, 256, 128, 128, 2, 4, 2)    \
-  X(19, 128, 128, 64, 3, 2, 2)     \
-  X(20, 256, 256, 128, 2, 4, 2)    \
-  X(21, 64, 64, 128, 6, 2, 2)      \
-  X(22, 64, 64, 128, 5, 2, 2)      \
-  X(23, 64, 64, 256, 2, 2, 2)      \
-  X(24, 64, 128, 256, 2, 2, 2)     \
-  X(25, 128, 320, 128, 2, 4, 2)    \
-  X(35, 128, 128, 64, 3, 4, 2)     \
-  X(41, 64, 128, 128, 3, 2, 4)
+// X(id, BM, BN, BK, STAGES, WM, WN, KSPLIT, MT): block tile, K-tile bytes, LDS stages, wave grid
+// (m x n), k-split groups (x WM*WN waves each), MFMA shape (32: 32x32x32, 16: 16x16x64)
+#define MIXDQ_IGEMM_CONFIGS(X)            \
+  X(1, 64, 64, 64, 2, 2, 2, 1, 32)        \
+  X(2, 64, 128, 64, 2, 2, 2, 1, 32)       \
+  X(3, 128, 128, 64, 2, 2, 2, 1, 32)      \
+  X(4, 64, 64, 128, 3, 2, 2, 1, 32)       \
+  X(6, 64, 128, 128, 3, 2, 2, 1, 32)      \
+  X(7, 128, 128, 128, 3, 2, 2, 1, 32)     \
+  X(13, 256, 128, 64, 3, 4, 2, 1, 32)     \
+  X(14, 256, 256, 64, 3, 4, 2, 1, 32)     \
+  X(15, 128, 256, 64, 3, 2, 4, 1, 32)     \
+  X(18, 256, 128, 128, 2, 4, 2, 1, 32)    \
+  X(20, 256, 256, 128, 2, 4, 2, 1, 32)    \
+  X(25, 128, 320, 128, 2, 4, 2, 1, 32)    \
+  X(35, 128, 128, 64, 3, 4, 2, 1, 32)     \
+  X(37, 64, 64, 128, 3, 2, 2, 2, 32)      \
+  X(41, 64, 128, 128, 3, 2, 4, 1, 32)     \
+  X(42, 64, 80, 128, 3, 4, 1, 2, 16)      \
+  X(43, 64, 240, 128, 3, 4, 1, 2, 16)     \
+  X(44, 128, 80, 128, 3, 4, 1, 2, 16)     \
+  X(45, 64, 80, 128, 4, 4, 1, 2, 16)      \
+  X(46, 128, 320, 64, 4, 4, 2, 1, 32)     \
+  X(47, 64, 80, 128, 3, 4, 1, 1, 16)      \
+  X(48, 64, 160, 128, 3, 4, 1, 2, 16)     \
+  X(49, 64, 80, 128, 8, 4, 1, 2, 16)      \
+  X(50, 64, 128, 128, 6, 2, 4, 1, 32)     \
+  X(51, 64, 64, 128, 8, 2, 2, 2, 32)      \
+  X(52, 64, 240, 128, 4, 4, 1, 2, 16)     \
+  X(53, 128, 80, 128, 6, 4, 1, 2, 16)     \
+  X(54, 128, 320, 64, 5, 4, 2, 1, 32)     \
+  X(55, 128, 128, 64, 6, 4, 2, 1, 32)     \
+  X(56, 64, 80, 128, 6, 4, 1, 2, 16)
 
-struct TileCfg { int id, bm, bn, bk, stages, wm, wn; };
+struct TileCfg { int id, bm, bn, bk, stages, wm, wn, ksplit, mt; };
 constexpr TileCfg kTileCfgs[] = {
-#define X(ID, BM, BN, BK, ST, WM, WN) {ID, BM, BN, BK, ST, WM, WN},
+#define X(ID, BM, BN, BK, ST, WM, WN, KS, MT) {ID, BM, BN, BK, ST, WM, WN, KS, MT},
     MIXDQ_IGEMM_CONFIGS(X)
 #undef X
-    {37, 64, 64, 128, 3, 2, 2},    // + 2 k-split groups: 8 waves (dispatched explicitly below)
 };
 
 // Automatic choice (tools/bench_gemm.py on MI355X): the largest tile that still fills the chip.
 // 8-wave 256-row tiles need ~2 blocks per CU of parallelism to pay; long-K problems take the
 // 256x256x128 tile (full 128-byte lines per DMA row, fewest L2->LDS bytes per MAC).
+// MIXDQ_IGEMM_TUNE="MxNxK=cfg,MxNxK=cfg,...": per-shape overrides of the automatic choice, read
+// once (tuning runs: A/B a configuration inside the whole UNet without a rebuild).
+struct TuneEntry { int64_t M; int N, K, cfg; };
+inline const std::vector<TuneEntry>& tune_overrides() {
+  static const std::vector<TuneEntry> table = [] {
+    std::vector<TuneEntry> t;
+    const char* e = getenv("MIXDQ_IGEMM_TUNE");
+    while (e && *e) {
+      long long m; int n, k, c, used = 0;
+      if (sscanf(e, "%lldx%dx%d=%d%n", &m, &n, &k, &c, &used) == 4) t.push_back({m, n, k, c});
+      else break;
+      e += used;
+      if (*e == ',') ++e;
+    }
+    return t;
+  }();
+  return table;
+}
+
 inline int select_cfg(int64_t M, int N, int Ktot) {
+  for (const TuneEntry& t : tune_overrides())
+    if (t.M == M && t.N == N && t.K == Ktot) return t.cfg;
   auto blocks = [&](int tm, int tn) {
     return ((M + tm - 1) / tm) * (int64_t)((N + tn - 1) / tn);
   };
@@ -761,6 +860,16 @@ inline int select_cfg(int64_t M, int N, int Ktot) {
     return 25;   // (K = 640: its two 128-byte-deep stages are too shallow, 128x128 wins)
   if (blocks(256, 128) >= 2 * kNumCU)
     return (Ktot >= 4096 && blocks(256, 256) >= kNumCU) ? 20 : 13;
+  // exact-fit 16x16x64-MFMA tiles (tools/bench_gemm.py, batch 1): 128x80 when that is exactly one
+  // or two workgroups per CU and K is long (M = 4096 / 16384 layers with N = 640 / 1280 / 320:
+  // 13.5 vs 15.3 us at (4096, 640, 2560); the 3x3 convs at 64x64 and 128x128: 75 vs 91, 43 vs 52 us)
+  const int64_t b80 = blocks(128, 80);
+  if (N % 80 == 0 && Ktot >= 2048 && (b80 == kNumCU || b80 == 2 * kNumCU)) return 44;
+  // ... and 64x80 when THAT is exactly one per CU (M = 1024, N = 1280): every CU streams
+  // (64 + 80) * K bytes instead of 160 CUs streaming (64 + 128) * K; four stages for long K
+  // ((1024, 1280, 5120): 14.1 vs 17.3 us; 3x3 convs at 32x32: 35.2 vs 36.6), six for K <= 2048
+  // where the weights arrive cold from HBM in the UNet (tools/bench_cold.py: 8.0 vs 8.8 us)
+  if (N % 80 == 0 && blocks(64, 80) == kNumCU) return Ktot > 2048 ? 45 : 56;
   // 128x128 with 8 waves of 32x64 from ~0.8 workgroups per CU on (measured on the UNet's shapes:
   // tools/bench_gemm.py); below that 64x64 tiles: with 8 waves that split each K-tile's k-steps
   // (cfg 37) when K is long or M tiny -- the chain per K-tile is what bounds these launches --
@@ -773,40 +882,29 @@ inline int select_cfg(int64_t M, int N, int Ktot) {
   return Ktot >= 2048 ? 37 : 4;
 }
 
+// Packed-W4 weights run every tile configuration (the weight stage is half the bytes, its pieces
+// dealt out wave by wave), but every wave unpacks the fragments it multiplies (6 VALU operations
+// per fragment), so tiles whose waves hold few weight fragments per MFMA win: the 32x32x32 tiles
+// rather than the 16-row exact-fit ones (tools/bench_gemm.py --w4: (1024, 1280, 5120) 17.1 us on
+// the k-split 64x64 tile vs 18.3 on 64x80; (1024, 10240, 1280) 26.7 on 128x128 vs 29.9 on 128x320).
 inline int select_cfg_w4(int64_t M, int N, int Ktot) {
+  for (const TuneEntry& t : tune_overrides())
+    if (t.M == M && t.N == N && t.K == Ktot) return t.cfg;
   auto blocks = [&](int tm, int tn) {
     return ((M + tm - 1) / tm) * (int64_t)((N + tn - 1) / tn);
   };
   if (blocks(256, 128) >= 2 * kNumCU)
     return (Ktot >= 4096 && blocks(256, 256) >= kNumCU) ? 20 : 18;
+  const int64_t b80 = blocks(128, 80);
+  if (N % 80 == 0 && Ktot >= 2048 && (b80 == kNumCU || b80 == 2 * kNumCU)) return 44;
   if (blocks(128, 128) >= kNumCU) return 3;
-  if (blocks(64, 128) >= kNumCU && N >= 2048) return 41;   // fused q|k|v: 12.0 vs 14.7 us (cfg 6)
-  return 4;
+  if (blocks(128, 128) >= 200) return 35;
+  if (M <= 256) return 37;
+  if (blocks(64, 64) < 2 * kNumCU && Ktot <= 2048 && N % 128 == 0) return 41;
+  return Ktot >= 2048 ? 37 : 4;
 }
 
-template <bool CONV>
-int dispatch_w4(IgemmParams& p, hipStream_t stream, int forced_cfg) {
-  if (p.M <= 0 || p.N <= 0) return MIXDQ_OK;
-  const int align_k = CONV ? p.C : p.Ktot;
-  if (align_k % 4 != 0 || p.N % 4 != 0) return MIXDQ_ERR_ALIGNMENT;
-  const bool ptr_ok = ((uintptr_t)p.A % 16 == 0) && ((uintptr_t)p.Wt % 16 == 0) &&
-                      ((uintptr_t)p.D % 16 == 0) && ((uintptr_t)p.scale % 16 == 0) &&
-                      ((uintptr_t)p.bias0 % 16 == 0) && ((uintptr_t)p.table % 16 == 0) &&
-                      ((uintptr_t)p.bias % 8 == 0) && ((uintptr_t)p.res % 16 == 0);
-  if (align_k % 32 != 0 || !ptr_ok) return MIXDQ_ERR_W4_SHAPE;   // packed pieces span 32 k
-  const int cfg = forced_cfg > 0 ? forced_cfg : select_cfg_w4(p.M, p.N, p.Ktot);
-  switch (cfg) {
-    case 3: return launch_tile_w4<128, 128, 64, 2, 2, 2, CONV>(p, stream);
-    case 4: return launch_tile_w4<64, 64, 128, 3, 2, 2, CONV>(p, stream);
-    case 6: return launch_tile_w4<64, 128, 128, 3, 2, 2, CONV>(p, stream);
-    case 41: return launch_tile_w4<64, 128, 128, 3, 2, 4, CONV>(p, stream);
-    case 18: return launch_tile_w4<256, 128, 128, 2, 4, 2, CONV>(p, stream);
-    case 20: return launch_tile_w4<256, 256, 128, 2, 4, 2, CONV>(p, stream);
-    default: return MIXDQ_ERR_INVALID_ARG;
-  }
-}
-
-template <bool CONV>
+template <bool CONV, bool W4>
 int dispatch(IgemmParams& p, hipStream_t stream, int forced_cfg) {
   if (p.M <= 0 || p.N <= 0) return MIXDQ_OK;
   const int align_k = CONV ? p.C : p.Ktot;
@@ -815,19 +913,113 @@ int dispatch(IgemmParams& p, hipStream_t stream, int forced_cfg) {
                       ((uintptr_t)p.D % 16 == 0) && ((uintptr_t)p.scale % 16 == 0) &&
                       ((uintptr_t)p.bias0 % 16 == 0) && ((uintptr_t)p.table % 16 == 0) &&
                       ((uintptr_t)p.bias % 8 == 0) && ((uintptr_t)p.res % 16 == 0);
-  if (align_k % 16 != 0 || !ptr_ok) {
-    int64_t blocks = (p.M * p.N + 255) / 256;
-    if (blocks > kNumCU * 16) blocks = kNumCU * 16;
-    igemm_generic_kernel<CONV><<<(int)blocks, 256, 0, stream>>>(p);
-    return launch_status();
+  if constexpr (W4) {
+    if (align_k % 32 != 0 || !ptr_ok) return MIXDQ_ERR_W4_SHAPE;   // packed pieces span 32 k
+  } else {
+    if (align_k % 16 != 0 || !ptr_ok) {
+      int64_t blocks = (p.M * p.N + 255) / 256;
+      if (blocks > kNumCU * 16) blocks = kNumCU * 16;
+      igemm_generic_kernel<CONV><<<(int)blocks, 256, 0, stream>>>(p);
+      return launch_status();
+    }
   }
-  int cfg = forced_cfg > 0 ? forced_cfg : select_cfg(p.M, p.N, p.Ktot);
+  const int cfg = forced_cfg > 0 ? forced_cfg
+                                 : (W4 ? select_cfg_w4(p.M, p.N, p.Ktot) : select_cfg(p.M, p.N, p.Ktot));
   switch (cfg) {
-#define X(ID, BM, BN, BK, ST, WM, WN) \
-  case ID: return launch_tile<BM, BN, BK, ST, WM, WN, CONV>(p, stream);
+#define X(ID, BM, BN, BK, ST, WM, WN, KS, MT) \
+  case ID: return launch_tile<BM, BN, BK, ST, WM, WN, CONV, W4, KS, MT>(p, stream);
     MIXDQ_IGEMM_CONFIGS(X)
 #undef X
-    case 37: return launch_tile<64, 64, 128, 3, 2, 2, CONV, 2>(p, stream);   // 8 waves, k-split
+    default: return MIXDQ_ERR_INVALID_ARG;
+  }
+}
+
+// ---- FP16 layers (the reference's FP fallback, nn/Linear.py:155-156, nn/Conv2d.py:306-309) ----
+// The tile configurations the FP16 instantiation is built for (K in bytes = 2 x elements; the
+// automatic choice is the INT8 rule on the byte counts, mapped into this list).
+#define MIXDQ_F16_CONFIGS(X)              \
+  X(4, 64, 64, 128, 3, 2, 2, 1, 32)       \
+  X(13, 256, 128, 64, 3, 4, 2, 1, 32)     \
+  X(20, 256, 256, 128, 2, 4, 2, 1, 32)    \
+  X(25, 128, 320, 128, 2, 4, 2, 1, 32)    \
+  X(35, 128, 128, 64, 3, 4, 2, 1, 32)     \
+  X(37, 64, 64, 128, 3, 2, 2, 2, 32)      \
+  X(41, 64, 128, 128, 3, 2, 4, 1, 32)     \
+  X(44, 128, 80, 128, 3, 4, 1, 2, 16)     \
+  X(45, 64, 80, 128, 4, 4, 1, 2, 16)      \
+  X(56, 64, 80, 128, 6, 4, 1, 2, 16)
+
+inline int select_cfg_f16(int64_t M, int N, int k_bytes) {
+  const int c = select_cfg(M, N, k_bytes);
+  switch (c) {
+#define X(ID, BM, BN, BK, ST, WM, WN, KS, MT) case ID:
+    MIXDQ_F16_CONFIGS(X)
+#undef X
+      return c;
+    default: return 35;
+  }
+}
+
+// Small-alignment FP16 fallback (C % 8 != 0: conv_in has 4 input channels): one output per thread,
+// FP32 fmaf chain in (r, s, c) order, bias added in FP32, one rounding.
+template <bool CONV>
+__global__ __launch_bounds__(256) void f16_generic_kernel(const IgemmParams p) {
+  const __half* A = reinterpret_cast<const __half*>(p.A);
+  const __half* Wt = reinterpret_cast<const __half*>(p.Wt);
+  const int C = p.C / 2, K = p.Ktot / 2;        // elements
+  const int64_t total = p.M * p.N;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = t / p.N;
+    const int n = (int)(t - m * p.N);
+    float acc = 0.f;
+    if constexpr (!CONV) {
+      const __half* a = A + m * K;
+      const __half* w = Wt + (int64_t)n * K;
+      for (int k = 0; k < K; ++k) acc = __builtin_fmaf(__half2float(a[k]), __half2float(w[k]), acc);
+    } else {
+      const int pq = p.P * p.Q;
+      const int64_t img = m / pq;
+      const int rem = (int)(m - img * pq);
+      const int pp = rem / p.Q, qq = rem - pp * p.Q;
+      const int hb = pp * p.stride - p.pad, wb = qq * p.stride - p.pad;
+      for (int r = 0; r < p.R; ++r)
+        for (int s = 0; s < p.S; ++s) {
+          const int hh = hb + r, ww = wb + s;
+          if ((unsigned)hh >= (unsigned)p.H || (unsigned)ww >= (unsigned)p.W) continue;
+          const __half* a = A + ((img * p.H + hh) * p.W + ww) * (int64_t)C;
+          const __half* w = Wt + ((int64_t)n * p.R * p.S + r * p.S + s) * C;
+          for (int c = 0; c < C; ++c)
+            acc = __builtin_fmaf(__half2float(a[c]), __half2float(w[c]), acc);
+        }
+    }
+    if (p.bias != nullptr) acc = __fadd_rn(acc, __half2float(p.bias[n]));
+    __half o = f32_to_f16_rn(acc);
+    if (p.res != nullptr)
+      o = f32_to_f16_rn(__fadd_rn(__half2float(o), __half2float(p.res[(m / p.res_div) * p.N + n])));
+    p.D[m * p.N + n] = o;
+  }
+}
+
+template <bool CONV>
+int dispatch_f16(IgemmParams& p, hipStream_t stream, int forced_cfg) {
+  if (p.M <= 0 || p.N <= 0) return MIXDQ_OK;
+  const int align_k = CONV ? p.C : p.Ktot;     // bytes
+  const bool ptr_ok = ((uintptr_t)p.A % 16 == 0) && ((uintptr_t)p.Wt % 16 == 0) &&
+                      ((uintptr_t)p.D % 16 == 0) && ((uintptr_t)p.bias % 8 == 0) &&
+                      ((uintptr_t)p.res % 16 == 0);
+  if (align_k % 16 != 0 || p.N % 4 != 0 || !ptr_ok) {
+    int64_t blocks = (p.M * p.N + 255) / 256;
+    if (blocks > kNumCU * 16) blocks = kNumCU * 16;
+    f16_generic_kernel<CONV><<<(int)blocks, 256, 0, stream>>>(p);
+    return launch_status();
+  }
+  const int cfg = forced_cfg > 0 ? forced_cfg : select_cfg_f16(p.M, p.N, p.Ktot);
+  switch (cfg) {
+#define X(ID, BM, BN, BK, ST, WM, WN, KS, MT) \
+  case ID: return launch_tile<BM, BN, BK, ST, WM, WN, CONV, false, KS, MT, true>(p, stream);
+    MIXDQ_F16_CONFIGS(X)
+#undef X
     default: return MIXDQ_ERR_INVALID_ARG;
   }
 }
@@ -856,8 +1048,8 @@ extern "C" int mixdq_qlinear_w8a8_rows(const int8_t* A, const int8_t* W, const f
   p.res_div = residual_row_div > 0 ? residual_row_div : 1;
   if (p.res && group_rows > 0) return MIXDQ_ERR_ROWMAP_RESIDUAL;   // residual rows follow m, not D_row
   p.unfused = (flags & MIXDQ_FLAG_UNFUSED) ? 1 : 0;
-  if (flags & MIXDQ_FLAG_W4) return dispatch_w4<false>(p, (hipStream_t)stream, (flags >> 8) & 0xff);
-  return dispatch<false>(p, (hipStream_t)stream, (flags >> 8) & 0xff);
+  if (flags & MIXDQ_FLAG_W4) return dispatch<false, true>(p, (hipStream_t)stream, (flags >> 8) & 0xff);
+  return dispatch<false, false>(p, (hipStream_t)stream, (flags >> 8) & 0xff);
 }
 
 extern "C" int mixdq_qlinear_w8a8_geglu(const int8_t* A, const int8_t* W, const float* bias0,
@@ -881,8 +1073,8 @@ extern "C" int mixdq_qlinear_w8a8_geglu(const int8_t* A, const int8_t* W, const 
   p.H = p.W = p.P = p.Q = 1; p.C = K; p.R = p.S = 1; p.stride = 1; p.pad = 0;
   p.res_div = 1;
   p.unfused = (flags & MIXDQ_FLAG_UNFUSED) ? 1 : 0;
-  if (flags & MIXDQ_FLAG_W4) return dispatch_w4<false>(p, (hipStream_t)stream, (flags >> 8) & 0xff);
-  return dispatch<false>(p, (hipStream_t)stream, (flags >> 8) & 0xff);
+  if (flags & MIXDQ_FLAG_W4) return dispatch<false, true>(p, (hipStream_t)stream, (flags >> 8) & 0xff);
+  return dispatch<false, false>(p, (hipStream_t)stream, (flags >> 8) & 0xff);
 }
 
 extern "C" int mixdq_qlinear_w8a8(const int8_t* A, const int8_t* W, const float* bias0,
@@ -934,8 +1126,8 @@ extern "C" int mixdq_qconv2d_w8a8_table(const int8_t* X, const int8_t* Wt, const
   p.res = (const __half*)residual_f16_or_null;
   p.res_div = residual_row_div > 0 ? residual_row_div : 1;
   p.unfused = (flags & MIXDQ_FLAG_UNFUSED) ? 1 : 0;
-  if (flags & MIXDQ_FLAG_W4) return dispatch_w4<true>(p, (hipStream_t)stream, (flags >> 8) & 0xff);
-  return dispatch<true>(p, (hipStream_t)stream, (flags >> 8) & 0xff);
+  if (flags & MIXDQ_FLAG_W4) return dispatch<true, true>(p, (hipStream_t)stream, (flags >> 8) & 0xff);
+  return dispatch<true, false>(p, (hipStream_t)stream, (flags >> 8) & 0xff);
 }
 
 extern "C" int mixdq_qconv2d_w8a8(const int8_t* X, const int8_t* Wt, const float* scale,
@@ -984,6 +1176,44 @@ extern "C" int mixdq_gemm_f16(const void* A, const void* B, void* D, int64_t M, 
   gemm_f16_kernel<<<(int)blocks, 256, 0, (hipStream_t)stream>>>((const __half*)A, (const __half*)B,
                                                                 (__half*)D, M, N, K);
   return launch_status();
+}
+
+extern "C" int mixdq_linear_f16(const void* A_f16, const void* W_f16, const void* bias_f16_or_null,
+                                void* D_f16, int64_t M, int N, int K,
+                                const void* residual_f16_or_null, int64_t residual_row_div,
+                                int flags, mixdq_stream_t stream) {
+  if (M < 0 || N < 0 || K < 0) return MIXDQ_ERR_INVALID_ARG;
+  if (M == 0 || N == 0) return MIXDQ_OK;
+  if (!A_f16 || !W_f16 || !D_f16) return MIXDQ_ERR_INVALID_ARG;
+  if ((int64_t)K * 2 > 0x7fffffff) return MIXDQ_ERR_SHAPE;
+  IgemmParams p{};
+  p.A = (const int8_t*)A_f16; p.Wt = (const int8_t*)W_f16; p.bias = (const __half*)bias_f16_or_null;
+  p.D = (__half*)D_f16;
+  p.M = M; p.N = N; p.Ktot = 2 * K;           // the kernel family counts K in bytes
+  p.H = p.W = p.P = p.Q = 1; p.C = 2 * K; p.R = p.S = 1; p.stride = 1; p.pad = 0;
+  p.res = (const __half*)residual_f16_or_null;
+  p.res_div = residual_row_div > 0 ? residual_row_div : 1;
+  return dispatch_f16<false>(p, (hipStream_t)stream, (flags >> 8) & 0xff);
+}
+
+extern "C" int mixdq_conv2d_f16(const void* X_f16, const void* Wt_f16, const void* bias_f16_or_null,
+                                void* D_f16, int N, int H, int W, int C, int K, int R, int S,
+                                int stride, int pad, const void* residual_f16_or_null,
+                                int64_t residual_row_div, int flags, mixdq_stream_t stream) {
+  if (N < 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || R <= 0 || S <= 0 || stride <= 0 || pad < 0)
+    return MIXDQ_ERR_INVALID_ARG;
+  if (!X_f16 || !Wt_f16 || !D_f16) return MIXDQ_ERR_INVALID_ARG;
+  const int P = (H + 2 * pad - (R - 1) - 1) / stride + 1;
+  const int Q = (W + 2 * pad - (S - 1) - 1) / stride + 1;
+  if (P <= 0 || Q <= 0 || N == 0) return MIXDQ_OK;
+  IgemmParams p{};
+  p.A = (const int8_t*)X_f16; p.Wt = (const int8_t*)Wt_f16; p.bias = (const __half*)bias_f16_or_null;
+  p.D = (__half*)D_f16;
+  p.M = (int64_t)N * P * Q; p.N = K; p.Ktot = R * S * C * 2;
+  p.H = H; p.W = W; p.C = 2 * C; p.R = R; p.S = S; p.P = P; p.Q = Q; p.stride = stride; p.pad = pad;
+  p.res = (const __half*)residual_f16_or_null;
+  p.res_div = residual_row_div > 0 ? residual_row_div : 1;
+  return dispatch_f16<true>(p, (hipStream_t)stream, (flags >> 8) & 0xff);
 }
 
 extern "C" const char* mixdq_status_string(int status) {

@@ -222,10 +222,34 @@ class QuantizedConv2d(nn.Module):
             _table=self._border_table(sfx), _residual=residual,
             _residual_per_image=residual_per_image, _w4=self.w_packed4)
 
+    # FP fallback layers: True = this repo's FP16 MFMA kernel (mixdq_conv2d_f16), False = F.conv2d
+    # as in the reference (MIOpen here, whose kernel search costs ~30 s of start-up).
+    fp16_kernel = True
+
+    def forward_fp(self, x, residual=None, residual_per_image=False):
+        """The reference's FP fallback, F.conv2d on the FP16 weight (nn/Conv2d.py:306-309)."""
+        square = (len(set(self.stride)) == 1 and len(set(self.padding)) == 1
+                  and all(d == 1 for d in self.dilation) and self.groups == 1)
+        if (self.fp16_kernel and square and x.is_cuda and x.dtype == torch.float16
+                and self.weight.dtype == torch.float16 and self.out_channels % 4 == 0):
+            w = self.weight
+            if not w.is_contiguous(memory_format=torch.channels_last):
+                # KRSC in memory, once (the kernel's layout; a captured graph must not re-lay it out)
+                w = self.weight = w.contiguous(memory_format=torch.channels_last)
+            if residual is not None and not residual_per_image and not residual.is_contiguous(
+                    memory_format=torch.channels_last):
+                return _C.conv2d_f16(x, w, self.bias, self.stride[0], self.padding[0]) + residual
+            return _C.conv2d_f16(x, w, self.bias, self.stride[0], self.padding[0],
+                                 _residual=residual, _residual_per_image=residual_per_image)
+        y = F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation,
+                     self.groups)
+        if residual is None:
+            return y
+        return y + (residual[:, :, None, None] if residual_per_image else residual)
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if not self.valid_for_acceleration:
-            return F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation,
-                            self.groups)
+            return self.forward_fp(x)
         if x.dtype != torch.float16:
             return self.forward_fallback(x)
         if self.split == 0:

@@ -195,9 +195,25 @@ class QuantizedLinear(nn.Module):
             self._gemm(x_int_tail, out=out, row_map=(T - 1, T, 1))
         return out
 
+    # FP fallback layers (no activation quantizer / unsupported weight bits): True = this repo's
+    # FP16 MFMA kernel (mixdq_linear_f16), False = F.linear as in the reference (hipBLASLt).
+    fp16_kernel = True
+
+    def forward_fp(self, x, residual=None):
+        """The reference's FP fallback, F.linear(x, weight, bias) (nn/Linear.py:155-156)."""
+        if (self.fp16_kernel and x.is_cuda and x.dtype == torch.float16
+                and self.weight.dtype == torch.float16 and self.in_features % 8 == 0
+                and self.out_features % 4 == 0):
+            from mixdq_amd._C import linear_f16
+            if residual is not None and not residual.is_contiguous():
+                return linear_f16(x, self.weight, self.bias) + residual
+            return linear_f16(x, self.weight, self.bias, _residual=residual)
+        y = F.linear(x, self.weight, self.bias)
+        return y if residual is None else y + residual
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if not self.valid_for_acceleration:
-            return F.linear(x, self.weight, self.bias)
+            return self.forward_fp(x)
         if x.dtype != torch.float16:
             return self.forward_fallback(x)
         if not getattr(self, "bos", False):

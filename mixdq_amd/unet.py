@@ -91,6 +91,26 @@ _PACK_VECS = (("wscale", "weight_scales"), ("wsum", "weight_sum_by_input_channel
               ("scale", "scale"), ("bias0", "bias0"))
 
 
+def _uniform_storage(layers) -> bool:
+    """Layers that are to share one GEMM must store their weights alike.  In a mixed-precision
+    config to_q / to_k / to_v may be a mix of int8 and packed 4-bit layers: the packed ones are then
+    widened to int8 storage (the VALUES stay the 4-bit integers, so every output is unchanged) --
+    one launch instead of three is worth more than those layers' halved bytes."""
+    kinds = {bool(m.w_packed4) for m in layers}
+    if len(kinds) == 1:
+        return True
+    if any(getattr(m, "weight_int4", None) is None and m.w_packed4 for m in layers):
+        return False
+    with torch.no_grad():
+        for m in layers:
+            if m.w_packed4:
+                w = m._weight_values().contiguous()
+                del m.weight_int4
+                m.register_buffer("weight_int", w)
+                m.w_packed4 = False
+    return True
+
+
 def _pack_rows(layers):
     """Row-concatenate the weights and per-channel epilogue vectors of Linear layers that read the
     same INT8 operand: one GEMM against [sum N_i, K] computes every output element exactly as the
@@ -196,8 +216,15 @@ def _run(layer, feed, residual=None):
     t, quantized = feed
     if quantized:
         return layer.forward_quantized(t, residual=residual)
+    if residual is not None and _fp_layer(layer):
+        return layer.forward_fp(t, residual=residual)       # FP16 kernel, add in its epilogue
     y = layer(t)
     return y if residual is None else y + residual
+
+
+def _fp_layer(layer) -> bool:
+    """A swapped layer on the reference's FP fallback (own FP16 kernels, residual-capable)."""
+    return hasattr(layer, "forward_fp") and not getattr(layer, "valid_for_acceleration", True)
 
 
 def _linear_res(layer, x, residual):
@@ -205,6 +232,8 @@ def _linear_res(layer, x, residual):
     if _accel(layer) and _fusable_f16(x) and residual.is_contiguous():
         from mixdq_amd.nn.Linear import quant_op
         return layer.forward_quantized(quant_op(x, *_qp(layer)), residual=residual)
+    if _fp_layer(layer) and _fusable_f16(x):
+        return layer.forward_fp(x, residual=residual)
     return layer(x) + residual
 
 
@@ -287,6 +316,8 @@ class ResnetBlock2D(nn.Module):
         feed, q = _gn_feed(self.norm1, x, self.conv1, silu=True)
         if q:   # h = conv1(..) + t[:, :, None, None], the add folded into the conv epilogue
             h = self.conv1.forward_quantized(feed, residual=t.contiguous(), residual_per_image=True)
+        elif _fp_layer(self.conv1):
+            h = self.conv1.forward_fp(feed, residual=t.contiguous(), residual_per_image=True)
         else:
             h = self.conv1(feed) + t[:, :, None, None]
         if sc is not None:
@@ -296,6 +327,8 @@ class ResnetBlock2D(nn.Module):
         feed, q = _gn_feed(self.norm2, h, self.conv2, silu=True)
         if q and x.is_contiguous(memory_format=torch.channels_last):
             return self.conv2.forward_quantized(feed, residual=x)  # x + conv2(..)
+        if not q and _fp_layer(self.conv2):
+            return self.conv2.forward_fp(feed, residual=x)
         return x + self.conv2(feed)
 
 
@@ -393,7 +426,7 @@ class FeedForward(nn.Module):
                 q, _ = _C.geglu_quantize(h, *_qp(out_layer))
                 return out_layer.forward_quantized(q, residual=residual)
             _, g = _C.geglu_quantize(h, want_f16=True)
-            return out_layer(g) + residual
+            return _run(out_layer, (g, False), residual)
         a, gate = h.chunk(2, dim=-1)
         return out_layer(a * F.gelu(gate)) + residual
 
@@ -426,10 +459,11 @@ class BasicTransformerBlock(nn.Module):
         or their quantizer tensors change (e.g. quantize_unet after an FP16 run of this graph)."""
         a = self.attn1
         layers = [a.to_q, a.to_k, a.to_v]
-        if not (all(_accel(m) and m.bias is None for m in layers)
-                and len({bool(m.w_packed4) for m in layers}) == 1):
+        if not all(_accel(m) and m.bias is None for m in layers):
             return None
         if len(set(_quantizer_groups(_memo(self), "qkv", layers))) != 1:
+            return None
+        if not _uniform_storage(layers):
             return None
         pack = self.__dict__.get("_qkv")
         if not _pack_valid(pack, layers):
@@ -717,12 +751,13 @@ class SDXLUNet(nn.Module):
         layers = [lk, lv]
         if not (all(getattr(m, "valid_for_acceleration", False) and getattr(m, "bos", False)
                     and m.bias is None for m in layers)
-                and bool(lk.w_packed4) == bool(lv.w_packed4)
                 and lk.out_features == lv.out_features):
             return None
         if context is not None and not (context.dtype == torch.float16 and context.shape[1] > 1):
             return None
         if len(set(_quantizer_groups(_memo(blk), "kv", layers))) != 1:
+            return None
+        if not _uniform_storage(layers):
             return None
         pack = blk.__dict__.get("_kvpack")
         if not _pack_valid(pack, layers):

@@ -147,6 +147,7 @@ GEGLU_GEMM_CASES = [  # M, D, K, forced tile config (0 = automatic), bias
     (1024, 640, 320, 0, True), (96, 64, 64, 4, True), (77, 32, 48, 4, False),
     (200, 160, 128, 3, True), (200, 160, 128, 6, True), (300, 128, 256, 13, True),
     (513, 256, 192, 18, False), (257, 256, 128, 20, True), (1, 32, 16, 0, True),
+    (300, 320, 256, 25, True), (300, 320, 192, 46, True), (130, 160, 128, 46, False),
 ]
 
 
@@ -175,6 +176,16 @@ def test_qlinear_geglu_equals_gemm_then_geglu_quantize(C, oracle, case):
                                None if bias is None else t(bias))
     q2, _ = C.geglu_quantize(hd, scal(s_inv), scal(zp))
     assert torch.equal(got, q2)
+
+
+def test_qlinear_geglu_rejects_tiles_without_whole_value_gate_groups(C):
+    """BN % 64 != 0 tiles (the 16x16x64-MFMA exact-fit tiles) cannot hold whole (value, gate) groups
+    of 32: forcing one is an error, not a wrong result."""
+    a = torch.zeros(64, 128, dtype=torch.int8, device=DEV)
+    w = torch.zeros(320, 128, dtype=torch.int8, device=DEV)
+    v = torch.ones(320, device=DEV)
+    with pytest.raises(RuntimeError, match="N % 64"):
+        C.qlinear_geglu(a, w, v, v, None, scal(1.0), scal(0.0), _cfg=42)
 
 
 def test_qlinear_geglu_argument_checks(C):

@@ -466,6 +466,15 @@ def test_every_kernel_configuration_is_bit_exact(C, oracle, cfg):
                                 _cfg=cfg)
     assert_bits_equal(out.cpu().numpy(), oracle.qlinear(a, w, b0, sc, bias, C.FLAGS & 1),
                       f"linear cfg {cfg}")
+    # K % BK == 0: the Linear fast staging path (scalar K-tile advance, clamped tail rows), with
+    # ragged M and N tails for every tile shape (64x80, 64x240, 128x320 ...) and > STAGES K-tiles
+    M, K, N = 331, 1280, 424
+    a, w = dd.int8(86, (M, K)), dd.int8(87, (N, K))
+    b0, sc = dd.f32(88, (N,), -500, 500), dd.f32(89, (N,), 1e-4, 1e-3)
+    out = C.qlinear_w8_a8_ohalf(t(a), t(w), t(sc), scal(1), scal(0), t(b0), t(sc), t(b0), None,
+                                _cfg=cfg)
+    assert_bits_equal(out.cpu().numpy(), oracle.qlinear(a, w, b0, sc, None, C.FLAGS & 1),
+                      f"linear fast path cfg {cfg}")
     case = next(c for c in CONV_CASES if c[0] == "conv_s2_odd")
     name, n, h, w_, c, k, r, s, pad, stride, has_bias, rng, seed = case
     x, wt, wscale, in_scale, in_zp, bias, scale, wsum, bias0 = conv_inputs(case)
@@ -495,7 +504,7 @@ def test_qlinear_w4_equals_w8_on_unpacked_values(C, oracle, M, K, N, bias):
     bs = dd.f16(94, (N,), -1, 1) if bias else None
     want = oracle.qlinear(a, oracle.unpack_w4(packed.numpy()), b0, sc, bs, C.FLAGS & 1)
     assert np.array_equal(oracle.unpack_w4(packed.numpy()), q)
-    for cfg in (0, 3, 4, 6, 18, 20):
+    for cfg in (0,) + tuple(sorted(C.IGEMM_CONFIGS)):
         out = C.qlinear_w8_a8_ohalf(t(a), packed.to(DEV), t(sc), scal(1), scal(0), t(wsum), t(sc),
                                     t(b0), None if bs is None else t(bs), _w4=True, _cfg=cfg)
         assert_bits_equal(out.cpu().numpy(), want, f"w4 linear cfg {cfg}")
@@ -518,7 +527,7 @@ def test_qconv2d_w4_equals_w8_on_unpacked_values(C, oracle, case):
     want = oracle.qconv2d(x, oracle.unpack_w4(packed.numpy()), sc, wsum if pad else None, zp,
                           bias0 if not pad else None, bias, stride, pad, C.FLAGS & 1)
     win = packed.to(DEV).permute(0, 3, 1, 2)                       # [K, C/2, R, S] channels-last
-    for cfg in (0, 3, 4, 6, 18, 20):
+    for cfg in (0,) + tuple(sorted(C.IGEMM_CONFIGS)):
         out = C.qconv2d_w8_a8_ohalf(t(x).permute(0, 3, 1, 2), win, t(sc), scal(1), scal(zp), t(sc),
                                     t(wsum.reshape(k, 1, r, s)) if pad else None,
                                     t(bias0) if not pad else None,

@@ -54,6 +54,7 @@ def main():
     ap.add_argument("--bs", type=int, default=1)
     ap.add_argument("--conv", action="store_true")
     ap.add_argument("--cfgs", default="")
+    ap.add_argument("--w4", action="store_true", help="packed 4-bit weights (MIXDQ_FLAG_W4)")
     args = ap.parse_args()
     cfgs = [int(c) for c in args.cfgs.split(",")] if args.cfgs else sorted(C.IGEMM_CONFIGS)
     g = torch.Generator(device="cpu").manual_seed(0)
@@ -69,6 +70,9 @@ def main():
                               ).to(DEV).contiguous(memory_format=torch.channels_last)
             pad = ks // 2
             wsum = w.float().sum(dim=1, keepdim=True)
+            if args.w4:
+                from mixdq_amd.nn.utils import pack_w4
+                w = pack_w4((w >> 4).permute(0, 2, 3, 1).contiguous()).permute(0, 3, 1, 2)
             table = C.conv_border_table(wsum) if pad else None
             b0 = None if pad else w.float().sum(dim=[1, 2, 3])
             sc = torch.rand(cout, generator=g).to(DEV) * 1e-4
@@ -77,20 +81,25 @@ def main():
 
             def run(cfg):
                 return C.qconv2d_w8_a8_ohalf(x, w, sc, zero, zero, sc, wsum if pad else None, b0,
-                                             bias, stride, pad, 1, _table=table, _cfg=cfg)
+                                             bias, stride, pad, 1, _table=table, _cfg=cfg,
+                                             _w4=args.w4)
             label = f"conv {hw}x{hw} {cin}->{cout} k{ks}"
         else:
             cnt, M, N, K = shp
             M *= args.bs
             a = torch.randint(-128, 128, (M, K), generator=g, dtype=torch.int8).to(DEV)
             w = torch.randint(-128, 128, (N, K), generator=g, dtype=torch.int8).to(DEV)
+            if args.w4:
+                from mixdq_amd.nn.utils import pack_w4
+                w = pack_w4(w >> 4)
             sc = torch.rand(N, generator=g).to(DEV) * 1e-4
             b0 = torch.rand(N, generator=g).to(DEV) * 100
             bias = torch.rand(N, generator=g).half().to(DEV)
             ops = 2.0 * M * N * K
 
             def run(cfg):
-                return C.qlinear_w8_a8_ohalf(a, w, sc, zero, zero, b0, sc, b0, bias, _cfg=cfg)
+                return C.qlinear_w8_a8_ohalf(a, w, sc, zero, zero, b0, sc, b0, bias, _cfg=cfg,
+                                             _w4=args.w4)
             label = f"lin M{M} N{N} K{K}"
         ref = run(1)
         row = dict(shape=label, count=cnt, gops=ops / 1e9, us={})
