@@ -159,7 +159,10 @@ def roofline_sweep(run_eager, device, reps):
         torch.cuda.synchronize(device)
     groups = {}
     for kind, (M, N, K, k_align), w4, replay in rec:
-        cid = C.igemm_select_id(M, N, k_align, K, w4=w4)
+        if kind == "linear_grouped":     # N = the members' total; mixdq_qlinear_w8a8_grouped's rule
+            cid = 37 if M <= 64 else 35
+        else:
+            cid = C.igemm_select_id(M, N, k_align, K, w4=w4)
         bm, bn, bk, st = C.IGEMM_CONFIGS.get(cid, (0, 0, 0, 0))
         kname = f"igemm_kernel<{bm},{bn},{bk},{st},{kind}{',w4' if w4 else ''}>#cfg{cid}"
         g_ = groups.setdefault(kname, dict(fns=[], ops=0.0, bytes=0.0))

@@ -217,6 +217,25 @@ int mixdq_geglu_quantize(const void* h_f16, int64_t M, int D,
                          int8_t* out_q_or_null, void* out_f16_or_null, int flags,
                          mixdq_stream_t stream);
 
+/* Grouped form of mixdq_qlinear_w8a8_rows: `ngroups` independent Linears that read the SAME int8
+ * activations A [M, K] -- the 70 cross-attention k|v projections of the text embeddings, the 22
+ * time-embedding projections -- in ONE launch (gridDim.y = member).  No reference counterpart (it
+ * launches one GEMM per layer); every member's outputs are bit-identical to its own launch.
+ * `groups_device`: DEVICE array of members; N may differ per member (max_N = the largest).  The
+ * row map is shared.  K % 16 == 0 (W4: % 32) and N % 4 == 0. */
+typedef struct mixdq_gemm_group {
+  const int8_t* W;               /* [N, K] (MIXDQ_FLAG_W4: [N, K/2] packed) */
+  const float* bias0;            /* [N] */
+  const float* scale;            /* [N] */
+  const void* bias_f16_or_null;  /* [N] */
+  void* D_f16;                   /* output base */
+  int32_t N;
+  int32_t reserved;
+} mixdq_gemm_group;
+int mixdq_qlinear_w8a8_grouped(const int8_t* A, const mixdq_gemm_group* groups_device, int ngroups,
+                               int64_t M, int max_N, int K, int group_rows, int group_stride,
+                               int group_offset, int flags, mixdq_stream_t stream);
+
 /* ff.net.0.proj + GEGLU + quantize in one launch: the GEMM of mixdq_qlinear_w8a8 whose N = 2D
  * output columns arrive as value/gate groups of 32 ([v 0..31 | g 0..31 | v 32..63 | g 32..63 ...]:
  * the caller stores W, bias0, scale and bias with rows in that order), reduced in the epilogue to

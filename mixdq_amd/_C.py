@@ -257,6 +257,62 @@ def qlinear_w8_a8_ohalf(input_int8, weight_int8, weight_scale, input_scale, inpu
     return D
 
 
+_lib.mixdq_qlinear_w8a8_grouped.argtypes = [_vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]
+_lib.mixdq_qlinear_w8a8_grouped.restype = _i32
+
+
+class GemmGroupTable:
+    """Device array of `mixdq_gemm_group` members (include/mixdq_hip.h) for qlinear_grouped.
+    members: iterable of (weight_int8 [N, K], bias0 [N], scale [N], bias fp16 [N] or None,
+    out fp16 tensor whose data_ptr() is the member's output base).  The table keeps references to
+    every tensor it points at; `key` identifies the storage it was built for."""
+
+    def __init__(self, members, w4=False):
+        import numpy as np
+        self.members = [tuple(m) for m in members]
+        self.w4 = bool(w4)
+        rows, keep = [], []
+        for w, b0, sc, bias, out in self.members:
+            _check(w.is_cuda and w.dtype == torch.int8 and w.is_contiguous(), "member weight: int8")
+            N = w.size(0)
+            b0, sc = _f32vec(b0), _f32vec(sc)
+            bias = None if bias is None else bias.contiguous()
+            _check(b0.numel() == N and sc.numel() == N and (bias is None or bias.numel() == N),
+                   "member epilogue vectors should have N elements")
+            _check(out.dtype == torch.float16 and out.data_ptr() % 16 == 0, "member output: fp16")
+            keep.append((w, b0, sc, bias, out))
+            rows.append([w.data_ptr(), b0.data_ptr(), sc.data_ptr(),
+                         0 if bias is None else bias.data_ptr(), out.data_ptr(), N])
+        self._keep = keep
+        self.K = self.members[0][0].size(1) * (2 if w4 else 1)
+        _check(all(m[0].size(1) == self.members[0][0].size(1) for m in self.members),
+               "members of a grouped launch share K")
+        self.max_N = max(r[5] for r in rows)
+        self.n = len(rows)
+        # struct mixdq_gemm_group: 5 pointers, int32 N, int32 reserved = 6 x 8 bytes
+        self.table = torch.from_numpy(np.asarray(rows, dtype=np.int64)).to(self.members[0][0].device)
+        self.key = tuple(r[0] for r in rows) + tuple(r[4] for r in rows)
+
+
+def qlinear_grouped(input_int8, table: "GemmGroupTable", *, _row_map=None, _cfg=0):
+    """`table.n` Linears on the same int8 input in one launch (mixdq_qlinear_w8a8_grouped); every
+    member writes its own output tensor (the ones the table was built with)."""
+    _check(input_int8.is_cuda and input_int8.dtype == torch.int8, "input_int8 should be int8 on GPU")
+    _check(input_int8.size(-1) == table.K, "The last dimension of input and weight should match")
+    a = input_int8.contiguous()
+    M = a.numel() // table.K if table.K else 0
+    rm = _row_map or (0, 0, 0)
+    _record("linear_grouped", M, sum(m[0].size(0) for m in table.members), table.K, table.K,
+            table.w4, qlinear_grouped,
+            (input_int8, table), dict(_row_map=_row_map, _cfg=_cfg))
+    with torch.cuda.device(a.device):
+        code = _lib.mixdq_qlinear_w8a8_grouped(a.data_ptr(), table.table.data_ptr(), table.n, M,
+                                               table.max_N, table.K, rm[0], rm[1], rm[2],
+                                               FLAGS | (_cfg << 8) | (FLAG_W4 if table.w4 else 0),
+                                               _stream())
+    _status(code, "qlinear_grouped")
+
+
 _lib.mixdq_qlinear_w8a8_geglu.argtypes = [_vp] * 6 + [_i64, _i32, _i32, _vp, _vp, _i32, _vp]
 _lib.mixdq_qlinear_w8a8_geglu.restype = _i32
 

@@ -57,6 +57,10 @@ struct IgemmParams {
   int8_t* Dq;
   const float* g_sinv;
   const float* g_zp;
+  // Grouped launch (groups != null): blockIdx.y selects a member; its weights, epilogue vectors,
+  // output and N replace the fields above (A, M, K, the row map and the flags are shared).
+  const mixdq_gemm_group* groups;
+  int ngroups_launch;    // host side only: gridDim.y
 };
 
 template <int BK>
@@ -123,8 +127,18 @@ __device__ __forceinline__ uint32_t add_f16x2(uint32_t a, uint32_t b) {
 // the act-protected ff.net.2 ..., nn/Linear.py:155-156): D = f16(acc + bias) [+ residual].
 template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool CONV, bool FAST, bool W4,
           int KSPLIT = 1, int MT = 32, bool F16 = false>
-__global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const IgemmParams p) {
+__global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const IgemmParams p_in) {
   static_assert(!(CONV && FAST), "the fast staging path is for Linear");
+  IgemmParams p = p_in;
+  int nwg = gridDim.x;
+  if (p_in.groups != nullptr) {     // one member of a grouped launch (wave-uniform scalar loads)
+    const mixdq_gemm_group g = p_in.groups[blockIdx.y];
+    p.Wt = g.W; p.bias0 = g.bias0; p.scale = g.scale; p.bias = (const __half*)g.bias_f16_or_null;
+    p.D = (__half*)g.D_f16; p.N = g.N;
+    p.tiles_n = (g.N + BN - 1) / BN;
+    nwg = p.tiles_m * p.tiles_n;
+    if ((int)blockIdx.x >= nwg) return;   // the grid is sized for the widest member
+  }
   static_assert(!(F16 && W4), "packed weights are an INT8-path format");
   static_assert(MT == 32 || MT == 16, "MFMA shapes: 32x32x32 or 16x16x64");
   constexpr int NWAVES = WM * WN * KSPLIT, NTHREADS = 64 * NWAVES;
@@ -163,7 +177,6 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const Igem
   //      so the ~100 blocks an XCD runs at once cover a near-square patch of the output and share
   //      both their activation rows and their weight panels in that L2 instead of streaming all
   //      of A for every column of tiles.
-  const int nwg = gridDim.x;
   const int bid = blockIdx.x;
   const int xcd = bid % kNumXCD, q8 = nwg / kNumXCD, r8 = nwg % kNumXCD;
   const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / kNumXCD;
@@ -765,8 +778,9 @@ int launch_kernel(IgemmParams& p, hipStream_t stream) {
   p.tiles_n = (p.N + BN - 1) / BN;
   const int64_t grid = (int64_t)p.tiles_m * p.tiles_n;
   if (grid <= 0 || grid > 0x7fffffff) return MIXDQ_ERR_INVALID_ARG;
+  const int ny = p.groups != nullptr ? p.ngroups_launch : 1;
   igemm_kernel<BM, BN, BK, STAGES, WM, WN, CONV, FAST, W4, KSPLIT, MT, F16>
-      <<<(int)grid, 64 * WM * WN * KSPLIT, SMEM, stream>>>(p);
+      <<<dim3((unsigned)grid, (unsigned)ny), 64 * WM * WN * KSPLIT, SMEM, stream>>>(p);
   return launch_status();
 }
 
@@ -847,7 +861,8 @@ inline const std::vector<TuneEntry>& tune_overrides() {
   return table;
 }
 
-inline int select_cfg(int64_t M, int N, int Ktot) {
+// whole64: the launch needs BN % 64 == 0 (GEMM+GEGLU: whole value/gate groups per tile)
+inline int select_cfg(int64_t M, int N, int Ktot, bool whole64 = false) {
   for (const TuneEntry& t : tune_overrides())
     if (t.M == M && t.N == N && t.K == Ktot) return t.cfg;
   auto blocks = [&](int tm, int tn) {
@@ -864,12 +879,12 @@ inline int select_cfg(int64_t M, int N, int Ktot) {
   // or two workgroups per CU and K is long (M = 4096 / 16384 layers with N = 640 / 1280 / 320:
   // 13.5 vs 15.3 us at (4096, 640, 2560); the 3x3 convs at 64x64 and 128x128: 75 vs 91, 43 vs 52 us)
   const int64_t b80 = blocks(128, 80);
-  if (N % 80 == 0 && Ktot >= 2048 && (b80 == kNumCU || b80 == 2 * kNumCU)) return 44;
+  if (!whole64 && N % 80 == 0 && Ktot >= 2048 && (b80 == kNumCU || b80 == 2 * kNumCU)) return 44;
   // ... and 64x80 when THAT is exactly one per CU (M = 1024, N = 1280): every CU streams
   // (64 + 80) * K bytes instead of 160 CUs streaming (64 + 128) * K; four stages for long K
   // ((1024, 1280, 5120): 14.1 vs 17.3 us; 3x3 convs at 32x32: 35.2 vs 36.6), six for K <= 2048
   // where the weights arrive cold from HBM in the UNet (tools/bench_cold.py: 8.0 vs 8.8 us)
-  if (N % 80 == 0 && blocks(64, 80) == kNumCU) return Ktot > 2048 ? 45 : 56;
+  if (!whole64 && N % 80 == 0 && blocks(64, 80) == kNumCU) return Ktot > 2048 ? 45 : 56;
   // 128x128 with 8 waves of 32x64 from ~0.8 workgroups per CU on (measured on the UNet's shapes:
   // tools/bench_gemm.py); below that 64x64 tiles: with 8 waves that split each K-tile's k-steps
   // (cfg 37) when K is long or M tiny -- the chain per K-tile is what bounds these launches --
@@ -887,7 +902,7 @@ inline int select_cfg(int64_t M, int N, int Ktot) {
 // per fragment), so tiles whose waves hold few weight fragments per MFMA win: the 32x32x32 tiles
 // rather than the 16-row exact-fit ones (tools/bench_gemm.py --w4: (1024, 1280, 5120) 17.1 us on
 // the k-split 64x64 tile vs 18.3 on 64x80; (1024, 10240, 1280) 26.7 on 128x128 vs 29.9 on 128x320).
-inline int select_cfg_w4(int64_t M, int N, int Ktot) {
+inline int select_cfg_w4(int64_t M, int N, int Ktot, bool whole64 = false) {
   for (const TuneEntry& t : tune_overrides())
     if (t.M == M && t.N == N && t.K == Ktot) return t.cfg;
   auto blocks = [&](int tm, int tn) {
@@ -896,7 +911,7 @@ inline int select_cfg_w4(int64_t M, int N, int Ktot) {
   if (blocks(256, 128) >= 2 * kNumCU)
     return (Ktot >= 4096 && blocks(256, 256) >= kNumCU) ? 20 : 18;
   const int64_t b80 = blocks(128, 80);
-  if (N % 80 == 0 && Ktot >= 2048 && (b80 == kNumCU || b80 == 2 * kNumCU)) return 44;
+  if (!whole64 && N % 80 == 0 && Ktot >= 2048 && (b80 == kNumCU || b80 == 2 * kNumCU)) return 44;
   if (blocks(128, 128) >= kNumCU) return 3;
   if (blocks(128, 128) >= 200) return 35;
   if (M <= 256) return 37;
@@ -923,11 +938,25 @@ int dispatch(IgemmParams& p, hipStream_t stream, int forced_cfg) {
       return launch_status();
     }
   }
+  const bool whole64 = p.Dq != nullptr;
   const int cfg = forced_cfg > 0 ? forced_cfg
-                                 : (W4 ? select_cfg_w4(p.M, p.N, p.Ktot) : select_cfg(p.M, p.N, p.Ktot));
+                                 : (W4 ? select_cfg_w4(p.M, p.N, p.Ktot, whole64)
+                                       : select_cfg(p.M, p.N, p.Ktot, whole64));
   switch (cfg) {
 #define X(ID, BM, BN, BK, ST, WM, WN, KS, MT) \
   case ID: return launch_tile<BM, BN, BK, ST, WM, WN, CONV, W4, KS, MT>(p, stream);
+    MIXDQ_IGEMM_CONFIGS(X)
+#undef X
+    default: return MIXDQ_ERR_INVALID_ARG;
+  }
+}
+
+template <bool W4>
+int dispatch_grouped(IgemmParams& p, int ngroups, hipStream_t stream, int cfg) {
+  p.ngroups_launch = ngroups;
+  switch (cfg) {
+#define X(ID, BM, BN, BK, ST, WM, WN, KS, MT) \
+  case ID: return launch_tile<BM, BN, BK, ST, WM, WN, false, W4, KS, MT>(p, stream);
     MIXDQ_IGEMM_CONFIGS(X)
 #undef X
     default: return MIXDQ_ERR_INVALID_ARG;
@@ -1075,6 +1104,31 @@ extern "C" int mixdq_qlinear_w8a8_geglu(const int8_t* A, const int8_t* W, const 
   p.unfused = (flags & MIXDQ_FLAG_UNFUSED) ? 1 : 0;
   if (flags & MIXDQ_FLAG_W4) return dispatch<false, true>(p, (hipStream_t)stream, (flags >> 8) & 0xff);
   return dispatch<false, false>(p, (hipStream_t)stream, (flags >> 8) & 0xff);
+}
+
+extern "C" int mixdq_qlinear_w8a8_grouped(const int8_t* A, const mixdq_gemm_group* groups_device,
+                                          int ngroups, int64_t M, int max_N, int K, int group_rows,
+                                          int group_stride, int group_offset, int flags,
+                                          mixdq_stream_t stream) {
+  if (M < 0 || max_N < 0 || K < 0 || ngroups < 0) return MIXDQ_ERR_INVALID_ARG;
+  if (M == 0 || max_N == 0 || ngroups == 0) return MIXDQ_OK;
+  if (!A || !groups_device || ngroups > 65535) return MIXDQ_ERR_INVALID_ARG;
+  const bool w4 = flags & MIXDQ_FLAG_W4;
+  if (K % (w4 ? 32 : 16) != 0 || max_N % 4 != 0 || ((uintptr_t)A & 15))
+    return w4 ? MIXDQ_ERR_W4_SHAPE : MIXDQ_ERR_ALIGNMENT;   // the LDS-DMA kernels only
+  IgemmParams p{};
+  p.A = A; p.groups = groups_device;
+  p.M = M; p.N = max_N; p.Ktot = K;
+  p.H = p.W = p.P = p.Q = 1; p.C = K; p.R = p.S = 1; p.stride = 1; p.pad = 0;
+  p.grp_rows = group_rows; p.grp_stride = group_stride; p.grp_off = group_offset;
+  p.res_div = 1;
+  p.unfused = (flags & MIXDQ_FLAG_UNFUSED) ? 1 : 0;
+  int cfg = (flags >> 8) & 0xff;
+  // the members are independent problems: the tile only has to suit one of them, the grid
+  // (x ngroups) fills the chip.  M <= 64: 64x64 k-split tiles, else 128x128 (8 waves).
+  if (cfg == 0) cfg = M <= 64 ? 37 : 35;
+  return w4 ? dispatch_grouped<true>(p, ngroups, (hipStream_t)stream, cfg)
+            : dispatch_grouped<false>(p, ngroups, (hipStream_t)stream, cfg);
 }
 
 extern "C" int mixdq_qlinear_w8a8(const int8_t* A, const int8_t* W, const float* bias0,

@@ -236,6 +236,22 @@ class QuantizedConv2d(nn.Module):
             if not w.is_contiguous(memory_format=torch.channels_last):
                 # KRSC in memory, once (the kernel's layout; a captured graph must not re-lay it out)
                 w = self.weight = w.contiguous(memory_format=torch.channels_last)
+            if self.in_channels % 8:
+                # conv_in (4 input channels): zero-pad the channels to a 16-byte multiple so the
+                # layer runs on the MFMA tiles (the padded weight is cached; zeros add nothing)
+                cp = -self.in_channels % 8
+                wp = self.__dict__.get("_w_padded")
+                if wp is None or wp[0] is not w or wp[1] != w._version:
+                    wpad = torch.zeros((w.shape[0], w.shape[1] + cp, w.shape[2], w.shape[3]),
+                                       dtype=w.dtype, device=w.device
+                                       ).contiguous(memory_format=torch.channels_last)
+                    wpad[:, :w.shape[1]] = w
+                    wp = self.__dict__["_w_padded"] = (w, w._version, wpad)
+                xp = torch.zeros((x.shape[0], x.shape[1] + cp, x.shape[2], x.shape[3]),
+                                 dtype=x.dtype, device=x.device
+                                 ).contiguous(memory_format=torch.channels_last)
+                xp[:, :x.shape[1]] = x
+                x, w = xp, wp[2]
             if residual is not None and not residual_per_image and not residual.is_contiguous(
                     memory_format=torch.channels_last):
                 return _C.conv2d_f16(x, w, self.bias, self.stride[0], self.padding[0]) + residual

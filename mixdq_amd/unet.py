@@ -170,6 +170,12 @@ def _gn_feed(norm: nn.GroupNorm, x, consumer, silu: bool):
 
 
 _SHORTCUT_STREAMS = {}
+# ResNet 1x1 shortcut convs beside norm1 / conv1 / norm2 on a side stream?  Off: measured on
+# MI355X / ROCm 7.2, every extra branch in the captured hipGraph costs more than the kernels it
+# overlaps (shortcut branch: 14.40 -> 13.70 ms per step without it; the K/V + time-embedding
+# branch: -0.5 ms) -- the step is one chain of launches on one stream.  MIXDQ_SHORTCUT_STREAM=1
+# restores the branch for A/B runs.
+SHORTCUT_SIDE_STREAM = __import__("os").environ.get("MIXDQ_SHORTCUT_STREAM", "0") == "1"
 
 
 def _shortcut_stream(device):
@@ -298,14 +304,18 @@ class ResnetBlock2D(nn.Module):
 
     def forward_fused(self, x, temb):
         ahead = self.__dict__.pop("_t", None)
-        if ahead is not None:       # projected ahead of time on the side stream (SDXLUNet.forward)
+        if ahead is not None:       # projected ahead of time (SDXLUNet._project_temb_ahead)
             t, ready = ahead
-            torch.cuda.current_stream().wait_event(ready)
-            t.record_stream(torch.cuda.current_stream())
+            if ready is not None:
+                torch.cuda.current_stream().wait_event(ready)
+                t.record_stream(torch.cuda.current_stream())
         else:
             t = self.time_emb_proj(F.silu(temb))                   # [N, Cout]
         sc = None
-        if self.conv_shortcut is not None:
+        side = None
+        if self.conv_shortcut is not None and not SHORTCUT_SIDE_STREAM:
+            sc = self.conv_shortcut(x)
+        elif self.conv_shortcut is not None:
             # the 1x1 shortcut (quantize + GEMM, twice for a split layer) only meets the main path
             # at conv2's residual add: it runs beside norm1 / conv1 / norm2 on a side stream
             main, side = torch.cuda.current_stream(), _shortcut_stream(x.device)
@@ -321,8 +331,9 @@ class ResnetBlock2D(nn.Module):
         else:
             h = self.conv1(feed) + t[:, :, None, None]
         if sc is not None:
-            main.wait_stream(side)
-            sc.record_stream(main)
+            if side is not None:
+                main.wait_stream(side)
+                sc.record_stream(main)
             x = sc
         feed, q = _gn_feed(self.norm2, h, self.conv2, silu=True)
         if q and x.is_contiguous(memory_format=torch.channels_last):
@@ -488,11 +499,12 @@ class BasicTransformerBlock(nn.Module):
         a = self.attn2
         (fq,) = _ln_feed(self.norm2, x, [a.to_q])
         kv = self.__dict__.pop("_kv", None)
-        if kv is not None:          # projected ahead of time on the side stream (SDXLUNet.forward)
+        if kv is not None:          # projected ahead of time (SDXLUNet._project_context_ahead)
             k, v, ready = kv
-            torch.cuda.current_stream().wait_event(ready)
-            k.record_stream(torch.cuda.current_stream())
-            v.record_stream(torch.cuda.current_stream())
+            if ready is not None:
+                torch.cuda.current_stream().wait_event(ready)
+                k.record_stream(torch.cuda.current_stream())
+                v.record_stream(torch.cuda.current_stream())
         else:
             k, v = a.to_k(context), a.to_v(context)                 # K/V: BOS path
         x = a.attend_out(_run(a.to_q, fq), k, v, x)                 # x + attn2(norm2(x), ctx)
@@ -660,18 +672,30 @@ class SDXLUNet(nn.Module):
 
     fused = False
 
+    def _grouped(self, name, key, members, w4):
+        """Cached device table of a grouped launch (rebuilt when any member's storage changed)."""
+        from mixdq_amd._C import GemmGroupTable
+        tables = self.__dict__.setdefault("_group_tables", {})
+        want = tuple(m[0].data_ptr() for m in members) + tuple(m[4].data_ptr() for m in members)
+        t = tables.get((name, key))
+        if t is None or t.key != want or t.w4 != bool(w4):
+            t = tables[(name, key)] = GemmGroupTable(members, w4=w4)
+        return t
+
     def _project_context_ahead(self, context):
         """Cross-attention keys / values depend only on the text embeddings, not on the latent: in
-        the fused graph all 2 x 70 to_k / to_v projections run on a side stream, concurrently with
-        the latent path, each block waiting only for its own pair (one event per block).  The
-        INT8 copy of the context (tokens 1.., BOS carve-out) is shared by every layer whose
-        activation quantizer is identical -- they are all calibrated on this same tensor."""
+        the fused graph all 2 x 70 to_k / to_v projections are issued up front -- as ONE grouped
+        launch per activation quantizer (gridDim.y = block; 367 MB of weights streamed at HBM rate
+        instead of 70 latency-bound launches), each writing its block's persistent [B, T, 2C] buffer
+        whose BOS row is a constant.  The INT8 copy of the context (tokens 1.., BOS carve-out) is
+        shared by every layer whose activation quantizer is identical.  (Round 1 ran these on a
+        side stream; measured, a second long-lived branch in the hipGraph costs more than the
+        kernels it hides: 14.96 -> 14.36 ms with both side branches removed.)"""
         blocks = [m for m in self.modules() if isinstance(m, BasicTransformerBlock)]
         if not blocks or not context.is_cuda:
             return
-        if getattr(self, "_kv_stream", None) is None:
-            self._kv_stream = torch.cuda.Stream(device=context.device)
         f16_tail = context.dtype == torch.float16 and context.shape[1] > 1
+        B, T = context.shape[0], context.shape[1]
 
         def bos_w8a8(layer):
             return bool(getattr(layer, "valid_for_acceleration", False)
@@ -681,66 +705,66 @@ class SDXLUNet(nn.Module):
         # comparison ever runs inside the forward proper, so the loop below is capture-safe)
         kv_layers = [l for blk in blocks for l in (blk.attn2.to_k, blk.attn2.to_v) if bos_w8a8(l)]
         gid = dict(zip(map(id, kv_layers), _quantizer_groups(_memo(self), "ctx", kv_layers)))
-        main = torch.cuda.current_stream()
-        side = self._kv_stream
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            shared = {}                       # quantizer group -> int8 context (tokens 1..)
+        shared = {}                       # quantizer group -> int8 context (tokens 1..)
 
-            def ctx_int8(layer):
-                g = gid[id(layer)]
-                if g not in shared:
-                    from mixdq_amd.nn.Linear import quant_op
-                    shared[g] = quant_op(context[:, 1:, :], layer.act_scales_inv,
-                                         layer.act_zero_points)
-                return shared[g]
+        def ctx_int8(layer):
+            g = gid[id(layer)]
+            if g not in shared:
+                from mixdq_amd.nn.Linear import quant_op
+                shared[g] = quant_op(context[:, 1:, :], layer.act_scales_inv,
+                                     layer.act_zero_points)
+            return shared[g]
 
-            for blk in blocks:
-                lk, lv = blk.attn2.to_k, blk.attn2.to_v
-                B, T = context.shape[0], context.shape[1]
-                pack = None
-                if bos_w8a8(lk) and bos_w8a8(lv) and gid[id(lk)] == gid[id(lv)]:
-                    pack = self._kv_pack(blk, context)
-                if pack is not None:        # to_k | to_v as ONE GEMM against [2C, K] (cf. _qkv_fused)
-                    from mixdq_amd.op.qlinear import qlinear
-                    x_int = ctx_int8(lk)
-                    # persistent [B, T, 2C] buffer, BOS row written once (it is a constant)
-                    key = (B, T, context.device, lk.bos_pre_computed.data_ptr(),
-                           lk.bos_pre_computed._version, lv.bos_pre_computed.data_ptr(),
-                           lv.bos_pre_computed._version)
-                    if pack.get("key") != key:
-                        o = torch.empty((B, T, 2 * pack["C"]), dtype=torch.float16,
-                                        device=context.device)
-                        o[:, :1, :] = torch.cat([lk.bos_pre_computed, lv.bos_pre_computed], dim=-1)
-                        pack["key"], pack["out"] = key, o
-                    o = pack["out"]
-                    qlinear(x_int, pack["w"], pack["wscale"], lk.act_scales, lk.act_zero_points,
-                            pack["wsum"], pack["scale"], pack["bias0"], None, _out=o,
-                            _row_map=(T - 1, T, 1), _w4=pack["w4"])
-                    ready = torch.cuda.Event()
-                    ready.record(side)
-                    blk._kv = (o[..., :pack["C"]], o[..., pack["C"]:], ready)
+        grouped = {}                      # (quantizer group, K, w4) -> [(block, pack)]
+        for blk in blocks:
+            lk, lv = blk.attn2.to_k, blk.attn2.to_v
+            pack = None
+            if bos_w8a8(lk) and bos_w8a8(lv) and gid[id(lk)] == gid[id(lv)]:
+                pack = self._kv_pack(blk, context)
+            if pack is not None:        # to_k | to_v as ONE GEMM against [2C, K] (cf. _qkv_fused)
+                # persistent [B, T, 2C] buffer, BOS row written once (it is a constant)
+                key = (B, T, context.device, lk.bos_pre_computed.data_ptr(),
+                       lk.bos_pre_computed._version, lv.bos_pre_computed.data_ptr(),
+                       lv.bos_pre_computed._version)
+                if pack.get("key") != key:
+                    o = torch.empty((B, T, 2 * pack["C"]), dtype=torch.float16,
+                                    device=context.device)
+                    o[:, :1, :] = torch.cat([lk.bos_pre_computed, lv.bos_pre_computed], dim=-1)
+                    pack["key"], pack["out"] = key, o
+                o = pack["out"]
+                blk._kv = (o[..., :pack["C"]], o[..., pack["C"]:], None)
+                grouped.setdefault((gid[id(lk)], lk.in_features, pack["w4"]), []).append((lk, pack))
+                continue
+            outs = []
+            for layer in (lk, lv):
+                if not bos_w8a8(layer):
+                    outs.append(layer(context))
                     continue
-                outs = []
-                for layer in (lk, lv):
-                    if not bos_w8a8(layer):
-                        outs.append(layer(context))
-                        continue
-                    # persistent K / V buffer per layer, BOS row written once: 140 copy kernels
-                    # fewer per step; consumed by this forward's attention only
-                    key = (B, T, context.device, layer.bos_pre_computed.data_ptr(),
-                           layer.bos_pre_computed._version)
-                    buf = layer.__dict__.get("_kv_buf")
-                    if buf is None or buf[0] != key:
-                        o = torch.empty((B, T, layer.out_features), dtype=torch.float16,
-                                        device=context.device)
-                        o[:, :1, :] = layer.bos_pre_computed
-                        buf = layer.__dict__["_kv_buf"] = (key, o)
-                    outs.append(layer.forward_bos_quantized(ctx_int8(layer), B, T, out=buf[1]))
-                ready = torch.cuda.Event()
-                ready.record(side)
-                blk._kv = (outs[0], outs[1], ready)
-        context.record_stream(side)
+                # persistent K / V buffer per layer, BOS row written once
+                key = (B, T, context.device, layer.bos_pre_computed.data_ptr(),
+                       layer.bos_pre_computed._version)
+                buf = layer.__dict__.get("_kv_buf")
+                if buf is None or buf[0] != key:
+                    o = torch.empty((B, T, layer.out_features), dtype=torch.float16,
+                                    device=context.device)
+                    o[:, :1, :] = layer.bos_pre_computed
+                    buf = layer.__dict__["_kv_buf"] = (key, o)
+                outs.append(layer.forward_bos_quantized(ctx_int8(layer), B, T, out=buf[1]))
+            blk._kv = (outs[0], outs[1], None)
+        from mixdq_amd import _C
+        from mixdq_amd.op.qlinear import qlinear
+        for (g, K, w4), members in grouped.items():
+            lk0 = members[0][0]
+            x_int = ctx_int8(lk0)
+            if len(members) == 1:
+                pack = members[0][1]
+                qlinear(x_int, pack["w"], pack["wscale"], lk0.act_scales, lk0.act_zero_points,
+                        pack["wsum"], pack["scale"], pack["bias0"], None, _out=pack["out"],
+                        _row_map=(T - 1, T, 1), _w4=w4)
+                continue
+            table = self._grouped("kv", (g, K, w4, B, T), [
+                (pk["w"], pk["bias0"], pk["scale"], None, pk["out"]) for _, pk in members], w4)
+            _C.qlinear_grouped(x_int, table, _row_map=(T - 1, T, 1))
 
     @staticmethod
     def _kv_pack(blk, context=None):
@@ -767,35 +791,43 @@ class SDXLUNet(nn.Module):
     def _project_temb_ahead(self, emb):
         """Every ResnetBlock2D adds time_emb_proj(silu(emb)): 22 M = batch GEMMs (plus their SiLU
         and quantize launches) that depend only on the time embedding.  In the fused graph they
-        run on the side stream before the keys / values; SiLU runs once, and layers with identical
-        activation quantizers (all calibrated on this same tensor) share one INT8 copy."""
+        are issued up front: SiLU once, one INT8 copy per distinct activation quantizer (the layers
+        are all calibrated on this same tensor) and ONE grouped launch for all layers that share
+        it (gridDim.y = layer; N differs per layer), into persistent [B, Cout] buffers."""
         resnets = [m for m in self.modules() if isinstance(m, ResnetBlock2D)]
         if not resnets or not emb.is_cuda:
             return
-        if getattr(self, "_kv_stream", None) is None:
-            self._kv_stream = torch.cuda.Stream(device=emb.device)
+        s = F.silu(emb)
+        B = s.shape[0]
         acc = [r.time_emb_proj for r in resnets if _accel(r.time_emb_proj)]
+        ok = _fusable_f16(s) and s.dim() == 2
         gid = dict(zip(map(id, acc), _quantizer_groups(_memo(self), "temb", acc)))
-        main = torch.cuda.current_stream()
-        side = self._kv_stream
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            s = F.silu(emb)
-            shared = {}
-            for res in resnets:
-                layer = res.time_emb_proj
-                if _accel(layer) and _fusable_f16(s):
-                    g = gid[id(layer)]
-                    if g not in shared:
-                        from mixdq_amd.nn.Linear import quant_op
-                        shared[g] = quant_op(s, *_qp(layer))
-                    t = layer.forward_quantized(shared[g])
-                else:
-                    t = layer(s)
-                ready = torch.cuda.Event()
-                ready.record(side)
-                res._t = (t, ready)
-        emb.record_stream(side)
+        shared, grouped = {}, {}
+        for res in resnets:
+            layer = res.time_emb_proj
+            if not (_accel(layer) and ok):
+                res._t = (layer(s), None)
+                continue
+            buf = layer.__dict__.get("_t_out")
+            if buf is None or buf.shape[0] != B or buf.device != s.device:
+                buf = layer.__dict__["_t_out"] = torch.empty((B, layer.out_features),
+                                                             dtype=torch.float16, device=s.device)
+            res._t = (buf, None)
+            grouped.setdefault((gid[id(layer)], layer.in_features, bool(layer.w_packed4)),
+                               []).append(layer)
+        from mixdq_amd import _C
+        for (g, K, w4), layers in grouped.items():
+            from mixdq_amd.nn.Linear import quant_op
+            if g not in shared:
+                shared[g] = quant_op(s, *_qp(layers[0]))
+            x_int = shared[g]
+            if len(layers) == 1:
+                layers[0]._gemm(x_int, out=layers[0]._t_out)
+                continue
+            table = self._grouped("temb", (g, K, w4, B), [
+                (m.weight_int4 if w4 else m.weight_int, m.bias0, m.scale, m.bias, m._t_out)
+                for m in layers], w4)
+            _C.qlinear_grouped(x_int, table)
 
     def refresh_derived_(self):
         """After buffers were written IN PLACE (load_state_dict, shard.broadcast_module_state):

@@ -543,3 +543,47 @@ def test_w4_rejects_unaligned_k(C):
     v = torch.zeros(8, device=DEV)
     with pytest.raises(RuntimeError, match="unsupported"):
         C.qlinear_w8_a8_ohalf(a, w, v, scal(0), scal(0), v, v, v, None, _w4=True)
+
+
+# ------------------------------------------------------------------------- grouped launch (f-1)
+@pytest.mark.parametrize("M,K,Ns,row_map,w4", [
+    (76, 2048, [2560, 1280, 2560, 1280, 1280], (76, 77, 1), False),   # k|v projections, BOS rows
+    (152, 2048, [640, 640], (76, 77, 1), False),                      # batch 2
+    (1, 1280, [320, 640, 1280, 1280, 320], None, False),              # time-embedding projections
+    (8, 1280, [320, 1280], None, False),
+    (76, 2048, [1280, 2560], (76, 77, 1), True),                      # packed W4 members
+    (200, 256, [136, 72, 8], None, False),                            # ragged N tails
+])
+def test_qlinear_grouped_members_equal_their_own_launches(C, oracle, M, K, Ns, row_map, w4):
+    """mixdq_qlinear_w8a8_grouped: every member of the one grouped launch gets the oracle's bits
+    (= what its own mixdq_qlinear_w8a8_rows launch gives), with per-member N, bias / no bias, the
+    shared BOS row map, and rows outside the map left untouched."""
+    from mixdq_amd.nn.utils import pack_w4
+    a = dd.int8(101, (M, K))
+    members, wants, outs = [], [], []
+    for i, N in enumerate(Ns):
+        q = dd.int8(110 + i, (N, K), -8 if w4 else -128, 8 if w4 else 128)
+        b0, sc = dd.f32(120 + i, (N,), -300, 300), dd.f32(130 + i, (N,), 1e-4, 1e-3)
+        bias = dd.f16(140 + i, (N,), -1, 1) if i % 2 else None
+        wants.append(oracle.qlinear(a, q, b0, sc, bias, C.FLAGS & 1))
+        wdev = pack_w4(torch.from_numpy(q)).to(DEV) if w4 else t(q)
+        if row_map:
+            g, stride, off = row_map
+            out = torch.full((M // g, stride, N), 7.0, dtype=torch.float16, device=DEV)
+        else:
+            out = torch.full((M, N), 7.0, dtype=torch.float16, device=DEV)
+        outs.append(out)
+        members.append((wdev, t(b0), t(sc), None if bias is None else t(bias), out))
+    table = C.GemmGroupTable(members, w4=w4)
+    for cfg in (0, 37, 35, 41, 4, 56):
+        for o in outs:
+            o.fill_(7.0)
+        C.qlinear_grouped(t(a), table, _row_map=row_map, _cfg=cfg)
+        for i, (o, want) in enumerate(zip(outs, wants)):
+            if row_map:
+                g, stride, off = row_map
+                got = o[:, off:off + g].reshape(M, -1)
+                assert (o[:, :off] == 7.0).all()
+            else:
+                got = o
+            assert_bits_equal(got.contiguous().cpu().numpy(), want, f"member {i} cfg {cfg}")
