@@ -83,20 +83,14 @@ def igemm_select(M: int, N: int, k_align: int, k_total: int = 0):
 
 # Kernel configurations of the INT8 GEMM / conv family (csrc/igemm.hip MIXDQ_IGEMM_CONFIGS):
 # id -> (BM, BN, BK, STAGES).  `_cfg=id` forces one (tuning and tests); 0 = automatic.
-IGEMM_CONFIGS = {1: (64, 64, 64, 2), 2: (64, 128, 64, 2), 3: (128, 128, 64, 2), 4: (64, 64, 128, 3),
-                 6: (64, 128, 128, 3), 7: (128, 128, 128, 3), 13: (256, 128, 64, 3),
-                 14: (256, 256, 64, 3), 15: (128, 256, 64, 3), 18: (256, 128, 128, 2),
-                 20: (256, 256, 128, 2), 25: (128, 320, 128, 2), 35: (128, 128, 64, 3),
-                 37: (64, 64, 128, 3), 41: (64, 128, 128, 3),
+IGEMM_CONFIGS = {1: (64, 64, 64, 2), 3: (128, 128, 64, 2), 4: (64, 64, 128, 3),
+                 13: (256, 128, 64, 3), 14: (256, 256, 64, 3), 15: (128, 256, 64, 3),
+                 18: (256, 128, 128, 2), 20: (256, 256, 128, 2), 25: (128, 320, 128, 2),
+                 35: (128, 128, 64, 3), 37: (64, 64, 128, 3), 41: (64, 128, 128, 3),
                  # 16x16x64-MFMA tiles (exactly one workgroup per CU on the UNet's M = 1024 / 4096
-                 # layers) and the 4-stage 128x320 tile
+                 # layers; 45 / 56: deeper pipelines) and the 4-stage 128x320 tile
                  42: (64, 80, 128, 3), 43: (64, 240, 128, 3), 44: (128, 80, 128, 3),
-                 45: (64, 80, 128, 4), 46: (128, 320, 64, 4), 47: (64, 80, 128, 3),
-                 48: (64, 160, 128, 3),
-                 # deep pipelines (one workgroup per CU: LDS is free for K-tiles in flight)
-                 49: (64, 80, 128, 8), 50: (64, 128, 128, 6), 51: (64, 64, 128, 8),
-                 52: (64, 240, 128, 4), 53: (128, 80, 128, 6), 54: (128, 320, 64, 5),
-                 55: (128, 128, 64, 6), 56: (64, 80, 128, 6)}
+                 45: (64, 80, 128, 4), 46: (128, 320, 64, 4), 56: (64, 80, 128, 6)}
 
 FLAG_W4 = 2   # MIXDQ_FLAG_W4: the weight tensor holds packed signed 4-bit values
 

@@ -338,3 +338,6 @@ def run(unet, args=None, batch_size: int = 1, sample_size: int = 128, cuda_graph
             torch.cuda.nvtx.range_pop()
         torch.cuda.synchronize()
     return latents, rep
+
+
+layers_nvtx_annotate = layers_roctx_annotate   # the reference's name (quantize_sdxl.py:387)

@@ -145,7 +145,7 @@ def test_shared_math_spec_matches_on_device(C, oracle):
 
 GEGLU_GEMM_CASES = [  # M, D, K, forced tile config (0 = automatic), bias
     (1024, 640, 320, 0, True), (96, 64, 64, 4, True), (77, 32, 48, 4, False),
-    (200, 160, 128, 3, True), (200, 160, 128, 6, True), (300, 128, 256, 13, True),
+    (200, 160, 128, 3, True), (200, 160, 128, 41, True), (300, 128, 256, 13, True),
     (513, 256, 192, 18, False), (257, 256, 128, 20, True), (1, 32, 16, 0, True),
     (300, 320, 256, 25, True), (300, 320, 192, 46, True), (130, 160, 128, 46, False),
 ]

@@ -434,7 +434,7 @@ def test_qlinear_residual_epilogue(C, oracle):
     assert torch.equal(fused, plain + t(res))
     want = oracle.add_f16(oracle.qlinear(a, w, b0, sc, bias, C.FLAGS & 1), res)
     assert_bits_equal(fused.cpu().numpy(), want, "residual epilogue")
-    for cfg in (1, 4, 7):
+    for cfg in (1, 4, 35, 41, 45, 20):
         assert torch.equal(C.qlinear_w8_a8_ohalf(*args, _residual=t(res), _cfg=cfg), fused)
 
 
