@@ -340,7 +340,9 @@ def main():
     torch.cuda.synchronize(device)   # persistent K/V buffers are static data, built before the meter
     import gc
     gc.collect()
-    torch.cuda.empty_cache()
+    if hasattr(torch._C, "_cuda_clearCublasWorkspaces"):
+        torch._C._cuda_clearCublasWorkspaces()   # hipBLASLt workspaces of the FP16 legs above: the
+    torch.cuda.empty_cache()                     # quantized step launches no vendor-library kernel
     weight_bytes = sum(b.numel() * b.element_size() for b in unet.buffers()) + sum(
         p.numel() * p.element_size() for p in unet.parameters())
     q_meter = MemoryMeter(device)                 # static = the quantized network, resident
