@@ -217,6 +217,21 @@ int mixdq_geglu_quantize(const void* h_f16, int64_t M, int D,
                          int8_t* out_q_or_null, void* out_f16_or_null, int flags,
                          mixdq_stream_t stream);
 
+/* to_q + cross-attention in ONE launch: the INT8 GEMM of attn2.to_q (no bias) whose fp16 result --
+ * 64 query rows x two heads per workgroup -- never leaves the chip: it is multiplied against the
+ * (at most 128) keys / values of those heads with the arithmetic of mixdq_attention_f16, and the
+ * attention output is written as to_out.0's INT8 operand (out_scale_inv given) or as fp16.
+ * Bit-identical to mixdq_qlinear_w8a8 followed by mixdq_attention_f16.  No reference counterpart.
+ * A [M, K] int8 (M = images x rows_per_image, rows_per_image % 64 == 0), W [N, K] (N % 128 == 0,
+ * heads = N / 64, K % 128 == 0), k / v fp16 [images, tkv, N] with the given strides in elements
+ * (multiples of 8; column slices of a packed k|v projection are fine), tkv <= 128. */
+int mixdq_qlinear_w8a8_attn(const int8_t* A, const int8_t* W, const float* bias0, const float* scale,
+                            const void* k_f16, const void* v_f16, void* out, int64_t M, int N, int K,
+                            int rows_per_image, int tkv, int64_t k_batch_stride, int k_row_stride,
+                            int64_t v_batch_stride, int v_row_stride, float softmax_scale,
+                            const float* out_scale_inv_or_null, const float* out_zero_point_or_null,
+                            int flags, mixdq_stream_t stream);
+
 /* Grouped form of mixdq_qlinear_w8a8_rows: `ngroups` independent Linears that read the SAME int8
  * activations A [M, K] -- the 70 cross-attention k|v projections of the text embeddings, the 22
  * time-embedding projections -- in ONE launch (gridDim.y = member).  No reference counterpart (it

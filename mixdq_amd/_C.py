@@ -307,6 +307,52 @@ def qlinear_grouped(input_int8, table: "GemmGroupTable", *, _row_map=None, _cfg=
     _status(code, "qlinear_grouped")
 
 
+_lib.mixdq_qlinear_w8a8_attn.argtypes = [_vp] * 7 + [_i64, _i32, _i32, _i32, _i32, _i64, _i32, _i64,
+                                          _i32, ctypes.c_float, _vp, _vp, _i32, _vp]
+_lib.mixdq_qlinear_w8a8_attn.restype = _i32
+
+
+def qlinear_attention_supported(x_shape, N, K, k) -> bool:
+    """Shapes the fused to_q + cross-attention launch takes (see qlinear_attention)."""
+    return (len(x_shape) == 3 and N % 128 == 0 and K % 128 == 0 and x_shape[1] % 64 == 0
+            and k.dim() == 3 and 0 < k.shape[1] <= 128 and k.shape[2] == N
+            and x_shape[0] * x_shape[1] * K < 2 ** 32 and N * K < 2 ** 32)
+
+
+def qlinear_attention(input_int8, weight_int8, scale, bias0, k, v, scale_inv=None, zero_point=None,
+                      softmax_scale=None, *, _w4=False):
+    """attn2.to_q (INT8 GEMM, no bias) and the cross-attention core in one launch
+    (mixdq_qlinear_w8a8_attn): input int8 [B, T, K], weight [N, K], k / v fp16 [B, Tkv <= 128, N]
+    with unit stride along N.  Returns the attention output [B, T, N]: int8 (to_out.0's operand)
+    when scale_inv / zero_point are given, else fp16.  Bit-identical to qlinear_w8_a8_ohalf
+    followed by attention_f16."""
+    _check(input_int8.is_cuda and input_int8.dtype == torch.int8 and input_int8.dim() == 3,
+           "input_int8 should be an int8 [B, T, K] GPU tensor")
+    _check(weight_int8.dtype == torch.int8, "weight_int8 should be int8 type")
+    N, K = weight_int8.size(0), weight_int8.size(1) * (2 if _w4 else 1)
+    B, T, _ = input_int8.shape
+    _check(input_int8.size(-1) == K, "The last dimension of input and weight should match")
+    for t, n in ((k, "k"), (v, "v")):
+        _check(t.is_cuda and t.dtype == torch.float16 and t.dim() == 3 and t.stride(-1) == 1
+               and t.shape[0] == B and t.shape[2] == N, f"{n} should be fp16 [B, Tkv, N]")
+    _check(k.shape == v.shape, "k / v shapes disagree")
+    _check(qlinear_attention_supported(input_int8.shape, N, K, k),
+           "qlinear_attention: unsupported configuration (N % 128, K % 128, T % 64, Tkv <= 128)")
+    quant = scale_inv is not None
+    a, w = input_int8.contiguous(), weight_int8.contiguous()
+    out = torch.empty((B, T, N), dtype=torch.int8 if quant else torch.float16, device=a.device)
+    sc, b0 = _f32vec(scale), _f32vec(bias0)
+    ss = float(softmax_scale) if softmax_scale is not None else 0.125
+    with torch.cuda.device(a.device):
+        code = _lib.mixdq_qlinear_w8a8_attn(
+            a.data_ptr(), w.data_ptr(), b0.data_ptr(), sc.data_ptr(), k.data_ptr(), v.data_ptr(),
+            out.data_ptr(), B * T, N, K, T, k.shape[1], k.stride(0), k.stride(1), v.stride(0),
+            v.stride(1), ss, _ptr(scale_inv), _ptr(zero_point),
+            FLAGS | (FLAG_W4 if _w4 else 0), _stream())
+    _status(code, "qlinear_attention")
+    return out
+
+
 _lib.mixdq_qlinear_w8a8_geglu.argtypes = [_vp] * 6 + [_i64, _i32, _i32, _vp, _vp, _i32, _vp]
 _lib.mixdq_qlinear_w8a8_geglu.restype = _i32
 

@@ -21,20 +21,12 @@
 // Softmax in FP32 with base-2 exponentials (v_exp_f32), P rounded to FP16 for the second MFMA, row
 // sums accumulated in FP32 from the unrounded P; O staged through LDS and stored as whole 128-B rows.
 #include "common.h"
+#include "attn_core.h"
 
 namespace mixdq {
 namespace {
 
-typedef _Float16 v8h __attribute__((ext_vector_type(8)));
-typedef float v16f __attribute__((ext_vector_type(16)));
 typedef short v4s16 __attribute__((__vector_size__(4 * sizeof(short))));
-
-constexpr int kHeadDim = 64;
-constexpr int kKeys = 64;            // keys per tile
-constexpr int kRow = 128;            // K and V images: 64 halfs per key, XOR-swizzled 16-B chunks
-constexpr int kTileBytes = kKeys * kRow;          // one K (or V) tile
-constexpr int kStageBytes = 2 * kTileBytes;       // K tile then V tile
-constexpr int kORow = 144;           // output staging row (32 x 144 B per wave)
 
 struct AttnParams {
   const __half* q; const __half* k; const __half* v;
@@ -46,11 +38,6 @@ struct AttnParams {
   int unfused;
 };
 
-__device__ __forceinline__ float half_max(float x) {
-  // max over lanes l and l^32
-  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
 __device__ __forceinline__ float half_sum(float x) {
   auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
@@ -60,22 +47,6 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
   __builtin_amdgcn_global_load_lds(
       (const __attribute__((address_space(1))) void*)gsrc,
       (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-
-typedef int v2i __attribute__((ext_vector_type(2)));
-union VFrag { struct { v2i lo, hi; } r; v8h h; };
-
-// Two transposed reads (keys k..k+3 and k+8..k+11 of 16 output columns) = one A operand.
-template <int OFF>
-__device__ __forceinline__ void tr_read2_imm(VFrag& f, unsigned addr) {
-  asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"
-               : "=&v"(f.r.lo), "=&v"(f.r.hi)
-               : "v"(addr), "n"(OFF), "n"(OFF + 8 * kRow)
-               : "memory");
-}
-__device__ __forceinline__ void s_waitcnt_lgkm0() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);   // keep register-only MFMAs behind the wait
 }
 
 template <int WAVES, int STAGES, bool QUANT, bool RAGGED>

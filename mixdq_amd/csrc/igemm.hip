@@ -27,10 +27,12 @@
 #include <vector>
 
 #include "common.h"
+#include "attn_core.h"
 #include "../../include/mixdq_math.h"
 
 // MIXDQ_ABLATE (diagnostic builds only, tools/ablate.sh): 1 = no MFMA, 2 = no LDS fragment reads,
 // 3 = no LDS-DMA in the main loop, 4 = no output stores.  Results are garbage; the timing shows what the loop waits for.
+#define NWAVES_OF(WM, WN, KSPLIT) ((WM) * (WN) * (KSPLIT))
 #ifndef MIXDQ_ABLATE
 #define MIXDQ_ABLATE 0
 #endif
@@ -67,6 +69,16 @@ struct IgemmParams {
   // output and N replace the fields above (A, M, K, the row map and the flags are shared).
   const mixdq_gemm_group* groups;
   int ngroups_launch;    // host side only: gridDim.y
+  // Cross-attention epilogue (ATT kernels; att_out != null): the tile's fp16 result is to_q's
+  // output for 64 query rows x two heads; instead of being stored it is multiplied against the
+  // (<= 128) keys / values of those heads, and the attention output leaves as to_out.0's INT8
+  // operand (or fp16 when att_sinv is null).
+  const __half* att_k; const __half* att_v;    // [B, tkv, N] fp16 (column slices allowed)
+  int64_t att_k_bs, att_v_bs;                  // batch strides, elements
+  int att_k_rs, att_v_rs, att_tkv, att_tq;     // row strides (elements), keys, query rows per image
+  float att_scale_log2;
+  void* att_out;                               // [M, N] int8 or fp16
+  const float* att_sinv; const float* att_zp;
 };
 
 template <int BK>
@@ -132,8 +144,10 @@ __device__ __forceinline__ uint32_t add_f16x2(uint32_t a, uint32_t b) {
 // Used for the layers the reference leaves in FP16 (no activation quantizer: conv_in / conv_out,
 // the act-protected ff.net.2 ..., nn/Linear.py:155-156): D = f16(acc + bias) [+ residual].
 template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool CONV, bool FAST, bool W4,
-          int KSPLIT = 1, int MT = 32, bool F16 = false>
+          int KSPLIT = 1, int MT = 32, bool F16 = false, bool ATT = false>
 __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const IgemmParams p_in) {
+  static_assert(!ATT || (BM == 64 && BN == 128 && NWAVES_OF(WM, WN, KSPLIT) == 8 && MT == 32 && !CONV &&
+                         !F16), "the attention epilogue is written for the 64x128 8-wave tile");
   static_assert(!(CONV && FAST), "the fast staging path is for Linear");
   IgemmParams p = p_in;
   int nwg = gridDim.x;
@@ -404,6 +418,29 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const Igem
   //      buffer (kt-1) % STAGES is no longer read, so tile kt+PRE may be staged into it.
   //      Tiles past the end of K stage zero-page reads so the count stays uniform.
   const int nk = (Ktot + BK - 1) / BK;
+  // ATT: the keys / values of this tile's two heads (two 64-key tiles each, K image then V image,
+  // the layout of csrc/attention.hip) are requested first -- 8 DMA pieces per wave, older than
+  // every K-tile piece, so the counted waits below retire them without further bookkeeping --
+  // into LDS behind the stage buffers and the epilogue vectors.
+  constexpr int ATT_OFF = ((igemm_smem_bytes<BM, BN, BK, STAGES>() + 1023) / 1024) * 1024;
+  if constexpr (ATT) {
+    const int hl = wid >> 2, part = wid & 3;            // head of the pair; (tile, K | V)
+    const int t = part >> 1;
+    const bool is_v = part & 1;
+    const int64_t img = m0 / p.att_tq;                   // a tile never straddles two images
+    const int rs = is_v ? p.att_v_rs : p.att_k_rs;
+    const __half* base = (is_v ? p.att_v + img * p.att_v_bs : p.att_k + img * p.att_k_bs) +
+                         (n0 + hl * kHeadDim);
+    const int srow = lane >> 3, spos = lane & 7;
+    char* dst = smem + ATT_OFF + hl * (2 * kStageBytes) + t * kStageBytes + (is_v ? kTileBytes : 0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int krow = i * 8 + srow;                     // key row within the tile
+      const int sw = is_v ? ((krow >> 1) & 1) << 2 : (krow >> 1) & 7;
+      const int key = min(t * kKeys + krow, p.att_tkv - 1);   // absent keys: finite, masked below
+      glds16(base + ((int64_t)key * rs + (spos ^ sw) * 8), dst + i * 1024);
+    }
+  }
 #pragma unroll
   for (int s = 0; s < PRE; ++s) stage(s, s * BK);
 
@@ -612,6 +649,153 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const Igem
     }
   }
   __syncthreads();
+  if constexpr (ATT) {
+    // ---- cross-attention on the staged tile: wave w < 4 owns head (w >> 1) of the pair and 32 of
+    //      the 64 query rows; arithmetic and order are those of attn_fwd_kernel (csrc/attention.hip)
+    //      for two key tiles, so the result is bit-identical to to_q followed by that kernel.
+    const int l32 = lane & 31, hh = lane >> 5;
+    const int hl = wid >> 1, rg = wid & 1;
+    v8h qf[4];
+    if (wid < 4) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        qf[ks] = *reinterpret_cast<const v8h*>(Cs + (rg * 32 + l32) * CS_STRIDE +
+                                               (hl * kHeadDim + ks * 16 + hh * 8) * 2);
+    }
+    __syncthreads();                   // the fp16 tile is consumed: its LDS becomes output staging
+    if (wid >= 4) return;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    const unsigned kv0 = lds0 + ATT_OFF + hl * (2 * kStageBytes);
+    unsigned k_a[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) k_a[ks] = kv0 + l32 * kRow + (((2 * ks + hh) ^ ((l32 >> 1) & 7)) << 4);
+    const int q4 = (lane & 15) >> 2, pp = lane & 3, g16 = (lane >> 4) & 1;
+    const int v_rd0 = kTileBytes + (4 * hh + q4) * kRow +
+                      (((2 * g16 + (pp >> 1)) ^ (((q4 >> 1) & 1) << 2)) << 4) + 8 * (pp & 1);
+    const unsigned v_a0 = kv0 + v_rd0, v_a1 = kv0 + (v_rd0 ^ 64);
+    const int ntiles = (p.att_tkv + kKeys - 1) / kKeys;
+    v16f o[2], lsum;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; lsum[i] = 0.f; }
+    float m_i = -INFINITY;
+    const float c = p.att_scale_log2;
+    v8h ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (_Float16)1.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      if (t >= ntiles) break;
+      VFrag vf[2][2][2];
+      {
+        const unsigned a0 = v_a0 + t * kStageBytes, a1 = v_a1 + t * kStageBytes;
+        tr_read2_imm<0 * kRow>(vf[0][0][0], a0);
+        tr_read2_imm<0 * kRow>(vf[0][0][1], a1);
+        tr_read2_imm<16 * kRow>(vf[0][1][0], a0);
+        tr_read2_imm<16 * kRow>(vf[0][1][1], a1);
+        tr_read2_imm<32 * kRow>(vf[1][0][0], a0);
+        tr_read2_imm<32 * kRow>(vf[1][0][1], a1);
+        tr_read2_imm<48 * kRow>(vf[1][1][0], a0);
+        tr_read2_imm<48 * kRow>(vf[1][1][1], a1);
+      }
+      v16f sc[2];
+      {
+        v8h kf[2][4];
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+            kf[kb][ks] = *(const __attribute__((address_space(3))) v8h*)(size_t)(
+                k_a[ks] + (t * kStageBytes + kb * 32 * kRow));
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+          for (int i = 0; i < 16; ++i) sc[kb][i] = 0.f;
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+            sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][ks], qf[ks], sc[kb], 0, 0, 0);
+        }
+      }
+      if (t == ntiles - 1 && (p.att_tkv & (kKeys - 1)) != 0) {   // mask the absent keys
+        const int lim = p.att_tkv - t * kKeys - 4 * hh;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (32 * kb + 8 * (r >> 2) + (r & 3) >= lim) sc[kb][r] = -INFINITY;
+      }
+      float mx = sc[0][0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[0][r]);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[1][r]);
+      mx = half_max(mx);
+      const float m_new = fmaxf(m_i, mx);
+      const bool grew = m_new > m_i;
+      const float mc = m_new * c;
+      v8h pf[2][2];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          pf[kb][r >> 3][r & 7] =
+              (_Float16)__builtin_amdgcn_exp2f(__builtin_fmaf(sc[kb][r], c, -mc));
+      if (__builtin_amdgcn_ballot_w64(grew)) {
+        const float alpha = __builtin_amdgcn_exp2f((m_i - m_new) * c);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+        lsum[0] *= alpha;
+      }
+      m_i = m_new;
+      s_waitcnt_lgkm0();
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+          for (int db = 0; db < 2; ++db)
+            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[kb][u][db].h, pf[kb][u], o[db], 0, 0, 0);
+          lsum = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf[kb][u], lsum, 0, 0, 0);
+        }
+    }
+    // normalise, stage through LDS (per wave), store whole 64-column head rows
+    const float inv = 1.f / lsum[0];
+    char* Os = smem + wid * (32 * kORow);
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        v4h w;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) w[j] = (_Float16)(o[db][4 * g + j] * inv);
+        *reinterpret_cast<v4h*>(Os + l32 * kORow + (32 * db + 8 * g + 4 * hh) * 2) = w;
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private staging: no block barrier
+    const bool quant = p.att_sinv != nullptr;
+    const float s_inv = quant ? *p.att_sinv : 0.f, zpq = quant ? *p.att_zp : 0.f;
+    const bool unf = p.unfused != 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int id = lane + 64 * i, row = id >> 3, ch = id & 7;
+      const int64_t m = m0 + rg * 32 + row;
+      if (m >= p.M) continue;
+      const uint4 w = *reinterpret_cast<const uint4*>(Os + row * kORow + ch * 16);
+      const int64_t off = m * p.N + n0 + hl * kHeadDim + ch * 8;
+      if (!quant) {
+        *reinterpret_cast<uint4*>(reinterpret_cast<__half*>(p.att_out) + off) = w;
+      } else {
+        const __half* hv = reinterpret_cast<const __half*>(&w);
+        uint32_t pk[2] = {0u, 0u};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float x = __half2float(hv[j]);
+          const int qv = unf ? quantize_one<true>(x, s_inv, zpq) : quantize_one<false>(x, s_inv, zpq);
+          pk[j >> 2] |= (uint32_t)(qv & 0xff) << (8 * (j & 3));
+        }
+        *reinterpret_cast<uint2*>(reinterpret_cast<int8_t*>(p.att_out) + off) = make_uint2(pk[0], pk[1]);
+      }
+    }
+    return;
+  }
   if constexpr (BN % 64 == 0) if (p.Dq != nullptr) {
     // GEGLU + quantize on the staged fp16 tile: every rounding point of the unfused chain
     // (GEMM -> fp16, gelu -> fp16, product -> fp16, quantize) is kept, so the int8 tensor is the
@@ -993,6 +1177,27 @@ int dispatch(IgemmParams& p, hipStream_t stream, int forced_cfg) {
   }
 }
 
+// to_q GEMM + cross-attention epilogue: the 64x128x128 8-wave tile (two heads per tile), Linear
+// fast path only.
+template <bool W4>
+int launch_att(IgemmParams& p, hipStream_t stream) {
+  constexpr int BM = 64, BN = 128, BK = 128, ST = 3;
+  constexpr int SMEM = ((igemm_smem_bytes<BM, BN, BK, ST>() + 1023) / 1024) * 1024 + 4 * kStageBytes;
+  static_assert(SMEM <= 160 * 1024, "LDS is 160 KiB per CU");
+  static const hipError_t attr = hipFuncSetAttribute(
+      reinterpret_cast<const void*>(
+          &igemm_kernel<BM, BN, BK, ST, 2, 4, false, true, W4, 1, 32, false, true>),
+      hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
+  if (attr != hipSuccess) return MIXDQ_ERR_LAUNCH;
+  p.tiles_m = (int)((p.M + BM - 1) / BM);
+  p.tiles_n = (p.N + BN - 1) / BN;
+  const int64_t grid = (int64_t)p.tiles_m * p.tiles_n;
+  if (grid <= 0 || grid > 0x7fffffff) return MIXDQ_ERR_INVALID_ARG;
+  igemm_kernel<BM, BN, BK, ST, 2, 4, false, true, W4, 1, 32, false, true>
+      <<<dim3((unsigned)grid), 512, SMEM, stream>>>(p);
+  return launch_status();
+}
+
 template <bool W4>
 int dispatch_grouped(IgemmParams& p, int ngroups, hipStream_t stream, int cfg) {
   p.ngroups_launch = ngroups;
@@ -1171,6 +1376,44 @@ extern "C" int mixdq_qlinear_w8a8_grouped(const int8_t* A, const mixdq_gemm_grou
   if (cfg == 0) cfg = M <= 64 ? 37 : 35;
   return w4 ? dispatch_grouped<true>(p, ngroups, (hipStream_t)stream, cfg)
             : dispatch_grouped<false>(p, ngroups, (hipStream_t)stream, cfg);
+}
+
+extern "C" int mixdq_qlinear_w8a8_attn(const int8_t* A, const int8_t* W, const float* bias0,
+                                       const float* scale, const void* k_f16, const void* v_f16,
+                                       void* out, int64_t M, int N, int K, int rows_per_image,
+                                       int tkv, int64_t k_batch_stride, int k_row_stride,
+                                       int64_t v_batch_stride, int v_row_stride,
+                                       float softmax_scale, const float* out_scale_inv_or_null,
+                                       const float* out_zero_point_or_null, int flags,
+                                       mixdq_stream_t stream) {
+  if (M < 0 || N < 0 || K < 0 || rows_per_image <= 0 || tkv <= 0) return MIXDQ_ERR_INVALID_ARG;
+  if (M == 0 || N == 0) return MIXDQ_OK;
+  if (!A || !W || !bias0 || !scale || !k_f16 || !v_f16 || !out) return MIXDQ_ERR_INVALID_ARG;
+  if ((out_scale_inv_or_null == nullptr) != (out_zero_point_or_null == nullptr))
+    return MIXDQ_ERR_INVALID_ARG;
+  const bool w4 = flags & MIXDQ_FLAG_W4;
+  // whole head pairs per tile, whole 64-row tiles per image, at most two key tiles, fast staging
+  if (N % 128 != 0 || K % 128 != 0 || rows_per_image % 64 != 0 || M % rows_per_image != 0 ||
+      tkv > 2 * kKeys || (uint64_t)M * (uint64_t)K >= (1ull << 32) ||
+      (uint64_t)N * (uint64_t)K >= (1ull << 32))
+    return MIXDQ_ERR_SHAPE;
+  if (k_row_stride % 8 || v_row_stride % 8 || k_batch_stride % 8 || v_batch_stride % 8 ||
+      (((uintptr_t)A | (uintptr_t)W | (uintptr_t)k_f16 | (uintptr_t)v_f16 | (uintptr_t)bias0 |
+        (uintptr_t)scale) & 15) || ((uintptr_t)out & (out_scale_inv_or_null ? 7 : 15)))
+    return MIXDQ_ERR_ALIGNMENT;
+  IgemmParams p{};
+  p.A = A; p.Wt = W; p.bias0 = bias0; p.scale = scale;
+  p.M = M; p.N = N; p.Ktot = K;
+  p.H = p.W = p.P = p.Q = 1; p.C = K; p.R = p.S = 1; p.stride = 1; p.pad = 0;
+  p.res_div = 1;
+  p.unfused = (flags & MIXDQ_FLAG_UNFUSED) ? 1 : 0;
+  p.att_k = (const __half*)k_f16; p.att_v = (const __half*)v_f16;
+  p.att_k_bs = k_batch_stride; p.att_v_bs = v_batch_stride;
+  p.att_k_rs = k_row_stride; p.att_v_rs = v_row_stride;
+  p.att_tkv = tkv; p.att_tq = rows_per_image;
+  p.att_scale_log2 = softmax_scale * 1.4426950408889634f;
+  p.att_out = out; p.att_sinv = out_scale_inv_or_null; p.att_zp = out_zero_point_or_null;
+  return w4 ? launch_att<true>(p, (hipStream_t)stream) : launch_att<false>(p, (hipStream_t)stream);
 }
 
 extern "C" int mixdq_qlinear_w8a8(const int8_t* A, const int8_t* W, const float* bias0,

@@ -366,6 +366,19 @@ class Attention(nn.Module):
         o = F.scaled_dot_product_attention(q, k, v)   # FP16, as in the reference
         return o.transpose(1, 2).reshape(B, T, C)
 
+    def cross_attend_out(self, feed_q, k, v, residual):
+        """residual + to_out[0](attention(to_q(feed_q), k, v)) for the cross-attention, whose keys /
+        values (77 text tokens) fit one workgroup's LDS: to_q's INT8 GEMM, the attention core and
+        to_out.0's quantizer are ONE launch; q never exists in memory.  Bit-identical to the
+        three-step path it replaces (tests/test_fused_gpu.py)."""
+        if _cross_fusable(self, feed_q, k, v, residual):
+            from mixdq_amd import _C
+            q, out = self.to_q, self.to_out[0]
+            o_int = _C.qlinear_attention(feed_q[0], q.weight_int4 if q.w_packed4 else q.weight_int,
+                                         q.scale, q.bias0, k, v, *_qp(out), _w4=q.w_packed4)
+            return out.forward_quantized(o_int, residual=residual)
+        return self.attend_out(_run(self.to_q, feed_q), k, v, residual)
+
     def attend_out(self, q, k, v, residual):
         """residual + to_out[0](attention(q, k, v)) on the fused path: the HIP FP16 attention core
         reads q/k/v in place (column slices of the fused projection included) and, when to_out[0]
@@ -382,6 +395,20 @@ class Attention(nn.Module):
             o_int = _C.attention_f16(q, k, v, self.heads, *_qp(out))
             return out.forward_quantized(o_int, residual=residual)
         return out(_C.attention_f16(q, k, v, self.heads)) + residual
+
+
+def _cross_fusable(attn, feed, k, v, residual) -> bool:
+    """to_q + cross-attention + quantize for to_out.0 as ONE launch (mixdq_qlinear_w8a8_attn)?"""
+    from mixdq_amd import _C
+    q, out = attn.to_q, attn.to_out[0]
+    t, quantized = feed
+    return bool(quantized and _accel(q) and q.bias is None and _accel(out) and t.dim() == 3
+                and attn.heads * 64 == q.out_features and residual.is_contiguous()
+                and all(_fusable_f16(z) and z.dim() == 3 and z.stride(-1) == 1
+                        and z.stride(0) % 8 == 0 and z.stride(1) % 8 == 0
+                        and z.data_ptr() % 16 == 0 for z in (k, v))
+                and k.shape == v.shape and k.shape[0] == t.shape[0]
+                and _C.qlinear_attention_supported(t.shape, q.out_features, q.in_features, k))
 
 
 class GEGLU(nn.Module):
@@ -507,7 +534,7 @@ class BasicTransformerBlock(nn.Module):
                 v.record_stream(torch.cuda.current_stream())
         else:
             k, v = a.to_k(context), a.to_v(context)                 # K/V: BOS path
-        x = a.attend_out(_run(a.to_q, fq), k, v, x)                 # x + attn2(norm2(x), ctx)
+        x = a.cross_attend_out(fq, k, v, x)                         # x + attn2(norm2(x), ctx)
         (ff,) = _ln_feed(self.norm3, x, [self.ff.net[0].proj])
         return self.ff.forward_fused(ff, x)                         # x + ff(norm3(x))
 

@@ -214,3 +214,61 @@ def test_qlinear_geglu_w4_equals_oracle_chain_on_unpacked_weights(C, oracle, M, 
     got = C.qlinear_geglu(t(a), packed.to(DEV)[perm].contiguous(), t(scale)[perm].contiguous(),
                           t(bias0)[perm].contiguous(), None, scal(s_inv), scal(zp), _cfg=cfg, _w4=True)
     assert np.array_equal(got.cpu().numpy(), q_ref)
+
+
+# ----------------------------------------------- to_q + cross-attention in one launch (f-1)
+QATT_CASES = [  # B, T (query rows per image), C = heads * 64, K, Tkv, packed k|v?, quantized out?
+    (1, 1024, 1280, 1280, 77, True, True), (2, 256, 640, 640, 77, True, True),
+    (1, 64, 128, 128, 77, False, False), (1, 128, 256, 384, 128, False, True),
+    (3, 64, 128, 256, 64, True, False), (1, 192, 256, 128, 13, False, True),
+    (1, 4096, 640, 640, 77, True, True),
+]
+
+
+@pytest.mark.parametrize("case", QATT_CASES, ids=[f"b{c[0]}_t{c[1]}_c{c[2]}_k{c[3]}_kv{c[4]}" for c in QATT_CASES])
+def test_qlinear_attention_equals_to_q_then_attention(C, oracle, case):
+    """mixdq_qlinear_w8a8_attn == mixdq_qlinear_w8a8 (to_q, bit-exact vs the oracle elsewhere)
+    followed by mixdq_attention_f16, bit for bit -- fp16 output and the fused INT8 output -- and
+    within the attention tolerance of the float64 oracle."""
+    B, T, Cc, K, Tkv, packed, quant = case
+    a = dd.int8(201, (B, T, K))
+    w = dd.int8(202, (Cc, K))
+    scale, bias0 = dd.f32(203, (Cc,), 1e-5, 6e-5), dd.f32(204, (Cc,), -300, 300)
+    if packed:   # column slices of a packed k|v projection, BOS-style rows
+        kv = t(dd.normal_f16(205, (B, Tkv, 2 * Cc), 1.0))
+        k, v = kv[..., :Cc], kv[..., Cc:]
+    else:
+        k, v = t(dd.normal_f16(206, (B, Tkv, Cc), 1.0)), t(dd.normal_f16(207, (B, Tkv, Cc), 1.0))
+    s_inv, zp = scal(30.0), scal(-3.0)
+    q = C.qlinear_w8_a8_ohalf(t(a), t(w), t(scale), scal(1), scal(0), t(bias0), t(scale), t(bias0), None)
+    want_h = C.attention_f16(q, k, v, Cc // 64)
+    got_h = C.qlinear_attention(t(a), t(w), t(scale), t(bias0), k, v)
+    assert got_h.dtype == torch.float16 and tuple(got_h.shape) == (B, T, Cc)
+    assert torch.equal(got_h, want_h), f"{(got_h != want_h).sum().item()} of {got_h.numel()} differ"
+    if quant:
+        want_q = C.attention_f16(q, k, v, Cc // 64, s_inv, zp)
+        got_q = C.qlinear_attention(t(a), t(w), t(scale), t(bias0), k, v, s_inv, zp)
+        assert got_q.dtype == torch.int8 and torch.equal(got_q, want_q)
+    if B * T <= 1024:
+        _, ref = oracle.attention_f16(q.cpu().numpy(), k.cpu().numpy(), v.cpu().numpy(), Cc // 64)
+        err = np.abs(got_h.cpu().numpy().astype(np.float64) - ref)
+        assert (err <= 2e-3 + 4e-3 * np.abs(ref)).all(), err.max()
+
+
+def test_qlinear_attention_w4_and_argument_checks(C):
+    from mixdq_amd.nn.utils import pack_w4
+    B, T, Cc, K, Tkv = 1, 128, 128, 256, 77
+    a = t(dd.int8(211, (B, T, K)))
+    qw = dd.int8(212, (Cc, K), -8, 8)
+    scale, bias0 = t(dd.f32(213, (Cc,), 1e-4, 6e-4)), t(dd.f32(214, (Cc,), -30, 30))
+    k, v = t(dd.normal_f16(215, (B, Tkv, Cc), 1.0)), t(dd.normal_f16(216, (B, Tkv, Cc), 1.0))
+    q = C.qlinear_w8_a8_ohalf(a, t(qw), scale, scal(1), scal(0), bias0, scale, bias0, None)
+    want = C.attention_f16(q, k, v, 2, scal(20.0), scal(1.0))
+    got = C.qlinear_attention(a, pack_w4(torch.from_numpy(qw)).to(DEV), scale, bias0, k, v, scal(20.0),
+                              scal(1.0), _w4=True)
+    assert torch.equal(got, want)
+    with pytest.raises(RuntimeError, match="unsupported configuration"):
+        C.qlinear_attention(a[:, :100], t(qw), scale, bias0, k, v)            # T % 64
+    k200 = t(dd.normal_f16(217, (B, 200, Cc), 1.0))
+    with pytest.raises(RuntimeError, match="unsupported configuration"):
+        C.qlinear_attention(a, t(qw), scale, bias0, k200, k200)               # Tkv > 128
