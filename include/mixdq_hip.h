@@ -201,6 +201,17 @@ int mixdq_groupnorm_silu_quantize(const void* x_nhwc_f16, const void* gamma_f16,
                                   int N, int64_t HW, int C, int G, int flags,
                                   mixdq_stream_t stream);
 
+/* The same on a channel concatenation that is never made in memory (an up-block's
+ * cat([hidden, skip], dim=1)): channels 0 .. C1-1 are read from x [N, HW, C1], the remaining C - C1
+ * from x2 [N, HW, C - C1] (C1 % 8 == 0; C1 == C and x2 == null: one source).  Every output is what
+ * mixdq_groupnorm_silu_quantize gives on the concatenated tensor. */
+int mixdq_groupnorm_silu_quantize2(const void* x_nhwc_f16, int C1, const void* x2_nhwc_f16_or_null,
+                                   const void* gamma_f16, const void* beta_f16, float eps,
+                                   int apply_silu, const float* scale_inv, const float* zero_point,
+                                   int8_t* out_q_or_null, void* out_f16_or_null, void* workspace,
+                                   int N, int64_t HW, int C, int G, int flags,
+                                   mixdq_stream_t stream);
+
 /* LayerNorm over the last dimension of x [M, C] (fp16) + up to three quantizers of the same
  * normalised FP16 value (to_q / to_k / to_v have their own activation scales).  HOST arrays of
  * n_out device pointers.  C % 8 == 0, C <= 2048. */

@@ -53,10 +53,20 @@ struct GnGeom {
   int ppb;      // pixels per block (multiple of PP)
   int nchunk;   // blocks per image
   int ppb_apply, nchunk_apply;   // apply pass split (elementwise: order-free; = the statistics')
+  int C1;       // two-source input (a skip connection never concatenated in memory): channels
+                // 0 .. C1-1 come from x [N, HW, C1], the rest from x2 [N, HW, C - C1]; C1 == C: one
 };
 
-__global__ void gn_stats_kernel(const __half* __restrict__ x, float2* __restrict__ partial,
-                                GnGeom g) {
+// this thread's channel octet: source row pointer of pixel 0 of image n and the row stride
+__device__ __forceinline__ const __half* gn_src(const __half* x, const __half* x2, const GnGeom& g,
+                                                int n, int o, int& stride) {
+  if (8 * o < g.C1) { stride = g.C1; return x + ((int64_t)n * g.HW) * g.C1 + 8 * o; }
+  stride = g.C - g.C1;
+  return x2 + ((int64_t)n * g.HW) * stride + (8 * o - g.C1);
+}
+
+__global__ void gn_stats_kernel(const __half* __restrict__ x, const __half* __restrict__ x2,
+                                float2* __restrict__ partial, GnGeom g) {
   extern __shared__ float lds[];   // [blockDim][4]: s0, q0, s1, q1
   const int t = threadIdx.x;
   const int o = t % g.OC, pp = t / g.OC;
@@ -65,10 +75,11 @@ __global__ void gn_stats_kernel(const __half* __restrict__ x, float2* __restrict
   const int jb = min(8, (g0 + 1) * g.cg - 8 * o);
   const int64_t p_begin = (int64_t)chunk * g.ppb;
   const int64_t p_end = min(g.HW, p_begin + g.ppb);
-  const __half* base = x + ((int64_t)n * g.HW) * g.C + 8 * o;
+  int xs;
+  const __half* base = gn_src(x, x2, g, n, o, xs);
   float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
   for (int64_t p = p_begin + pp; p < p_end; p += g.PP) {
-    const Half8 h = *reinterpret_cast<const Half8*>(base + p * g.C);
+    const Half8 h = *reinterpret_cast<const Half8*>(base + p * xs);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const float v = half_at(h, j);
@@ -134,7 +145,8 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float2* __restric
 }
 
 template <bool SILU, bool UNFUSED>
-__global__ void gn_apply_kernel(const __half* __restrict__ x, const float2* __restrict__ partial,
+__global__ void gn_apply_kernel(const __half* __restrict__ x, const __half* __restrict__ x2,
+                                const float2* __restrict__ partial,
                                 const float2* __restrict__ stats, float eps,
                                 const __half* __restrict__ gamma,
                                 const __half* __restrict__ beta,
@@ -175,8 +187,10 @@ __global__ void gn_apply_kernel(const __half* __restrict__ x, const float2* __re
   const int64_t p_begin = (int64_t)chunk * g.ppb_apply;
   const int64_t p_end = min(g.HW, p_begin + g.ppb_apply);
   const int64_t img = ((int64_t)n * g.HW) * g.C + 8 * o;
+  int xs;
+  const __half* src = gn_src(x, x2, g, n, o, xs);
   for (int64_t p = p_begin + pp; p < p_end; p += g.PP) {
-    const Half8 h = *reinterpret_cast<const Half8*>(x + img + p * g.C);
+    const Half8 h = *reinterpret_cast<const Half8*>(src + p * xs);
     Half8 oh;
     Char8 oq;
     oq.w[0] = oq.w[1] = 0;
@@ -210,6 +224,7 @@ inline bool make_gn_geom(int N, int64_t HW, int C, int G, GnGeom& g) {
   g.nchunk = (int)((HW + ppb - 1) / ppb);
   g.ppb_apply = g.ppb;
   g.nchunk_apply = g.nchunk;
+  g.C1 = C;
   return true;
 }
 
@@ -345,14 +360,37 @@ extern "C" size_t mixdq_groupnorm_workspace_bytes(int N, int64_t HW, int C, int 
   return ((size_t)N * g.nchunk * G + (size_t)N * G) * sizeof(float2);
 }
 
+extern "C" int mixdq_groupnorm_silu_quantize2(const void* x_nhwc, int C1, const void* x2_nhwc,
+                                              const void* gamma, const void* beta, float eps,
+                                              int apply_silu, const float* scale_inv,
+                                              const float* zero_point, int8_t* out_q_or_null,
+                                              void* out_f16_or_null, void* workspace, int N,
+                                              int64_t HW, int C, int G, int flags,
+                                              mixdq_stream_t stream_);
+
 extern "C" int mixdq_groupnorm_silu_quantize(const void* x_nhwc, const void* gamma,
                                              const void* beta, float eps, int apply_silu,
                                              const float* scale_inv, const float* zero_point,
                                              int8_t* out_q_or_null, void* out_f16_or_null,
                                              void* workspace, int N, int64_t HW, int C, int G,
                                              int flags, mixdq_stream_t stream_) {
+  return mixdq_groupnorm_silu_quantize2(x_nhwc, C, nullptr, gamma, beta, eps, apply_silu, scale_inv,
+                                        zero_point, out_q_or_null, out_f16_or_null, workspace, N, HW,
+                                        C, G, flags, stream_);
+}
+
+extern "C" int mixdq_groupnorm_silu_quantize2(const void* x_nhwc, int C1, const void* x2_nhwc,
+                                              const void* gamma, const void* beta, float eps,
+                                              int apply_silu, const float* scale_inv,
+                                              const float* zero_point, int8_t* out_q_or_null,
+                                              void* out_f16_or_null, void* workspace, int N,
+                                              int64_t HW, int C, int G, int flags,
+                                              mixdq_stream_t stream_) {
   GnGeom g;
   if (!make_gn_geom(N, HW, C, G, g)) return MIXDQ_ERR_SHAPE;
+  if (C1 <= 0 || C1 > C || C1 % 8 != 0) return MIXDQ_ERR_SHAPE;
+  if ((C1 < C) != (x2_nhwc != nullptr) || ((uintptr_t)x2_nhwc % 16)) return MIXDQ_ERR_INVALID_ARG;
+  g.C1 = C1;
   if (!x_nhwc || !gamma || !beta || !workspace || (!out_q_or_null && !out_f16_or_null))
     return MIXDQ_ERR_INVALID_ARG;
   if (out_q_or_null && (!scale_inv || !zero_point)) return MIXDQ_ERR_INVALID_ARG;
@@ -363,7 +401,7 @@ extern "C" int mixdq_groupnorm_silu_quantize(const void* x_nhwc, const void* gam
   float2* partial = (float2*)workspace;
   const int threads = g.OC * g.PP;
   gn_stats_kernel<<<dim3(g.nchunk, N), threads, threads * 4 * sizeof(float), stream>>>(
-      (const __half*)x_nhwc, partial, g);
+      (const __half*)x_nhwc, (const __half*)x2_nhwc, partial, g);
   float2* stats = nullptr;          // null: the apply blocks finalize themselves (<= 64 partials)
   if (g.nchunk > 64) {
     stats = partial + (size_t)N * g.nchunk * G;
@@ -373,7 +411,8 @@ extern "C" int mixdq_groupnorm_silu_quantize(const void* x_nhwc, const void* gam
   const bool unfused = flags & MIXDQ_FLAG_UNFUSED;
 #define GN_APPLY(S, U)                                                                          \
   gn_apply_kernel<S, U><<<grid, threads, 0, stream>>>(                                          \
-      (const __half*)x_nhwc, partial, stats, eps, (const __half*)gamma, (const __half*)beta,    \
+      (const __half*)x_nhwc, (const __half*)x2_nhwc, partial, stats, eps, (const __half*)gamma, \
+      (const __half*)beta,                                                                      \
       scale_inv, zero_point, out_q_or_null, (__half*)out_f16_or_null, g)
   if (apply_silu) { if (unfused) GN_APPLY(true, true); else GN_APPLY(true, false); }
   else            { if (unfused) GN_APPLY(false, true); else GN_APPLY(false, false); }

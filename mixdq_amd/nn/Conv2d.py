@@ -263,6 +263,15 @@ class QuantizedConv2d(nn.Module):
             return y
         return y + (residual[:, :, None, None] if residual_per_image else residual)
 
+    def forward_parts(self, x_a: torch.Tensor, x_b: torch.Tensor) -> torch.Tensor:
+        """forward(cat([x_a, x_b], dim=1)) of a split layer (x_a has `split` channels) without the
+        concatenation: each half is quantized with its own activation quantizer where it lies."""
+        assert self.valid_for_acceleration and self.split == x_a.shape[1]
+        x_int = quant_op(x_a, self.act_scales_inv, self.act_zero_points)
+        x_int_0 = quant_op(x_b, self.act_scales_inv_0, self.act_zero_points_0)
+        first = self._conv(x_int, "", self.bias)
+        return self._conv(x_int_0, "_0", None, residual=first)
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if not self.valid_for_acceleration:
             return self.forward_fp(x)
@@ -273,5 +282,8 @@ class QuantizedConv2d(nn.Module):
             return self._conv(x_int, "", self.bias)
         x_int = quant_op(x[:, :self.split], self.act_scales_inv, self.act_zero_points)
         x_int_0 = quant_op(x[:, self.split:], self.act_scales_inv_0, self.act_zero_points_0)
-        # bias is applied once, in the first half (nn/Conv2d.py:341-343)
-        return self._conv(x_int, "", self.bias) + self._conv(x_int_0, "_0", None)
+        # bias is applied once, in the first half (nn/Conv2d.py:341-343); the reference's half add of
+        # the two fp16 outputs rides in the second launch's epilogue (same arithmetic: each output
+        # rounded to fp16, then one fp32 add rounded to fp16)
+        first = self._conv(x_int, "", self.bias)
+        return self._conv(x_int_0, "_0", None, residual=first)

@@ -152,19 +152,26 @@ def _refresh_after_load(mod, _incompatible_keys):
     mod.refresh_derived_()
 
 
-def _gn_feed(norm: nn.GroupNorm, x, consumer, silu: bool):
-    """GroupNorm(+SiLU) of a channels-last fp16 x for `consumer`: returns (tensor, quantized?)."""
+def _gn_feed(norm: nn.GroupNorm, x, consumer, silu: bool, x2=None):
+    """GroupNorm(+SiLU) of a channels-last fp16 x for `consumer`: returns (tensor, quantized?).
+    x2: the norm is over cat([x, x2], dim=1), read from the two tensors in place."""
     from mixdq_amd import _C
     N, C, H, W = x.shape
+    C += 0 if x2 is None else x2.shape[1]
     if (_fusable_f16(x) and x.is_contiguous(memory_format=torch.channels_last)
+            and (x2 is None or (_fusable_f16(x2)
+                                and x2.is_contiguous(memory_format=torch.channels_last)
+                                and x.shape[1] % 8 == 0 and x2.shape[1] % 8 == 0))
             and _C.groupnorm_supported(N, H * W, C, norm.num_groups)):
         if _accel(consumer):
             q, _ = _C.groupnorm_silu_quantize(x, norm.num_groups, norm.weight, norm.bias, norm.eps,
-                                              *_qp(consumer), silu=silu)
+                                              *_qp(consumer), silu=silu, x2=x2)
             return q, True
         _, h = _C.groupnorm_silu_quantize(x, norm.num_groups, norm.weight, norm.bias, norm.eps,
-                                          silu=silu, want_f16=True)
+                                          silu=silu, want_f16=True, x2=x2)
         return h, False
+    if x2 is not None:
+        x = torch.cat([x, x2], dim=1)
     h = norm(x)
     return (F.silu(h) if silu else h), False
 
@@ -292,9 +299,15 @@ class ResnetBlock2D(nn.Module):
 
     fused = False
 
-    def forward(self, x, temb):
+    def forward(self, x, temb, skip=None):
+        """skip: the up-block's skip connection; the input is cat([x, skip], dim=1).  The fused
+        path reads the two tensors in place (two-source GroupNorm, split shortcut) when it can."""
         if self.fused and _fusable_f16(x):
-            return self.forward_fused(x, temb)
+            if skip is not None and not self._pair_ok(x, skip):
+                x, skip = torch.cat([x, skip], dim=1), None
+            return self.forward_fused(x, temb, skip)
+        if skip is not None:
+            x = torch.cat([x, skip], dim=1)
         h = self.conv1(F.silu(self.norm1(x)))
         h = h + self.time_emb_proj(F.silu(temb))[:, :, None, None]
         h = self.conv2(F.silu(self.norm2(h)))
@@ -302,7 +315,17 @@ class ResnetBlock2D(nn.Module):
             x = self.conv_shortcut(x)
         return x + h
 
-    def forward_fused(self, x, temb):
+    def _pair_ok(self, x, skip) -> bool:
+        """The (hidden, skip) pair can stay unconcatenated: the shortcut is a W8A8 split layer whose
+        split is exactly `hidden`, and both tensors are channels-last with channel counts % 8."""
+        sc = self.conv_shortcut
+        return bool(sc is not None and getattr(sc, "valid_for_acceleration", False)
+                    and getattr(sc, "split", 0) == x.shape[1] and _fusable_f16(skip)
+                    and x.is_contiguous(memory_format=torch.channels_last)
+                    and skip.is_contiguous(memory_format=torch.channels_last)
+                    and x.shape[1] % 8 == 0 and skip.shape[1] % 8 == 0)
+
+    def forward_fused(self, x, temb, skip=None):
         ahead = self.__dict__.pop("_t", None)
         if ahead is not None:       # projected ahead of time (SDXLUNet._project_temb_ahead)
             t, ready = ahead
@@ -313,7 +336,9 @@ class ResnetBlock2D(nn.Module):
             t = self.time_emb_proj(F.silu(temb))                   # [N, Cout]
         sc = None
         side = None
-        if self.conv_shortcut is not None and not SHORTCUT_SIDE_STREAM:
+        if skip is not None:      # split shortcut on the two halves as they are (no concatenation)
+            sc = self.conv_shortcut.forward_parts(x, skip)
+        elif self.conv_shortcut is not None and not SHORTCUT_SIDE_STREAM:
             sc = self.conv_shortcut(x)
         elif self.conv_shortcut is not None:
             # the 1x1 shortcut (quantize + GEMM, twice for a split layer) only meets the main path
@@ -323,7 +348,7 @@ class ResnetBlock2D(nn.Module):
             with torch.cuda.stream(side):
                 sc = self.conv_shortcut(x)
             x.record_stream(side)
-        feed, q = _gn_feed(self.norm1, x, self.conv1, silu=True)
+        feed, q = _gn_feed(self.norm1, x, self.conv1, silu=True, x2=skip)
         if q:   # h = conv1(..) + t[:, :, None, None], the add folded into the conv epilogue
             h = self.conv1.forward_quantized(feed, residual=t.contiguous(), residual_per_image=True)
         elif _fp_layer(self.conv1):
@@ -652,8 +677,7 @@ class UpBlock(nn.Module):
 
     def forward(self, x, skips, temb, context):
         for i, res in enumerate(self.resnets):
-            x = torch.cat([x, skips.pop()], dim=1)
-            x = res(x, temb)
+            x = res(x, temb, skips.pop())      # input = cat([x, skip], dim=1)
             if self.has_attn:
                 x = self.attentions[i](x, context)
         if self.has_up:

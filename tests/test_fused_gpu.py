@@ -272,3 +272,41 @@ def test_qlinear_attention_w4_and_argument_checks(C):
     k200 = t(dd.normal_f16(217, (B, 200, Cc), 1.0))
     with pytest.raises(RuntimeError, match="unsupported configuration"):
         C.qlinear_attention(a, t(qw), scale, bias0, k200, k200)               # Tkv > 128
+
+
+# ------------------------------------ up-block skip connections without the concatenation (f-1)
+@pytest.mark.parametrize("N,H,W,C1,C2,G,silu", [(1, 16, 16, 64, 32, 8, True), (2, 8, 12, 32, 64, 8, False),
+                                                (1, 32, 32, 640, 320, 32, True), (1, 9, 7, 24, 8, 4, True)])
+def test_groupnorm_two_sources_equals_concatenation(C, N, H, W, C1, C2, G, silu):
+    """GroupNorm over cat([x, x2], dim=1) read from the two tensors in place == the same kernel on
+    the concatenated tensor (itself bit-exact vs the oracle above), int8 and fp16 outputs."""
+    xa = t(dd.normal_f16(301, (N, H, W, C1), 1.3)).permute(0, 3, 1, 2)      # channels-last
+    xb = t(dd.normal_f16(302, (N, H, W, C2), 0.7)).permute(0, 3, 1, 2)
+    gamma = t((dd.normal_f16(303, (C1 + C2,), 0.3).astype(np.float32) + 1).astype(np.float16))
+    beta = t(dd.normal_f16(304, (C1 + C2,), 0.2))
+    s_inv, zp = scal(25.0), scal(-9.0)
+    cat = torch.cat([xa, xb], dim=1).contiguous(memory_format=torch.channels_last)
+    q1, h1 = C.groupnorm_silu_quantize(cat, G, gamma, beta, 1e-5, s_inv, zp, silu=silu, want_f16=True)
+    q2, h2 = C.groupnorm_silu_quantize(xa, G, gamma, beta, 1e-5, s_inv, zp, silu=silu, want_f16=True,
+                                       x2=xb)
+    assert q2.shape == q1.shape and q2.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(q1, q2) and torch.equal(h1, h2)
+
+
+def test_split_shortcut_on_unconcatenated_halves(C, modules_golden):
+    """QuantizedConv2d.forward_parts(x_a, x_b) == forward(cat([x_a, x_b])) == the reference class's
+    output (modules.npz), bit for bit."""
+    from mixdq_amd.nn import QuantizedConv2d
+    from tests.cases import MODULE_CASES, module_ckpt, module_input
+    from tests.test_host import prepared
+    c = next(c for c in MODULE_CASES if c["key"] == "conv_split")
+    qm = QuantizedConv2d.from_float(prepared(c, modules_golden), split=c["split"],
+                                    ckpt=module_ckpt(c, modules_golden)).to(DEV)
+    x = module_input(c).to(DEV).contiguous(memory_format=torch.channels_last)
+    xa = x[:, :c["split"]].contiguous(memory_format=torch.channels_last)
+    xb = x[:, c["split"]:].contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        y, yp = qm(x), qm.forward_parts(xa, xb)
+    assert torch.equal(y, yp)
+    want = modules_golden["conv_split.out"]
+    assert np.array_equal(yp.contiguous().cpu().numpy().view(np.uint16), want.view(np.uint16))
