@@ -161,6 +161,8 @@ def roofline_sweep(run_eager, device, reps):
     for kind, (M, N, K, k_align), w4, replay in rec:
         if kind == "linear_grouped":     # N = the members' total; mixdq_qlinear_w8a8_grouped's rule
             cid = 37 if M <= 64 else 35
+        elif kind == "linear_attn":      # to_q + cross-attention: always the 64x128 8-wave tile
+            cid = 41
         else:
             cid = C.igemm_select_id(M, N, k_align, K, w4=w4)
         bm, bn, bk, st = C.IGEMM_CONFIGS.get(cid, (0, 0, 0, 0))

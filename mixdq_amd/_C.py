@@ -343,6 +343,9 @@ def qlinear_attention(input_int8, weight_int8, scale, bias0, k, v, scale_inv=Non
     out = torch.empty((B, T, N), dtype=torch.int8 if quant else torch.float16, device=a.device)
     sc, b0 = _f32vec(scale), _f32vec(bias0)
     ss = float(softmax_scale) if softmax_scale is not None else 0.125
+    _record("linear_attn", B * T, N, K, K, _w4, qlinear_attention,
+            (input_int8, weight_int8, scale, bias0, k, v, scale_inv, zero_point, softmax_scale),
+            dict(_w4=_w4))
     with torch.cuda.device(a.device):
         code = _lib.mixdq_qlinear_w8a8_attn(
             a.data_ptr(), w.data_ptr(), b0.data_ptr(), sc.data_ptr(), k.data_ptr(), v.data_ptr(),

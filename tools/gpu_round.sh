@@ -1,5 +1,5 @@
 #!/bin/bash
-# One GPU lease of the round: full GPU test suite, flake probe, default bench line, rocprofv3
+# One GPU lease of the round: full GPU test suite, default bench line, rocprofv3
 # kernel trace of the graph that is benchmarked.  Outputs under gpurun_out/r02_*.
 #   bash tools/gpu_round.sh [tag]
 tag=${1:-a}
@@ -8,8 +8,6 @@ mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 ( time timeout 1500 python -m pytest tests -m gpu -x -q ) > $out/pytest.log 2>&1
 tail -5 $out/pytest.log
-timeout 600 python tools/flake_probe.py 20 > $out/flake_probe.txt 2>&1
-tail -12 $out/flake_probe.txt
 timeout 900 python bench.py > $out/bench_default.json 2> $out/bench_default.err
 tail -c 1500 $out/bench_default.json
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o bench -- python3 bench.py --no-fp16 --no-cpu-baseline --no-roofline --steps 20 > $out/bench_prof.json 2> $out/bench_prof.err
