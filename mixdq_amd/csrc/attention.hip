@@ -7,19 +7,21 @@
 // and writing either FP16 rows or, fused, the INT8 operand of to_out.0 (same quantize arithmetic as
 // mixdq_quantize_f16_i8 applied to the FP16-rounded output).
 //
-// Structure per workgroup: WAVES waves x 32 query rows; K/V tiles of 64 keys, double-buffered in
-// LDS through registers (loads for tile t+1 are issued before the MFMAs of tile t and written after
-// them: one barrier per tile).
+// Structure per workgroup: WAVES waves x 32 query rows; K/V tiles of 64 keys arrive by LDS-DMA into a
+// ring of four (three in flight, one barrier per tile).  Each wave runs a three-deep software
+// pipeline over the tiles (attn_tile_step): the softmax of tile t on the VALU next to the MFMAs of
+// P V (t-1) and Q K^T (t+1), interleaved by hand at two waves per SIMD (<= 256 registers).
 //   S^T = K Q^T      v_mfma_f32_32x32x16_f16, A = K rows (ds_read_b128, XOR-swizzled image),
 //                    B = Q^T held in registers.  Lane (q = lane%32, h = lane/32) then owns, for ITS
 //                    query, keys 32kb + 8g + 4h + 0..3: the row max / row sum are in-lane reductions
 //                    plus one v_permlane32_swap.
 //   O^T = V^T P^T    B = P^T is the S^T accumulator itself, converted to FP16 in place (k-slot j of
 //                    half h <-> key 32kb + 16u + 8(j/4) + 4h + j%4); A = V^T comes from the row-major
-//                    V image through ds_read_b64_tr_b16 with the same slot order (192-B row stride:
-//                    the four rows of a transposed read fall in four disjoint 16-bank ranges).
+//                    V image through ds_read_b64_tr_b16 with the same slot order (128-B rows, 16-B
+//                    chunks XOR-swizzled: the four rows of a transposed read fall in four disjoint
+//                    16-bank ranges).
 // Softmax in FP32 with base-2 exponentials (v_exp_f32), P rounded to FP16 for the second MFMA, row
-// sums accumulated in FP32 from the unrounded P; O staged through LDS and stored as whole 128-B rows.
+// sums accumulated in FP32 from that rounded P (a third MFMA with a ones operand); O staged through LDS and stored as whole 128-B rows.
 #include "common.h"
 #include "attn_core.h"
 
@@ -49,8 +51,167 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
       (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+template <int OFF>
+__device__ __forceinline__ void lds_read128_imm(v8h& d, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+
+// Running state of one wave's 32 query rows.
+struct AttnState {
+  v16f o[2], lsum;               // O^T accumulators (d 0..31, 32..63); row sums, every register equal
+  float m_i;                     // running row maximum
+  VFrag vf[2][2][2];             // V^T fragments of the tile whose P V product is issued next
+};
+
+__device__ __forceinline__ void attn_state_init(AttnState& st) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { st.o[0][i] = 0.f; st.o[1][i] = 0.f; st.lsum[i] = 0.f; }
+  st.m_i = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {                  // "tile -1": a zero product
+    st.vf[i >> 2][(i >> 1) & 1][i & 1].r.lo = v2i{0, 0};
+    st.vf[i >> 2][(i >> 1) & 1][i & 1].r.hi = v2i{0, 0};
+  }
+}
+
+// O^T += V^T P^T and the row sums for one whole tile (the pipeline's drain).
+__device__ __forceinline__ void attn_pv_tile(AttnState& st, const v8h (&pu)[2][2], const v8h& ones) {
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+        st.o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(st.vf[kb][u][db].h, pu[kb][u], st.o[db], 0, 0, 0);
+      st.lsum = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pu[kb][u], st.lsum, 0, 0, 0);
+    }
+}
+
+// One iteration of the software pipeline, for the wave's tile t ("this"), the one before it
+// ("last") and the one after it ("next").  A wave issues in order and an MFMA runs for 32 cycles
+// after its issue, so matrix work hides under VALU work only when the two are interleaved
+// instruction by instruction and independent.  The iteration therefore pairs the softmax of this
+// tile (VALU: maximum, 32 exponentials, FP16 conversion; scores `sc` -> probabilities `pc`) with
+// MFMAs that do not depend on it: P V of the last tile (12, row sums included; `pl` and st.vf) and
+// Q K^T of the next one (8, into `sn`).  hipcc's own placement clusters the MFMAs in front of the
+// VALU block (sched_group_barrier requests notwithstanding), so the order is pinned by hand.
+//   k_next[ks]: LDS address of this lane's K row chunk of k-step ks in the next tile's image
+//   v0 / v1   : LDS addresses of this lane's transposed V reads (d 0..31 / 32..63) in this tile's
+// Every LDS read is inline asm and counted by hand: hipcc would put `s_waitcnt vmcnt(0)` in front
+// of a ds_read_tr builtin while an LDS-DMA is in flight (draining the prefetch ring every tile) and
+// cannot count asm reads next to its own.  On return st.vf holds this tile's V^T fragments, still
+// in flight: the caller waits lgkmcnt(0) before the next step (or the drain).
+template <bool RAGGED>
+__device__ __forceinline__ void attn_tile_step(AttnState& st, v16f (&sc)[2], v16f (&sn)[2],
+                                               v8h (&pc)[2][2], v8h (&pl)[2][2],
+                                               const v8h (&qf)[4], const v8h& ones, float c,
+                                               const unsigned (&k_next)[4], unsigned v0, unsigned v1,
+                                               bool mask_next, int lim_next) {
+  v16f (&o)[2] = st.o;
+  v16f& lsum = st.lsum;
+  VFrag (&vf)[2][2][2] = st.vf;
+  v8h kf[2][2];                                  // two k-steps at a time: registers
+  auto pv = [&](int g) {                         // keys 16 g .. 16 g + 15 of the last tile
+    const int kb = g >> 1, u = g & 1;
+    o[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[kb][u][0].h, pl[kb][u], o[0], 0, 0, 0);
+    o[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[kb][u][1].h, pl[kb][u], o[1], 0, 0, 0);
+    lsum = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pl[kb][u], lsum, 0, 0, 0);
+  };
+  auto qk1 = [&](int i) {                        // one k-step of the next tile's scores
+    const int kb = i & 1, ks = i >> 1;
+    const v16f zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    sn[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][ks & 1], qf[ks], ks ? sn[kb] : zero, 0, 0, 0);
+  };
+  auto k_read = [&](int ks0) {                   // K fragments of k-steps ks0, ks0 + 1
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      lds_read128_imm<0>(kf[0][ks], k_next[ks0 + ks]);
+      lds_read128_imm<32 * kRow>(kf[1][ks], k_next[ks0 + ks]);
+    }
+  };
+  float mc = 0.f;
+  auto ex = [&](int i) {                         // four exponentials -> two packed FP16 pairs
+    const int kb = i >> 2;
+#pragma unroll
+    for (int r = 4 * (i & 3); r < 4 * (i & 3) + 4; ++r)
+      pc[kb][r >> 3][r & 7] = (_Float16)__builtin_amdgcn_exp2f(__builtin_fmaf(sc[kb][r], c, -mc));
+  };
+  // A stage = a few MFMAs + a slice of the softmax, fenced by empty asm statements that the
+  // stage's inputs and results pass through ("+v"): volatile asms keep their order, so nothing
+  // of a stage can be hoisted above its opening fence or sink below its closing one.
+#define MIXDQ_FENCE_PV(B)  asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(lsum), "+v"(B), "+v"(mc))
+#define MIXDQ_FENCE_QK(A0, A1, PCV) \
+  asm volatile("" : "+v"(sn[0]), "+v"(sn[1]), "+v"(A0), "+v"(A1), "+v"(mc), "+v"(PCV))
+
+  // ---- maximum of this tile (lane = one query row; the other 32 keys: lane ^ 32) ----
+  MIXDQ_FENCE_PV(pl[0][0]);
+  pv(0);
+  float mx = sc[0][0];
+#pragma unroll
+  for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[0][r]);
+  asm volatile("" : "+v"(mx));
+  MIXDQ_FENCE_PV(pl[0][1]);
+  pv(1);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[1][r]);
+  mx = half_max(mx);
+  const float m_new = fmaxf(st.m_i, mx);
+  const bool grew = m_new > st.m_i;
+  mc = m_new * c;
+  // ---- exponentials, four keys at a time behind one or two MFMAs ----
+  MIXDQ_FENCE_PV(pl[1][0]);
+  k_read(0);                                     // in flight until the first Q K^T stage
+  pv(2); ex(0);
+  asm volatile("" : "+v"(pc[0][0]));
+  MIXDQ_FENCE_PV(pl[1][1]);
+  pv(3); ex(1);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // the K fragments
+  asm volatile("" : "+v"(o[0]), "+v"(o[1]), "+v"(lsum));
+  asm volatile("" : "+v"(kf[0][0]), "+v"(kf[1][0]), "+v"(mc), "+v"(pc[0][0]));
+  qk1(0); qk1(1); ex(2);
+  MIXDQ_FENCE_QK(kf[0][1], kf[1][1], pc[0][1]);
+  qk1(2); qk1(3); ex(3);
+  MIXDQ_FENCE_QK(kf[0][0], kf[1][0], pc[0][1]);
+  k_read(2);
+  ex(4);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  MIXDQ_FENCE_QK(kf[0][0], kf[1][0], pc[1][0]);
+  // V^T fragments of this tile: the products of the last one were issued stages ago
+  tr_read2_imm<0 * kRow>(vf[0][0][0], v0);
+  tr_read2_imm<0 * kRow>(vf[0][0][1], v1);
+  tr_read2_imm<16 * kRow>(vf[0][1][0], v0);
+  tr_read2_imm<16 * kRow>(vf[0][1][1], v1);
+  tr_read2_imm<32 * kRow>(vf[1][0][0], v0);
+  tr_read2_imm<32 * kRow>(vf[1][0][1], v1);
+  tr_read2_imm<48 * kRow>(vf[1][1][0], v0);
+  tr_read2_imm<48 * kRow>(vf[1][1][1], v1);
+  qk1(4); qk1(5); ex(5);
+  MIXDQ_FENCE_QK(kf[0][1], kf[1][1], pc[1][0]);
+  qk1(6); ex(6);
+  asm volatile("" : "+v"(sn[0]), "+v"(kf[1][1]), "+v"(mc), "+v"(pc[1][1]));
+  qk1(7); ex(7);
+  asm volatile("" : "+v"(sn[1]), "+v"(pc[1][1]));
+#undef MIXDQ_FENCE_PV
+#undef MIXDQ_FENCE_QK
+  if (RAGGED && mask_next) {                     // mask the absent keys of the last tile
+    asm volatile("" ::: "memory");               // a real branch: not worth if-converting
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (32 * kb + 8 * (r >> 2) + (r & 3) >= lim_next) sn[kb][r] = -INFINITY;
+  }
+  if (__builtin_amdgcn_ballot_w64(grew)) {       // some row's maximum moved: rescale O and sums
+    const float alpha = __builtin_amdgcn_exp2f((st.m_i - m_new) * c);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+    lsum[0] *= alpha;
+  }
+  st.m_i = m_new;
+}
+
 template <int WAVES, int STAGES, bool QUANT, bool RAGGED>
-__global__ __launch_bounds__(WAVES * 64) void attn_fwd_kernel(const AttnParams p) {
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd_kernel(const AttnParams p) {
   constexpr int NI = 16 / WAVES;                 // LDS-DMA wave-instructions per wave per tile
   constexpr int PRE = STAGES - 1;                // tiles staged ahead of the one whose V is consumed
   static_assert(STAGES >= 3, "tiles t (V) and t+1 (K) are read while t+2.. are in flight");
@@ -80,29 +241,31 @@ __global__ __launch_bounds__(WAVES * 64) void attn_fwd_kernel(const AttnParams p
   // A wave's NI instructions are all-K or all-V (waves 0..WAVES/2-1 stage K, the rest V).
   const int srow = lane >> 3, spos = lane & 7;
   const bool stage_v = wave * NI >= 8;
-  const __half* sbase = (stage_v ? p.v + b * p.v_bs : p.k + b * p.k_bs) + head * kHeadDim;
-  const int srs = (int)(stage_v ? p.v_rs : p.k_rs);
+  // wave-uniform byte base (SGPR pair) + 32-bit per-lane byte offsets: the saddr form of the DMA
+  const char* sbase = reinterpret_cast<const char*>(
+      (stage_v ? p.v + b * p.v_bs : p.k + b * p.k_bs) + head * kHeadDim);
+  const unsigned srs = 2u * (unsigned)(stage_v ? p.v_rs : p.k_rs);   // key row stride in bytes
   const int last_key = p.tkv - 1;
-  int row_off[NI], col_off[NI];                  // element offsets of this lane's rows / chunks
+  unsigned row_off[NI], col_off[NI];             // byte offsets of this lane's rows / chunks
 #pragma unroll
   for (int i = 0; i < NI; ++i) {
     const int krow = ((wave * NI + i) & 7) * 8 + srow;     // key row within the tile
     const int sw = stage_v ? ((krow >> 1) & 1) << 2 : (krow >> 1) & 7;
-    col_off[i] = (spos ^ sw) * 8;
+    col_off[i] = (spos ^ sw) * 16;
     row_off[i] = krow * srs + col_off[i];
   }
   auto stage = [&](int buf, int t) {
     char* dst = smem + buf * kStageBytes + wave * NI * 1024;
     if ((t + 1) * kKeys <= p.tkv) {                       // whole tile in range (wave-uniform)
-      const int tile_off = t * kKeys * srs;
+      const char* tile = sbase + (size_t)((unsigned)(t * kKeys) * srs);
 #pragma unroll
-      for (int i = 0; i < NI; ++i) glds16(sbase + (tile_off + row_off[i]), dst + i * 1024);
+      for (int i = 0; i < NI; ++i) glds16(tile + row_off[i], dst + i * 1024);
     } else {
       // keys past the end re-read the last key: finite data whose scores are masked to -inf below
 #pragma unroll
       for (int i = 0; i < NI; ++i) {
         const int key = min(t * kKeys + ((wave * NI + i) & 7) * 8 + srow, last_key);
-        glds16(sbase + (key * srs + col_off[i]), dst + i * 1024);
+        glds16(sbase + ((unsigned)key * srs + col_off[i]), dst + i * 1024);
       }
     }
   };
@@ -152,10 +315,8 @@ __global__ __launch_bounds__(WAVES * 64) void attn_fwd_kernel(const AttnParams p
   };
 
   static_assert(STAGES % 2 == 0, "the score registers ping-pong with the buffer parity");
-  v16f o[2], lsum;                               // lsum: row sums, every register of a lane equal
-#pragma unroll
-  for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; lsum[i] = 0.f; }
-  float m_i = -INFINITY;
+  AttnState st;
+  attn_state_init(st);
   const float c = p.scale_log2;
   v8h ones;
 #pragma unroll
@@ -166,92 +327,37 @@ __global__ __launch_bounds__(WAVES * 64) void attn_fwd_kernel(const AttnParams p
   asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((PRE - 1) * NI) : "memory");
   v16f S[2][2];                                  // scores: S[t & 1] softmaxed now, S[~t & 1] next
   qk(0, 0, S[0]);
+  v8h P[2][2][2];                                // P[t & 1]: probabilities of tile t, FP16, B operand
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) P[1][kb][u][j] = (_Float16)0.f;
 
-  // Software pipeline, per iteration t: [V(t) transposed reads, K(t+1) reads] -> QK^T(t+1) MFMAs
-  // -> softmax(t) on the VALU while those MFMAs run -> PV(t) MFMAs (+ the row sums, as a product
-  // with a ones operand: the sums of the FP16-rounded P the second product actually uses).
+  // Software pipeline (attn_tile_step): iteration t = softmax(t) next to P V(t-1) and Q K^T(t+1).
   for (int t0 = 0; t0 < ntiles; t0 += STAGES) {
 #pragma unroll
     for (int sb = 0; sb < STAGES; ++sb) {          // tile t0 + sb lives in buffer sb (compile-time)
       const int t = t0 + sb;
       if (t >= ntiles) break;
-      v16f (&sc)[2] = S[sb & 1];
-      v16f (&sn)[2] = S[(sb + 1) & 1];
-      // tile t+1 has landed (PRE-2 younger tiles may still fly); every wave is past tile t-1,
-      // whose buffer is restaged next
-      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((PRE - 2) * NI) : "memory");
+      // tile t+1 has landed (PRE-2 younger tiles may still fly); every wave is past tile t-1 --
+      // its V fragments are in registers (lgkmcnt) -- whose buffer is restaged next
+      asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((PRE - 2) * NI) : "memory");
       stage((sb + PRE) % STAGES, t + PRE);
-
-      // V^T fragments of tile t.  Inline asm: hipcc puts `s_waitcnt vmcnt(0)` in front of the
-      // ds_read_tr builtin while an LDS-DMA is in flight (draining the prefetch ring every tile);
-      // the asm reads are counted by hand (s_waitcnt_lgkm0 below).
-      VFrag vf[2][2][2];
-      {
-        const unsigned a0 = v_a0 + sb * kStageBytes, a1 = v_a1 + sb * kStageBytes;
-        tr_read2_imm<0 * kRow>(vf[0][0][0], a0);
-        tr_read2_imm<0 * kRow>(vf[0][0][1], a1);
-        tr_read2_imm<16 * kRow>(vf[0][1][0], a0);
-        tr_read2_imm<16 * kRow>(vf[0][1][1], a1);
-        tr_read2_imm<32 * kRow>(vf[1][0][0], a0);
-        tr_read2_imm<32 * kRow>(vf[1][0][1], a1);
-        tr_read2_imm<48 * kRow>(vf[1][1][0], a0);
-        tr_read2_imm<48 * kRow>(vf[1][1][1], a1);
-      }
-
-      // ---- scores of the NEXT tile: these MFMAs run under the softmax below ----
-      // (past the last tile this reads a re-staged copy of the last key; the scores are unused)
-      qk((sb + 1) % STAGES, t + 1, sn);
-
-      // ---- online softmax of tile t (lane = one query row; the other 32 keys: lane ^ 32) ----
-      float mx = sc[0][0];
+      unsigned k_next[4];                          // past the last tile: a re-staged key, unused
 #pragma unroll
-      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[0][r]);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[1][r]);
-      mx = half_max(mx);
-      const float m_new = fmaxf(m_i, mx);
-      const bool grew = m_new > m_i;
-      const float mc = m_new * c;
-      v8h pf[2][2];
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          pf[kb][r >> 3][r & 7] =
-              (_Float16)__builtin_amdgcn_exp2f(__builtin_fmaf(sc[kb][r], c, -mc));
-      // pin P here: otherwise the exponentials sink below the rescale branch, away from the MFMAs
-      asm volatile("" ::"v"(pf[0][0]), "v"(pf[0][1]), "v"(pf[1][0]), "v"(pf[1][1]));
-      if constexpr (!RAGGED) {
-        // QK^T(t+1) MFMAs are independent of this softmax: spread them through it, one MFMA per
-        // 16 VALU instructions (a wave issues in order — left clustered, the MFMAs and the VALU
-        // work would run back to back instead of side by side)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
-          __builtin_amdgcn_sched_group_barrier(0x002, 16, 0);  // 16 VALU
-        }
-      }
-      if (__builtin_amdgcn_ballot_w64(grew)) {     // some row's maximum moved: rescale O and sums
-        const float alpha = __builtin_amdgcn_exp2f((m_i - m_new) * c);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
-        lsum[0] *= alpha;
-      }
-      m_i = m_new;
-
-      // ---- O^T += V^T P^T, row sums += 1^T P^T ----
-      s_waitcnt_lgkm0();
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-#pragma unroll
-          for (int db = 0; db < 2; ++db)
-            o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[kb][u][db].h, pf[kb][u], o[db], 0, 0, 0);
-          lsum = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf[kb][u], lsum, 0, 0, 0);
-        }
+      for (int ks = 0; ks < 4; ++ks) k_next[ks] = k_a[ks] + ((sb + 1) % STAGES) * kStageBytes;
+      attn_tile_step<RAGGED>(st, S[sb & 1], S[(sb + 1) & 1], P[sb & 1], P[(sb + 1) & 1], qf, ones, c,
+                             k_next, v_a0 + sb * kStageBytes, v_a1 + sb * kStageBytes,
+                             t + 1 == ntiles - 1, p.tkv - (t + 1) * kKeys - 4 * hh);
     }
   }
+  // ---- the last tile's product ----
+  s_waitcnt_lgkm0();
+  if ((ntiles - 1) & 1) attn_pv_tile(st, P[1], ones); else attn_pv_tile(st, P[0], ones);
+  v16f (&o)[2] = st.o;
+  v16f& lsum = st.lsum;
   // the DMAs staged for tiles >= ntiles may still be in flight: drain before LDS reuse
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
