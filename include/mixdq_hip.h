@@ -212,6 +212,21 @@ int mixdq_groupnorm_silu_quantize2(const void* x_nhwc_f16, int C1, const void* x
                                    int N, int64_t HW, int C, int G, int flags,
                                    mixdq_stream_t stream);
 
+/* ... and, from the same pass, the INPUT itself quantized (no normalisation): raw_q[i] (HOST arrays
+ * of two device pointers; entry 0: source x, entry 1: source x2; null entries / null arrays: none)
+ * receives mixdq_quantize_f16_i8(source i; raw_scale_inv[i], raw_zero_point[i]) in that source's own
+ * [N, HW, Cs] layout -- the operand of a layer that reads the same activation as the norm (the ResNet
+ * block's 1x1 conv_shortcut beside norm1; a split shortcut quantizes each half with its own
+ * quantizer, nn/Conv2d.py:330-343). */
+int mixdq_groupnorm_silu_quantize3(const void* x_nhwc_f16, int C1, const void* x2_nhwc_f16_or_null,
+                                   const void* gamma_f16, const void* beta_f16, float eps,
+                                   int apply_silu, const float* scale_inv, const float* zero_point,
+                                   int8_t* out_q_or_null, void* out_f16_or_null,
+                                   const float* const* raw_scale_inv,
+                                   const float* const* raw_zero_point, int8_t* const* raw_q,
+                                   void* workspace, int N, int64_t HW, int C, int G, int flags,
+                                   mixdq_stream_t stream);
+
 /* LayerNorm over the last dimension of x [M, C] (fp16) + up to three quantizers of the same
  * normalised FP16 value (to_q / to_k / to_v have their own activation scales).  HOST arrays of
  * n_out device pointers.  C % 8 == 0, C <= 2048. */

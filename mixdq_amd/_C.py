@@ -646,6 +646,10 @@ _lib.mixdq_groupnorm_silu_quantize.argtypes = [_vp, _vp, _vp, ctypes.c_float, _i
 _lib.mixdq_groupnorm_silu_quantize2.restype = _i32
 _lib.mixdq_groupnorm_silu_quantize2.argtypes = [_vp, _i32, _vp, _vp, _vp, ctypes.c_float, _i32, _vp,
                                                 _vp, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _i32, _vp]
+_lib.mixdq_groupnorm_silu_quantize3.restype = _i32
+_lib.mixdq_groupnorm_silu_quantize3.argtypes = [_vp, _i32, _vp, _vp, _vp, ctypes.c_float, _i32, _vp,
+                                                _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i64, _i32,
+                                                _i32, _i32, _vp]
 _lib.mixdq_layernorm_quantize.restype = _i32
 _lib.mixdq_layernorm_quantize.argtypes = [_vp, _vp, _vp, ctypes.c_float, _i64, _i32, _i32, _vp, _vp,
                                           _vp, _vp, _i32, _vp]
@@ -658,11 +662,14 @@ def groupnorm_supported(N, HW, C, G) -> bool:
 
 
 def groupnorm_silu_quantize(x, num_groups, weight, bias, eps, scale_inv=None, zero_point=None,
-                            silu=True, want_f16=False, x2=None):
+                            silu=True, want_f16=False, x2=None, raw_qparams=None):
     """x: fp16 [N, C, H, W] in channels-last memory (or [N, HW, C] contiguous).  Returns
     (int8 or None, fp16 or None) with x's shape and strides.
     x2 (same layout, same N / H / W): the GroupNorm of cat([x, x2], dim=channels) without making
-    the concatenation; the outputs have the concatenated shape."""
+    the concatenation; the outputs have the concatenated shape.
+    raw_qparams: one (scale_inv, zero_point) pair or None per source tensor; the return value gains
+    a third element, the list of `quantize_per_tensor(source)` results (None where not asked for),
+    written by the same pass."""
     _check(x.is_cuda and x.dtype == torch.float16, "x should be an fp16 GPU tensor")
     if x.dim() == 4:
         _check(x.is_contiguous(memory_format=torch.channels_last),
@@ -671,48 +678,48 @@ def groupnorm_silu_quantize(x, num_groups, weight, bias, eps, scale_inv=None, ze
     else:
         _check(x.dim() == 3 and x.is_contiguous(), "x should be [N, HW, C] contiguous")
         N, HW, C = x.shape
+    C1 = C
+    shape = tuple(x.shape)
     if x2 is not None:
         _check(x2.is_cuda and x2.dtype == torch.float16 and x2.dim() == x.dim()
                and x2.shape[0] == N and (x2.shape[2:] == x.shape[2:] if x.dim() == 4
                                          else x2.shape[1] == HW)
                and (x2.is_contiguous(memory_format=torch.channels_last) if x.dim() == 4
                     else x2.is_contiguous()), "x2 should match x in batch / spatial size and layout")
-        C1, C2 = C, x2.shape[1] if x.dim() == 4 else x2.shape[2]
+        C2 = x2.shape[1] if x.dim() == 4 else x2.shape[2]
         _check(C1 % 8 == 0 and C2 % 8 == 0, "two-source GroupNorm needs channel counts % 8 == 0")
         C = C1 + C2
         shape = (N, C, x.shape[2], x.shape[3]) if x.dim() == 4 else (N, HW, C)
-        fmt = dict(memory_format=torch.channels_last) if x.dim() == 4 else {}
-        want_q = scale_inv is not None
-        _check(want_q or want_f16, "nothing to compute")
-        ws_bytes = _lib.mixdq_groupnorm_workspace_bytes(N, HW, C, num_groups)
-        _check(ws_bytes > 0, "groupnorm_silu_quantize: unsupported configuration")
-        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
-        out_q = torch.empty(shape, dtype=torch.int8, device=x.device, **fmt) if want_q else None
-        out_h = torch.empty(shape, dtype=torch.float16, device=x.device, **fmt) if want_f16 else None
-        w, b = weight.contiguous(), bias.contiguous()
-        _check(w.dtype == torch.float16 and b.dtype == torch.float16, "gamma/beta should be fp16")
-        with torch.cuda.device(x.device):
-            code = _lib.mixdq_groupnorm_silu_quantize2(
-                x.data_ptr(), C1, x2.data_ptr(), w.data_ptr(), b.data_ptr(), float(eps),
-                int(bool(silu)), _ptr(scale_inv), _ptr(zero_point), _ptr(out_q), _ptr(out_h),
-                ws.data_ptr(), N, HW, C, num_groups, FLAGS, _stream())
-        _status(code, "groupnorm_silu_quantize")
-        return out_q, out_h
+    fmt = dict(memory_format=torch.channels_last) if x.dim() == 4 else {}
     want_q = scale_inv is not None
     _check(want_q or want_f16, "nothing to compute")
     ws_bytes = _lib.mixdq_groupnorm_workspace_bytes(N, HW, C, num_groups)
     _check(ws_bytes > 0, "groupnorm_silu_quantize: unsupported configuration")
     ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=x.device)
-    out_q = torch.empty_like(x, dtype=torch.int8) if want_q else None
-    out_h = torch.empty_like(x) if want_f16 else None
+    out_q = torch.empty(shape, dtype=torch.int8, device=x.device, **fmt) if want_q else None
+    out_h = torch.empty(shape, dtype=torch.float16, device=x.device, **fmt) if want_f16 else None
     w, b = weight.contiguous(), bias.contiguous()
     _check(w.dtype == torch.float16 and b.dtype == torch.float16, "gamma/beta should be fp16")
+    raws = None
+    arr = ctypes.c_void_p * 2
+    r_si = r_zp = r_q = None
+    if raw_qparams is not None:
+        sources = [x] if x2 is None else [x, x2]
+        _check(len(raw_qparams) == len(sources), "one raw quantizer slot per source tensor")
+        raws = [None if qp is None else torch.empty_like(src, dtype=torch.int8)
+                for qp, src in zip(raw_qparams, sources)]
+        pad = [None] * (2 - len(sources))
+        r_si = arr(*[_ptr(None if qp is None else qp[0]) for qp in list(raw_qparams) + pad])
+        r_zp = arr(*[_ptr(None if qp is None else qp[1]) for qp in list(raw_qparams) + pad])
+        r_q = arr(*[_ptr(t) for t in raws + pad])
     with torch.cuda.device(x.device):
-        code = _lib.mixdq_groupnorm_silu_quantize(
-            x.data_ptr(), w.data_ptr(), b.data_ptr(), float(eps), int(bool(silu)),
-            _ptr(scale_inv), _ptr(zero_point), _ptr(out_q), _ptr(out_h), ws.data_ptr(),
-            N, HW, C, num_groups, FLAGS, _stream())
+        code = _lib.mixdq_groupnorm_silu_quantize3(
+            x.data_ptr(), C1, _ptr(x2), w.data_ptr(), b.data_ptr(), float(eps),
+            int(bool(silu)), _ptr(scale_inv), _ptr(zero_point), _ptr(out_q), _ptr(out_h),
+            r_si, r_zp, r_q, ws.data_ptr(), N, HW, C, num_groups, FLAGS, _stream())
     _status(code, "groupnorm_silu_quantize")
+    if raw_qparams is not None:
+        return out_q, out_h, raws
     return out_q, out_h
 
 

@@ -65,6 +65,16 @@ __device__ __forceinline__ const __half* gn_src(const __half* x, const __half* x
   return x2 + ((int64_t)n * g.HW) * stride + (8 * o - g.C1);
 }
 
+// Optional second product of the apply pass: the INPUT itself (no normalisation) quantized per
+// source tensor, in that source's own [N, HW, Cs] layout -- the operand of a layer that reads the
+// same activation as the norm (the ResNet block's 1x1 shortcut, nn/Conv2d.py:330-343 quantizes each
+// half of a split input with its own quantizer).  The apply pass already holds x in registers.
+struct GnRaw {
+  const float* s_inv[2];
+  const float* zp[2];
+  int8_t* q[2];
+};
+
 __global__ void gn_stats_kernel(const __half* __restrict__ x, const __half* __restrict__ x2,
                                 float2* __restrict__ partial, GnGeom g) {
   extern __shared__ float lds[];   // [blockDim][4]: s0, q0, s1, q1
@@ -151,7 +161,8 @@ __global__ void gn_apply_kernel(const __half* __restrict__ x, const __half* __re
                                 const __half* __restrict__ gamma,
                                 const __half* __restrict__ beta,
                                 const float* __restrict__ s_inv_p, const float* __restrict__ zp_p,
-                                int8_t* __restrict__ out_q, __half* __restrict__ out_h, GnGeom g) {
+                                int8_t* __restrict__ out_q, __half* __restrict__ out_h, GnGeom g,
+                                GnRaw raw) {
   __shared__ float2 s_stats[1024];   // G <= OC * PP <= 1024
   const int t = threadIdx.x;
   const int o = t % g.OC, pp = t / g.OC;
@@ -189,11 +200,15 @@ __global__ void gn_apply_kernel(const __half* __restrict__ x, const __half* __re
   const int64_t img = ((int64_t)n * g.HW) * g.C + 8 * o;
   int xs;
   const __half* src = gn_src(x, x2, g, n, o, xs);
+  const int which = 8 * o < g.C1 ? 0 : 1;
+  int8_t* raw_q = raw.q[which];
+  const float raw_si = raw_q ? *raw.s_inv[which] : 0.f, raw_zp = raw_q ? *raw.zp[which] : 0.f;
+  if (raw_q) raw_q += ((int64_t)n * g.HW) * xs + (8 * o - (which ? g.C1 : 0));
   for (int64_t p = p_begin + pp; p < p_end; p += g.PP) {
     const Half8 h = *reinterpret_cast<const Half8*>(src + p * xs);
     Half8 oh;
-    Char8 oq;
-    oq.w[0] = oq.w[1] = 0;
+    Char8 oq, rq;
+    oq.w[0] = oq.w[1] = rq.w[0] = rq.w[1] = 0;
     oh.w[0] = oh.w[1] = oh.w[2] = oh.w[3] = 0;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -201,9 +216,11 @@ __global__ void gn_apply_kernel(const __half* __restrict__ x, const __half* __re
       if (SILU) y = round_f16(mixdq_siluf(y));                          // SiLU -> fp16
       put_half(oh, j, y);
       put_q(oq, j, quantize_one<UNFUSED>(y, s_inv, zp));
+      put_q(rq, j, quantize_one<UNFUSED>(half_at(h, j), raw_si, raw_zp));
     }
     if (want_q) *reinterpret_cast<Char8*>(out_q + img + p * g.C) = oq;
     if (out_h) *reinterpret_cast<Half8*>(out_h + img + p * g.C) = oh;
+    if (raw_q) *reinterpret_cast<Char8*>(raw_q + p * xs) = rq;
   }
 }
 
@@ -367,6 +384,16 @@ extern "C" int mixdq_groupnorm_silu_quantize2(const void* x_nhwc, int C1, const 
                                               void* out_f16_or_null, void* workspace, int N,
                                               int64_t HW, int C, int G, int flags,
                                               mixdq_stream_t stream_);
+extern "C" int mixdq_groupnorm_silu_quantize3(const void* x_nhwc, int C1, const void* x2_nhwc,
+                                              const void* gamma, const void* beta, float eps,
+                                              int apply_silu, const float* scale_inv,
+                                              const float* zero_point, int8_t* out_q_or_null,
+                                              void* out_f16_or_null,
+                                              const float* const* raw_scale_inv,
+                                              const float* const* raw_zero_point,
+                                              int8_t* const* raw_q, void* workspace, int N,
+                                              int64_t HW, int C, int G, int flags,
+                                              mixdq_stream_t stream_);
 
 extern "C" int mixdq_groupnorm_silu_quantize(const void* x_nhwc, const void* gamma,
                                              const void* beta, float eps, int apply_silu,
@@ -386,6 +413,32 @@ extern "C" int mixdq_groupnorm_silu_quantize2(const void* x_nhwc, int C1, const 
                                               void* out_f16_or_null, void* workspace, int N,
                                               int64_t HW, int C, int G, int flags,
                                               mixdq_stream_t stream_) {
+  return mixdq_groupnorm_silu_quantize3(x_nhwc, C1, x2_nhwc, gamma, beta, eps, apply_silu, scale_inv,
+                                        zero_point, out_q_or_null, out_f16_or_null, nullptr, nullptr,
+                                        nullptr, workspace, N, HW, C, G, flags, stream_);
+}
+
+extern "C" int mixdq_groupnorm_silu_quantize3(const void* x_nhwc, int C1, const void* x2_nhwc,
+                                              const void* gamma, const void* beta, float eps,
+                                              int apply_silu, const float* scale_inv,
+                                              const float* zero_point, int8_t* out_q_or_null,
+                                              void* out_f16_or_null,
+                                              const float* const* raw_scale_inv,
+                                              const float* const* raw_zero_point,
+                                              int8_t* const* raw_q, void* workspace, int N,
+                                              int64_t HW, int C, int G, int flags,
+                                              mixdq_stream_t stream_) {
+  GnRaw raw = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};
+  if (raw_q != nullptr) {
+    for (int i = 0; i < 2; ++i) {
+      if (raw_q[i] == nullptr) continue;
+      if (i == 1 && x2_nhwc == nullptr) return MIXDQ_ERR_INVALID_ARG;   // no second source
+      if (!raw_scale_inv || !raw_zero_point || !raw_scale_inv[i] || !raw_zero_point[i])
+        return MIXDQ_ERR_INVALID_ARG;
+      if ((uintptr_t)raw_q[i] % 8) return MIXDQ_ERR_ALIGNMENT;
+      raw.s_inv[i] = raw_scale_inv[i]; raw.zp[i] = raw_zero_point[i]; raw.q[i] = raw_q[i];
+    }
+  }
   GnGeom g;
   if (!make_gn_geom(N, HW, C, G, g)) return MIXDQ_ERR_SHAPE;
   if (C1 <= 0 || C1 > C || C1 % 8 != 0) return MIXDQ_ERR_SHAPE;
@@ -413,7 +466,7 @@ extern "C" int mixdq_groupnorm_silu_quantize2(const void* x_nhwc, int C1, const 
   gn_apply_kernel<S, U><<<grid, threads, 0, stream>>>(                                          \
       (const __half*)x_nhwc, (const __half*)x2_nhwc, partial, stats, eps, (const __half*)gamma, \
       (const __half*)beta,                                                                      \
-      scale_inv, zero_point, out_q_or_null, (__half*)out_f16_or_null, g)
+      scale_inv, zero_point, out_q_or_null, (__half*)out_f16_or_null, g, raw)
   if (apply_silu) { if (unfused) GN_APPLY(true, true); else GN_APPLY(true, false); }
   else            { if (unfused) GN_APPLY(false, true); else GN_APPLY(false, false); }
 #undef GN_APPLY

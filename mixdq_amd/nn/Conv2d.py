@@ -272,6 +272,13 @@ class QuantizedConv2d(nn.Module):
         first = self._conv(x_int, "", self.bias)
         return self._conv(x_int_0, "_0", None, residual=first)
 
+    def forward_parts_quantized(self, x_int: torch.Tensor, x_int_0: torch.Tensor) -> torch.Tensor:
+        """forward_parts for halves already quantized with this layer's two activation quantizers
+        (act_scales / act_scales_0), e.g. by the GroupNorm pass that reads the same tensors."""
+        assert self.valid_for_acceleration and self.split == x_int.shape[1]
+        first = self._conv(x_int, "", self.bias)
+        return self._conv(x_int_0, "_0", None, residual=first)
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if not self.valid_for_acceleration:
             return self.forward_fp(x)

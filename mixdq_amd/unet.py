@@ -152,9 +152,12 @@ def _refresh_after_load(mod, _incompatible_keys):
     mod.refresh_derived_()
 
 
-def _gn_feed(norm: nn.GroupNorm, x, consumer, silu: bool, x2=None):
+def _gn_feed(norm: nn.GroupNorm, x, consumer, silu: bool, x2=None, raw_for=None):
     """GroupNorm(+SiLU) of a channels-last fp16 x for `consumer`: returns (tensor, quantized?).
-    x2: the norm is over cat([x, x2], dim=1), read from the two tensors in place."""
+    x2: the norm is over cat([x, x2], dim=1), read from the two tensors in place.
+    raw_for: a W8A8 conv that reads the norm's INPUT (the ResNet 1x1 shortcut, split when x2 is
+    given); the return value gains a third element: the input(s) quantized for it by the same pass
+    (a list, one INT8 tensor per source), or None when that pass is not the HIP kernel."""
     from mixdq_amd import _C
     N, C, H, W = x.shape
     C += 0 if x2 is None else x2.shape[1]
@@ -163,17 +166,28 @@ def _gn_feed(norm: nn.GroupNorm, x, consumer, silu: bool, x2=None):
                                 and x2.is_contiguous(memory_format=torch.channels_last)
                                 and x.shape[1] % 8 == 0 and x2.shape[1] % 8 == 0))
             and _C.groupnorm_supported(N, H * W, C, norm.num_groups)):
+        raw_qp = None
+        if (GN_RAW_OUTPUTS and raw_for is not None and _accel(raw_for)
+                and raw_for.split == (0 if x2 is None else x.shape[1])):
+            raw_qp = [(raw_for.act_scales_inv, raw_for.act_zero_points)]
+            if x2 is not None:
+                raw_qp.append((raw_for.act_scales_inv_0, raw_for.act_zero_points_0))
         if _accel(consumer):
-            q, _ = _C.groupnorm_silu_quantize(x, norm.num_groups, norm.weight, norm.bias, norm.eps,
-                                              *_qp(consumer), silu=silu, x2=x2)
-            return q, True
-        _, h = _C.groupnorm_silu_quantize(x, norm.num_groups, norm.weight, norm.bias, norm.eps,
-                                          silu=silu, want_f16=True, x2=x2)
-        return h, False
+            out = _C.groupnorm_silu_quantize(x, norm.num_groups, norm.weight, norm.bias, norm.eps,
+                                             *_qp(consumer), silu=silu, x2=x2, raw_qparams=raw_qp)
+            res = (out[0], True)
+        else:
+            out = _C.groupnorm_silu_quantize(x, norm.num_groups, norm.weight, norm.bias, norm.eps,
+                                             silu=silu, want_f16=True, x2=x2, raw_qparams=raw_qp)
+            res = (out[1], False)
+        if raw_for is None:
+            return res
+        return res + (out[2] if raw_qp is not None else None,)
     if x2 is not None:
         x = torch.cat([x, x2], dim=1)
     h = norm(x)
-    return (F.silu(h) if silu else h), False
+    res = ((F.silu(h) if silu else h), False)
+    return res if raw_for is None else res + (None,)
 
 
 _SHORTCUT_STREAMS = {}
@@ -183,6 +197,9 @@ _SHORTCUT_STREAMS = {}
 # branch: -0.5 ms) -- the step is one chain of launches on one stream.  MIXDQ_SHORTCUT_STREAM=1
 # restores the branch for A/B runs.
 SHORTCUT_SIDE_STREAM = __import__("os").environ.get("MIXDQ_SHORTCUT_STREAM", "0") == "1"
+# norm1's apply pass also writes the shortcut conv's INT8 operand(s) (MIXDQ_GN_RAW=0: separate
+# quantize launches, for A/B runs)
+GN_RAW_OUTPUTS = __import__("os").environ.get("MIXDQ_GN_RAW", "1") == "1"
 
 
 def _shortcut_stream(device):
@@ -336,19 +353,31 @@ class ResnetBlock2D(nn.Module):
             t = self.time_emb_proj(F.silu(temb))                   # [N, Cout]
         sc = None
         side = None
-        if skip is not None:      # split shortcut on the two halves as they are (no concatenation)
-            sc = self.conv_shortcut.forward_parts(x, skip)
-        elif self.conv_shortcut is not None and not SHORTCUT_SIDE_STREAM:
-            sc = self.conv_shortcut(x)
-        elif self.conv_shortcut is not None:
-            # the 1x1 shortcut (quantize + GEMM, twice for a split layer) only meets the main path
-            # at conv2's residual add: it runs beside norm1 / conv1 / norm2 on a side stream
+        if self.conv_shortcut is not None and SHORTCUT_SIDE_STREAM and skip is None:
+            # the 1x1 shortcut (quantize + GEMM) only meets the main path at conv2's residual add:
+            # beside norm1 / conv1 / norm2 on a side stream (A/B runs only, see above)
             main, side = torch.cuda.current_stream(), _shortcut_stream(x.device)
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 sc = self.conv_shortcut(x)
             x.record_stream(side)
-        feed, q = _gn_feed(self.norm1, x, self.conv1, silu=True, x2=skip)
+            feed, q = _gn_feed(self.norm1, x, self.conv1, silu=True)
+        elif self.conv_shortcut is not None:
+            # norm1's apply pass holds the block input in registers: it also writes the shortcut's
+            # INT8 operand(s) -- each half of a split shortcut with its own quantizer, where it lies
+            # (no concatenation) -- instead of separate quantize launches
+            feed, q, raw = _gn_feed(self.norm1, x, self.conv1, silu=True, x2=skip,
+                                    raw_for=self.conv_shortcut)
+            if raw is not None and skip is not None:
+                sc = self.conv_shortcut.forward_parts_quantized(raw[0], raw[1])
+            elif raw is not None:
+                sc = self.conv_shortcut.forward_quantized(raw[0])
+            elif skip is not None:
+                sc = self.conv_shortcut.forward_parts(x, skip)
+            else:
+                sc = self.conv_shortcut(x)
+        else:
+            feed, q = _gn_feed(self.norm1, x, self.conv1, silu=True, x2=skip)
         if q:   # h = conv1(..) + t[:, :, None, None], the add folded into the conv epilogue
             h = self.conv1.forward_quantized(feed, residual=t.contiguous(), residual_per_image=True)
         elif _fp_layer(self.conv1):

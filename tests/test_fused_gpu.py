@@ -293,6 +293,42 @@ def test_groupnorm_two_sources_equals_concatenation(C, N, H, W, C1, C2, G, silu)
     assert torch.equal(q1, q2) and torch.equal(h1, h2)
 
 
+@pytest.mark.parametrize("N,H,W,C1,C2,G,which", [(1, 16, 16, 64, 32, 8, (1, 1)), (2, 8, 12, 32, 64, 8, (0, 1)),
+                                                 (1, 32, 32, 640, 320, 32, (1, 1)), (1, 9, 7, 24, 0, 4, (1,)),
+                                                 (2, 32, 32, 320, 0, 32, (1,)), (1, 9, 7, 24, 8, 4, (1, 0))])
+def test_groupnorm_raw_outputs_are_the_quantized_inputs(C, oracle, N, H, W, C1, C2, G, which):
+    """The apply pass's second product: each source tensor quantized as it is (the ResNet
+    shortcut's operand) == mixdq_quantize_f16_i8 of that tensor == the oracle, with the norm's own
+    outputs unchanged."""
+    xa = t(dd.normal_f16(311, (N, H, W, C1), 1.3)).permute(0, 3, 1, 2)
+    xb = t(dd.normal_f16(312, (N, H, W, C2), 0.7)).permute(0, 3, 1, 2) if C2 else None
+    gamma = t((dd.normal_f16(313, (C1 + C2,), 0.3).astype(np.float32) + 1).astype(np.float16))
+    beta = t(dd.normal_f16(314, (C1 + C2,), 0.2))
+    s_inv, zp = scal(25.0), scal(-9.0)
+    qps = [(scal(40.0), scal(11.0)), (scal(17.5), scal(-30.0))][:len(which)]
+    raw_qp = [qp if w else None for qp, w in zip(qps, which)]
+    q0, h0 = C.groupnorm_silu_quantize(xa, G, gamma, beta, 1e-5, s_inv, zp, want_f16=True, x2=xb)
+    q1, h1, raws = C.groupnorm_silu_quantize(xa, G, gamma, beta, 1e-5, s_inv, zp, want_f16=True, x2=xb,
+                                             raw_qparams=raw_qp)
+    assert torch.equal(q0, q1) and torch.equal(h0, h1)
+    for src, qp, w, r in zip([xa, xb], qps, which, raws):
+        if not w:
+            assert r is None
+            continue
+        assert r.shape == src.shape and r.is_contiguous(memory_format=torch.channels_last)
+        assert torch.equal(r, C.quantize_per_tensor_to_int8(src, qp[0], qp[1]))
+        want = oracle.quantize(src.permute(0, 2, 3, 1).contiguous().cpu().numpy(),
+                               float(qp[0]), float(qp[1]), C.FLAGS & 1)
+        assert np.array_equal(r.permute(0, 2, 3, 1).contiguous().cpu().numpy(), want)
+    # only the f16 output, no consumer quantizer
+    _, h2, raws2 = C.groupnorm_silu_quantize(xa, G, gamma, beta, 1e-5, want_f16=True, x2=xb,
+                                             raw_qparams=raw_qp)
+    assert torch.equal(h2, h0) and all((a is None) == (b is None) and (a is None or torch.equal(a, b))
+                                       for a, b in zip(raws, raws2))
+    with pytest.raises(RuntimeError):
+        C.groupnorm_silu_quantize(xa, G, gamma, beta, 1e-5, s_inv, zp, x2=xb, raw_qparams=[qps[0]] * 3)
+
+
 def test_split_shortcut_on_unconcatenated_halves(C, modules_golden):
     """QuantizedConv2d.forward_parts(x_a, x_b) == forward(cat([x_a, x_b])) == the reference class's
     output (modules.npz), bit for bit."""
@@ -307,6 +343,9 @@ def test_split_shortcut_on_unconcatenated_halves(C, modules_golden):
     xb = x[:, c["split"]:].contiguous(memory_format=torch.channels_last)
     with torch.no_grad():
         y, yp = qm(x), qm.forward_parts(xa, xb)
-    assert torch.equal(y, yp)
+        ypq = qm.forward_parts_quantized(C.quantize_per_tensor_to_int8(xa, qm.act_scales_inv, qm.act_zero_points),
+                                         C.quantize_per_tensor_to_int8(xb, qm.act_scales_inv_0,
+                                                               qm.act_zero_points_0))
+    assert torch.equal(y, yp) and torch.equal(y, ypq)
     want = modules_golden["conv_split.out"]
     assert np.array_equal(yp.contiguous().cpu().numpy().view(np.uint16), want.view(np.uint16))

@@ -1,0 +1,4 @@
+#!/bin/bash
+# A/B an environment switch inside the whole captured step:  gpu_ab_env.sh VAR=a VAR=b ...
+run() { echo "== $1"; env "$1" timeout 600 python bench.py --no-fp16 --no-cpu-baseline --no-roofline --steps 30 2>/dev/null | python3 -c "import sys,json; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(r['ms_per_step'])"; }
+for c in "$@"; do run "$c"; done
