@@ -90,7 +90,9 @@ IGEMM_CONFIGS = {1: (64, 64, 64, 2), 3: (128, 128, 64, 2), 4: (64, 64, 128, 3),
                  # 16x16x64-MFMA tiles (exactly one workgroup per CU on the UNet's M = 1024 / 4096
                  # layers; 45 / 56: deeper pipelines) and the 4-stage 128x320 tile
                  42: (64, 80, 128, 3), 43: (64, 240, 128, 3), 44: (128, 80, 128, 3),
-                 45: (64, 80, 128, 4), 46: (128, 320, 64, 4), 56: (64, 80, 128, 6)}
+                 45: (64, 80, 128, 4), 46: (128, 320, 64, 4), 56: (64, 80, 128, 6),
+                 # 256x256x128 on the four-phase loop (2 x 4 waves of 128x64, 16x16x64 MFMAs)
+                 70: (256, 256, 128, 2), 71: (256, 256, 64, 4)}
 
 FLAG_W4 = 2   # MIXDQ_FLAG_W4: the weight tensor holds packed signed 4-bit values
 

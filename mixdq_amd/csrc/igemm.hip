@@ -144,8 +144,13 @@ __device__ __forceinline__ uint32_t add_f16x2(uint32_t a, uint32_t b) {
 // Used for the layers the reference leaves in FP16 (no activation quantizer: conv_in / conv_out,
 // the act-protected ff.net.2 ..., nn/Linear.py:155-156): D = f16(acc + bias) [+ residual].
 template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool CONV, bool FAST, bool W4,
-          int KSPLIT = 1, int MT = 32, bool F16 = false, bool ATT = false>
+          int KSPLIT = 1, int MT = 32, bool F16 = false, bool ATT = false, bool PHASED = false>
 __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const IgemmParams p_in) {
+  static_assert(!PHASED || (BM == 256 && BN == 256 && ((BK == 128 && STAGES == 2) || (BK == 64 && STAGES == 4)) &&
+                            WM == 2 && WN == 4 && KSPLIT == 1 && MT == 16 && FAST && !CONV && !W4 &&
+                            !F16 && !ATT),
+                "the phased loops are written for the 256x256 tile, 2 x 4 waves of 128x64");
+  static_assert(MT == 32 || BK == 128 || PHASED, "the 16x16x64 fragment reads are laid out for 128-byte rows");
   static_assert(!ATT || (BM == 64 && BN == 128 && NWAVES_OF(WM, WN, KSPLIT) == 8 && MT == 32 && !CONV &&
                          !F16), "the attention epilogue is written for the 64x128 8-wave tile");
   static_assert(!(CONV && FAST), "the fast staging path is for Linear");
@@ -182,7 +187,6 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const Igem
   static_assert(TM >= 1 && TN >= 1 && TM * MT * WM == BM && TN * MT * WN == BN,
                 "wave tiles are whole MFMA tiles");
   static_assert(STAGES >= 2 && (PRE - 1) * (A_NI + B_NI) <= 63, "vmcnt is a 6-bit counter");
-  static_assert(MT == 32 || BK == 128, "the 16x16x64 fragment reads are laid out for 128-byte rows");
   extern __shared__ __attribute__((aligned(16))) char smem[];   // igemm_smem_bytes<...>()
 
   const int tid = threadIdx.x;
@@ -441,8 +445,80 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const Igem
       glds16(base + ((int64_t)key * rs + (spos ^ sw) * 8), dst + i * 1024);
     }
   }
+  // ---- PHASED: the 256x256x128 tile in four phases per K-tile ---------------------------------
+  // Each wave owns 128 x 64 of the output as 2 x 2 quadrants of 64 x 32 (16 MFMAs 16x16x64 over the
+  // K-tile each); a phase = one quadrant: the LDS reads of the fragments that changed (snake order:
+  // 12, 4, 8, 4 ds_read_b128), the DMA of one quarter of the NEXT K-tile, then the 16 MFMAs at raised
+  // priority between two barriers.  Waves 4..7 run one barrier behind waves 0..3, so on every SIMD
+  // one wave multiplies while the other reads and stages.  The next K-tile is staged in the four
+  // "units" the phases consume -- activation rows of row-half mh of every wave, weight rows of
+  // column-half nh -- in the order they are first read (A0, B0, B1, A1), two 1-KiB pieces per wave
+  // each; three phases of DMA lead, counted waits (vmcnt(4): the two youngest units may fly).
+  unsigned ph_a[2][2], ph_b[2][2];      // per-lane source offsets of (unit, piece)
+  if constexpr (PHASED) {
 #pragma unroll
-  for (int s = 0; s < PRE; ++s) stage(s, s * BK);
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int q = wid * 2 + j;                                   // piece of the unit, 0..15
+        const int ra = (q >> 3) * 128 + h * 64 + (q & 7) * 8 + (lane >> 3);
+        const int rb = (q >> 2) * 64 + h * 32 + (q & 3) * 8 + (lane >> 3);
+        const int64_t m = m0 + ra;
+        const int n = n0 + rb;
+        ph_a[h][j] = (uint32_t)(m < p.M ? m : p.M - 1) * (uint32_t)Ktot + (((lane & 7) ^ swz<BK>(ra)) << 4);
+        ph_b[h][j] = (uint32_t)min(n, p.N - 1) * (uint32_t)Ktot + (((lane & 7) ^ swz<BK>(rb)) << 4);
+      }
+  }
+  auto stage_unit = [&](int buf, int kk, int unit) {   // unit: 0 A0, 1 B0, 2 B1, 3 A1 (compile-time)
+    const int kk_u = __builtin_amdgcn_readfirstlane(kk < Ktot ? kk : 0);
+    char* S = smem + buf * STAGE;
+    const bool is_a = unit == 0 || unit == 3;
+    const int h = unit >= 2 ? 1 : 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int q = wid * 2 + j;
+      if (is_a)
+        glds16(p.A + kk_u + ph_a[h][j], S + ((q >> 3) * 128 + h * 64 + (q & 7) * 8) * BK);
+      else
+        glds16(p.Wt + kk_u + ph_b[h][j], S + A_STAGE + ((q >> 2) * 64 + h * 32 + (q & 3) * 8) * BK);
+    }
+  };
+  // ---- PHASED, BK = 64: the same tile over 64-byte K-tiles in a ring of FOUR buffers ----------
+  // The loop above keeps 32-48 KB of DMA in flight per CU and moves ~31 GB/s per CU: with ~1 us of
+  // loaded L2 latency the bytes in flight are the limit, and what can be in flight is what LDS can
+  // land.  Here a K-tile is 32 KB (one 16x16x64 k-step): one buffer is read while up to five 16-KB
+  // units (activation tile, weight tile, alternating; 2.5 K-tiles) fly into the other three.  Two
+  // phases per K-tile (the wave's row halves), 16 MFMAs each; unit P + 5 is staged in phase P.
+  unsigned ph4_a[2], ph4_b[2];          // per-lane source offsets of a unit's two pieces
+  if constexpr (PHASED && BK == 64) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int r = (wid * 2 + j) * 16 + (lane >> 2);                // piece = 16 rows x 64 B
+      const int64_t m = m0 + r;
+      const int n = n0 + r;
+      ph4_a[j] = (uint32_t)(m < p.M ? m : p.M - 1) * (uint32_t)Ktot + (((lane & 3) ^ swz<BK>(r)) << 4);
+      ph4_b[j] = (uint32_t)min(n, p.N - 1) * (uint32_t)Ktot + (((lane & 3) ^ swz<BK>(r)) << 4);
+    }
+  }
+  auto stage_unit4 = [&](int u) {       // unit u: the activation (even) or weight (odd) tile of K-tile u / 2
+    const int kt = u >> 1;
+    const int kk_u = __builtin_amdgcn_readfirstlane(kt * BK < Ktot ? kt * BK : 0);
+    char* S = smem + (kt & 3) * STAGE + ((u & 1) ? A_STAGE : 0);
+    const int8_t* src = ((u & 1) ? p.Wt : p.A) + kk_u;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      glds16(src + ((u & 1) ? ph4_b[j] : ph4_a[j]), S + (wid * 2 + j) * 1024);
+  };
+  if constexpr (!PHASED) {
+#pragma unroll
+    for (int s = 0; s < PRE; ++s) stage(s, s * BK);
+  } else if constexpr (BK == 128) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) stage_unit(0, 0, u);
+  } else {
+#pragma unroll
+    for (int u = 0; u < 5; ++u) stage_unit4(u);
+  }
 
   // ---- per-channel epilogue vectors -> LDS, issued now so their latency hides under the main
   //      loop (read back ~100 cycles away instead of ~1 us away per quad at the end).
@@ -471,7 +547,121 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const Igem
     *reinterpret_cast<uint2*>(P_BS + tid * 4) = bs;
   }
 
-  for (int kt0 = 0; kt0 < nk; kt0 += STAGES) {
+  if constexpr (PHASED && BK == 64) {
+    const int a_lane = (wm * WTM + lrow) * BK + ((lkq ^ swz<BK>(lrow)) << 4);
+    const int b_lane = A_STAGE + (wn * WTN + lrow) * BK + ((lkq ^ swz<BK>(lrow)) << 4);
+    v4i af[4], bf[4];
+    auto half = [&](int mh) {
+      asm volatile("s_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_setprio(1);
+#if MIXDQ_ABLATE == 1
+#pragma unroll
+      for (int t = 0; t < 4; ++t) { asm volatile("" ::"v"(bf[t])); asm volatile("" ::"v"(af[t])); }
+#else
+#pragma unroll
+      for (int tn = 0; tn < 4; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) acc[tn][mh * 4 + tm] = mfma(bf[tn], af[tm], acc[tn][mh * 4 + tm]);
+#endif
+      __builtin_amdgcn_s_setprio(0);
+      asm volatile("s_barrier" ::: "memory");
+    };
+    // K-tile 0 has landed (units 2..4 may fly) and is visible to every wave
+    asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+    if (wid >= 4) asm volatile("s_barrier" ::: "memory");   // the second wave group: one barrier behind
+    for (int kt = 0; kt < nk; ++kt) {
+      const char* S0 = smem + (kt & 3) * STAGE;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) bf[t] = *reinterpret_cast<const v4i*>(S0 + b_lane + t * 16 * BK);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) af[t] = *reinterpret_cast<const v4i*>(S0 + a_lane + t * 16 * BK);
+      if (MIXDQ_ABLATE != 3) stage_unit4(2 * kt + 5);
+      half(0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) af[t] = *reinterpret_cast<const v4i*>(S0 + a_lane + (4 + t) * 16 * BK);
+      if (MIXDQ_ABLATE != 3) stage_unit4(2 * kt + 6);
+      // K-tile kt + 1 (units 2 kt + 2, 2 kt + 3): waited for one phase before its first read, so
+      // that both wave groups' pieces are behind a barrier every reader has passed
+      if (MIXDQ_ABLATE != 5) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      half(1);
+    }
+    if (wid < 4) asm volatile("s_barrier" ::: "memory");    // the groups meet again
+  }
+  if constexpr (PHASED && BK == 128) {
+    // fragment read offsets: the swizzle term depends on the lane's row within its 16-row tile
+    // only, so every other tile of the wave is the same address plus an immediate
+    const int a_lane = (wm * WTM + lrow) * BK, b_lane = A_STAGE + (wn * WTN + lrow) * BK;
+    int fr[2];                             // 16-byte chunk of k-step ks for this lane, swizzled
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) fr[ks] = ((ks * CPS + lkq) ^ swz<BK>(lrow)) << 4;
+    v4i af[4][2], bf[2][2];
+    auto read_a = [&](const char* S0, int mh) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          af[t][ks] = *reinterpret_cast<const v4i*>(S0 + a_lane + (mh * 4 + t) * 16 * BK + fr[ks]);
+    };
+    auto read_b = [&](const char* S0, int nh) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+          bf[t][ks] = *reinterpret_cast<const v4i*>(S0 + b_lane + (nh * 2 + t) * 16 * BK + fr[ks]);
+    };
+    auto quadrant = [&](int mh, int nh) {
+      asm volatile("s_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_setprio(1);
+#if MIXDQ_ABLATE == 1
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) asm volatile("" ::"v"(bf[tn][ks]));
+#pragma unroll
+        for (int tm = 0; tm < 4; ++tm) asm volatile("" ::"v"(af[tm][ks]));
+      }
+#else
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+          for (int tm = 0; tm < 4; ++tm)
+            acc[nh * 2 + tn][mh * 4 + tm] =
+                mfma(bf[tn][ks], af[tm][ks], acc[nh * 2 + tn][mh * 4 + tm]);
+#endif
+      __builtin_amdgcn_s_setprio(0);
+      asm volatile("s_barrier" ::: "memory");
+    };
+    // tile 0's A0 and B0 have landed (its B1, A1 may fly) and are visible to every wave
+    asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+    if (wid >= 4) asm volatile("s_barrier" ::: "memory");   // the second wave group: one barrier behind
+    for (int kt = 0; kt < nk; ++kt) {
+      const char* S0 = smem + (kt & 1) * STAGE;
+      const int nb = (kt + 1) & 1, nkk = (kt + 1) * BK;
+      // a unit is read one phase (two barriers) after the wait that retires it: both wave groups'
+      // pieces have then been waited for in front of a barrier the reader has passed
+      read_b(S0, 0); __builtin_amdgcn_sched_barrier(0); read_a(S0, 0);
+      if (MIXDQ_ABLATE != 3) stage_unit(nb, nkk, 0);
+#define MIXDQ_PH_WAIT() do { if (MIXDQ_ABLATE != 5) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); } while (0)
+      MIXDQ_PH_WAIT();                                      // B1 of this tile (phase 1)
+      quadrant(0, 0);
+      read_b(S0, 1);
+      if (MIXDQ_ABLATE != 3) stage_unit(nb, nkk, 1);
+      MIXDQ_PH_WAIT();                                      // A1 of this tile (phase 2)
+      quadrant(0, 1);
+      read_a(S0, 1);
+      if (MIXDQ_ABLATE != 3) stage_unit(nb, nkk, 2);
+      quadrant(1, 1);
+      read_b(S0, 0);
+      if (MIXDQ_ABLATE != 3) stage_unit(nb, nkk, 3);
+      MIXDQ_PH_WAIT();                                      // A0, B0 of the next tile (its phase 0)
+      quadrant(1, 0);
+    }
+    if (wid < 4) asm volatile("s_barrier" ::: "memory");    // the groups meet again
+  }
+  for (int kt0 = 0; !PHASED && kt0 < nk; kt0 += STAGES) {
 #pragma unroll
     for (int s = 0; s < STAGES; ++s) {      // tile kt0 + s lives in buffer s (compile-time)
       const int kt = kt0 + s;
@@ -1000,7 +1190,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const __half* __restrict_
 }
 
 template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool CONV, bool FAST, bool W4, int KSPLIT,
-          int MT, bool F16 = false>
+          int MT, bool F16 = false, bool PHASED = false>
 int launch_kernel(IgemmParams& p, hipStream_t stream) {
   constexpr int SMEM = igemm_smem_bytes<BM, BN, BK, STAGES>();
   static_assert(SMEM <= 160 * 1024, "LDS is 160 KiB per CU");
@@ -1008,7 +1198,7 @@ int launch_kernel(IgemmParams& p, hipStream_t stream) {
   if constexpr (SMEM > 64 * 1024) {   // opt in to > 64 KiB of dynamic LDS, once per instantiation
     static const hipError_t attr = hipFuncSetAttribute(
         reinterpret_cast<const void*>(
-            &igemm_kernel<BM, BN, BK, STAGES, WM, WN, CONV, FAST, W4, KSPLIT, MT, F16>),
+            &igemm_kernel<BM, BN, BK, STAGES, WM, WN, CONV, FAST, W4, KSPLIT, MT, F16, false, PHASED>),
         hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (attr != hipSuccess) return MIXDQ_ERR_LAUNCH;
   }
@@ -1017,50 +1207,60 @@ int launch_kernel(IgemmParams& p, hipStream_t stream) {
   const int64_t grid = (int64_t)p.tiles_m * p.tiles_n;
   if (grid <= 0 || grid > 0x7fffffff) return MIXDQ_ERR_INVALID_ARG;
   const int ny = p.groups != nullptr ? p.ngroups_launch : 1;
-  igemm_kernel<BM, BN, BK, STAGES, WM, WN, CONV, FAST, W4, KSPLIT, MT, F16>
+  igemm_kernel<BM, BN, BK, STAGES, WM, WN, CONV, FAST, W4, KSPLIT, MT, F16, false, PHASED>
       <<<dim3((unsigned)grid, (unsigned)ny), 64 * WM * WN * KSPLIT, SMEM, stream>>>(p);
   return launch_status();
 }
 
 template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool CONV, bool W4, int KSPLIT, int MT,
-          bool F16 = false>
+          bool F16 = false, bool PHASED = false>
 int launch_tile(IgemmParams& p, hipStream_t stream) {
   if constexpr (!CONV) {
     const bool fits32 = (uint64_t)p.M * (uint64_t)p.Ktot < (1ull << 32) &&
                         (uint64_t)p.N * (uint64_t)p.Ktot < (1ull << 32);
-    if (p.Ktot % BK == 0 && fits32)
-      return launch_kernel<BM, BN, BK, STAGES, WM, WN, false, true, W4, KSPLIT, MT, F16>(p, stream);
+    if (p.Ktot % BK == 0 && fits32) {
+      if constexpr (PHASED && !W4 && !F16)
+        return launch_kernel<BM, BN, BK, STAGES, WM, WN, false, true, false, KSPLIT, MT, false, true>(p, stream);
+      else if constexpr (!PHASED)
+        return launch_kernel<BM, BN, BK, STAGES, WM, WN, false, true, W4, KSPLIT, MT, F16>(p, stream);
+    }
   }
-  return launch_kernel<BM, BN, BK, STAGES, WM, WN, CONV, false, W4, KSPLIT, MT, F16>(p, stream);
+  if constexpr (PHASED)   // convs, packed weights, K tails: the same tile on the one-phase loop
+    return launch_kernel<BM, BN, BK, STAGES, 4, 2, CONV, false, W4, 1, 32, F16>(p, stream);
+  else
+    return launch_kernel<BM, BN, BK, STAGES, WM, WN, CONV, false, W4, KSPLIT, MT, F16>(p, stream);
 }
 
 // Kernel configurations.  id 0 = automatic choice; ids 1.. can be forced through bits 8..15 of
 // the `flags` argument of the C entry points (tuning / tests only).
-// X(id, BM, BN, BK, STAGES, WM, WN, KSPLIT, MT): block tile, K-tile bytes, LDS stages, wave grid
-// (m x n), k-split groups (x WM*WN waves each), MFMA shape (32: 32x32x32, 16: 16x16x64)
+// X(id, BM, BN, BK, STAGES, WM, WN, KSPLIT, MT, PHASED): block tile, K-tile bytes, LDS stages, wave
+// grid (m x n), k-split groups (x WM*WN waves each), MFMA shape (32: 32x32x32, 16: 16x16x64), the
+// four-phase main loop
 #define MIXDQ_IGEMM_CONFIGS(X)            \
-  X(1, 64, 64, 64, 2, 2, 2, 1, 32)        \
-  X(3, 128, 128, 64, 2, 2, 2, 1, 32)      \
-  X(4, 64, 64, 128, 3, 2, 2, 1, 32)       \
-  X(13, 256, 128, 64, 3, 4, 2, 1, 32)     \
-  X(14, 256, 256, 64, 3, 4, 2, 1, 32)     \
-  X(15, 128, 256, 64, 3, 2, 4, 1, 32)     \
-  X(18, 256, 128, 128, 2, 4, 2, 1, 32)    \
-  X(20, 256, 256, 128, 2, 4, 2, 1, 32)    \
-  X(25, 128, 320, 128, 2, 4, 2, 1, 32)    \
-  X(35, 128, 128, 64, 3, 4, 2, 1, 32)     \
-  X(37, 64, 64, 128, 3, 2, 2, 2, 32)      \
-  X(41, 64, 128, 128, 3, 2, 4, 1, 32)     \
-  X(42, 64, 80, 128, 3, 4, 1, 2, 16)      \
-  X(43, 64, 240, 128, 3, 4, 1, 2, 16)     \
-  X(44, 128, 80, 128, 3, 4, 1, 2, 16)     \
-  X(45, 64, 80, 128, 4, 4, 1, 2, 16)      \
-  X(46, 128, 320, 64, 4, 4, 2, 1, 32)     \
-  X(56, 64, 80, 128, 6, 4, 1, 2, 16)
+  X(1, 64, 64, 64, 2, 2, 2, 1, 32, false)        \
+  X(3, 128, 128, 64, 2, 2, 2, 1, 32, false)      \
+  X(4, 64, 64, 128, 3, 2, 2, 1, 32, false)       \
+  X(13, 256, 128, 64, 3, 4, 2, 1, 32, false)     \
+  X(14, 256, 256, 64, 3, 4, 2, 1, 32, false)     \
+  X(15, 128, 256, 64, 3, 2, 4, 1, 32, false)     \
+  X(18, 256, 128, 128, 2, 4, 2, 1, 32, false)    \
+  X(20, 256, 256, 128, 2, 4, 2, 1, 32, false)    \
+  X(25, 128, 320, 128, 2, 4, 2, 1, 32, false)    \
+  X(35, 128, 128, 64, 3, 4, 2, 1, 32, false)     \
+  X(37, 64, 64, 128, 3, 2, 2, 2, 32, false)      \
+  X(41, 64, 128, 128, 3, 2, 4, 1, 32, false)     \
+  X(42, 64, 80, 128, 3, 4, 1, 2, 16, false)      \
+  X(43, 64, 240, 128, 3, 4, 1, 2, 16, false)     \
+  X(44, 128, 80, 128, 3, 4, 1, 2, 16, false)     \
+  X(45, 64, 80, 128, 4, 4, 1, 2, 16, false)      \
+  X(46, 128, 320, 64, 4, 4, 2, 1, 32, false)     \
+  X(56, 64, 80, 128, 6, 4, 1, 2, 16, false)  \
+  X(70, 256, 256, 128, 2, 2, 4, 1, 16, true)   \
+  X(71, 256, 256, 64, 4, 2, 4, 1, 16, true)
 
 struct TileCfg { int id, bm, bn, bk, stages, wm, wn, ksplit, mt; };
 constexpr TileCfg kTileCfgs[] = {
-#define X(ID, BM, BN, BK, ST, WM, WN, KS, MT) {ID, BM, BN, BK, ST, WM, WN, KS, MT},
+#define X(ID, BM, BN, BK, ST, WM, WN, KS, MT, PH) {ID, BM, BN, BK, ST, WM, WN, KS, MT},
     MIXDQ_IGEMM_CONFIGS(X)
 #undef X
 };
@@ -1088,7 +1288,8 @@ inline const std::vector<TuneEntry>& tune_overrides() {
 }
 
 // whole64: the launch needs BN % 64 == 0 (GEMM+GEGLU: whole value/gate groups per tile)
-inline int select_cfg(int64_t M, int N, int Ktot, bool whole64 = false) {
+// phased_ok: a Linear launch on the fast staging path (K % 128 == 0, 32-bit operand offsets)
+inline int select_cfg(int64_t M, int N, int Ktot, bool whole64 = false, bool phased_ok = false) {
   for (const TuneEntry& t : tune_overrides())
     if (t.M == M && t.N == N && t.K == Ktot) return t.cfg;
   auto blocks = [&](int tm, int tn) {
@@ -1099,6 +1300,12 @@ inline int select_cfg(int64_t M, int N, int Ktot, bool whole64 = false) {
   const int64_t b320 = blocks(128, 320);
   if (N % 320 == 0 && Ktot % 128 == 0 && Ktot >= 1024 && (b320 == kNumCU || b320 == 2 * kNumCU))
     return 25;   // (K = 640: its two 128-byte-deep stages are too shallow, 128x128 wins)
+  // from 1.5 workgroups of 256x256 per CU on: the four-phase loop (fewest L2->LDS bytes per MAC, the
+  // reads and the DMA of one wave group under the other's MFMAs): (8192, 10240, 1280) 135 vs 153 us on
+  // 256x128, (8192, 3840, 1280) 56 vs 62, (32768, 1920, 640) 77 vs 84 (tools/bench_gemm.py --bs 8)
+  // (not for GEMM+GEGLU: with one workgroup per CU nothing runs under the GELU epilogue of a 256x256
+  // tile -- batch 8 step 59.1 ms with those launches on it, 57.1 with them on 256x128)
+  if (phased_ok && !whole64 && Ktot >= 640 && 2 * blocks(256, 256) >= 3 * kNumCU) return 70;
   if (blocks(256, 128) >= 2 * kNumCU)
     return (Ktot >= 4096 && blocks(256, 256) >= kNumCU) ? 20 : 13;
   // exact-fit 16x16x64-MFMA tiles (tools/bench_gemm.py, batch 1): 128x80 when that is exactly one
@@ -1165,12 +1372,15 @@ int dispatch(IgemmParams& p, hipStream_t stream, int forced_cfg) {
     }
   }
   const bool whole64 = p.Dq != nullptr;
+  const bool phased_ok = !CONV && p.Ktot % 128 == 0 &&
+                         (uint64_t)p.M * (uint64_t)p.Ktot < (1ull << 32) &&
+                         (uint64_t)p.N * (uint64_t)p.Ktot < (1ull << 32);
   const int cfg = forced_cfg > 0 ? forced_cfg
                                  : (W4 ? select_cfg_w4(p.M, p.N, p.Ktot, whole64)
-                                       : select_cfg(p.M, p.N, p.Ktot, whole64));
+                                       : select_cfg(p.M, p.N, p.Ktot, whole64, phased_ok));
   switch (cfg) {
-#define X(ID, BM, BN, BK, ST, WM, WN, KS, MT) \
-  case ID: return launch_tile<BM, BN, BK, ST, WM, WN, CONV, W4, KS, MT>(p, stream);
+#define X(ID, BM, BN, BK, ST, WM, WN, KS, MT, PH) \
+  case ID: return launch_tile<BM, BN, BK, ST, WM, WN, CONV, W4, KS, MT, false, PH>(p, stream);
     MIXDQ_IGEMM_CONFIGS(X)
 #undef X
     default: return MIXDQ_ERR_INVALID_ARG;
@@ -1202,8 +1412,8 @@ template <bool W4>
 int dispatch_grouped(IgemmParams& p, int ngroups, hipStream_t stream, int cfg) {
   p.ngroups_launch = ngroups;
   switch (cfg) {
-#define X(ID, BM, BN, BK, ST, WM, WN, KS, MT) \
-  case ID: return launch_tile<BM, BN, BK, ST, WM, WN, false, W4, KS, MT>(p, stream);
+#define X(ID, BM, BN, BK, ST, WM, WN, KS, MT, PH) \
+  case ID: return launch_tile<BM, BN, BK, ST, WM, WN, false, W4, KS, MT, false, PH>(p, stream);
     MIXDQ_IGEMM_CONFIGS(X)
 #undef X
     default: return MIXDQ_ERR_INVALID_ARG;
@@ -1581,10 +1791,16 @@ extern "C" const char* mixdq_status_string(int status) {
 
 extern "C" int mixdq_abi_version(void) { return MIXDQ_ABI_VERSION; }
 
+// a Linear problem (k_align == k_total: no taps) that takes the fast staging path
+static bool linear_fast(int64_t M, int N, int k_align, int k_total) {
+  return k_align == k_total && k_total % 128 == 0 &&
+         (uint64_t)M * (uint64_t)k_total < (1ull << 32) && (uint64_t)N * (uint64_t)k_total < (1ull << 32);
+}
+
 extern "C" int mixdq_igemm_select_id(int64_t M, int N, int k_align, int k_total) {
   if (M <= 0 || N <= 0 || k_align % 4 != 0 || N % 4 != 0) return -1;
   if (k_align % 16 != 0) return 0;   // generic kernel
-  return select_cfg(M, N, k_total);
+  return select_cfg(M, N, k_total, false, linear_fast(M, N, k_align, k_total));
 }
 
 extern "C" int mixdq_igemm_select_id_w4(int64_t M, int N, int k_align, int k_total) {
@@ -1597,7 +1813,7 @@ extern "C" int mixdq_igemm_select(int64_t M, int N, int k_align, int k_total, in
   if (!bm || !bn || !bk || !stages || M <= 0 || N <= 0) return MIXDQ_ERR_INVALID_ARG;
   if (k_align % 4 != 0 || N % 4 != 0) return MIXDQ_ERR_ALIGNMENT;
   if (k_align % 16 != 0) { *bm = *bn = *bk = *stages = 0; return MIXDQ_OK; }   // generic kernel
-  const int cfg = select_cfg(M, N, k_total);
+  const int cfg = select_cfg(M, N, k_total, false, linear_fast(M, N, k_align, k_total));
   for (const TileCfg& c : kTileCfgs)
     if (c.id == cfg) { *bm = c.bm; *bn = c.bn; *bk = c.bk; *stages = c.stages; }
   return MIXDQ_OK;

@@ -148,6 +148,8 @@ GEGLU_GEMM_CASES = [  # M, D, K, forced tile config (0 = automatic), bias
     (200, 160, 128, 3, True), (200, 160, 128, 41, True), (300, 128, 256, 13, True),
     (513, 256, 192, 18, False), (257, 256, 128, 20, True), (1, 32, 16, 0, True),
     (300, 320, 256, 25, True), (300, 320, 192, 46, True), (130, 160, 128, 46, False),
+    # the four-phase 256x256 loop: M tail, several column tiles, a K tail (one-phase fallback)
+    (300, 256, 256, 70, True), (513, 384, 384, 70, False), (257, 256, 192, 70, True),
 ]
 
 
