@@ -167,7 +167,8 @@ def _gn_feed(norm: nn.GroupNorm, x, consumer, silu: bool, x2=None, raw_for=None)
                                 and x.shape[1] % 8 == 0 and x2.shape[1] % 8 == 0))
             and _C.groupnorm_supported(N, H * W, C, norm.num_groups)):
         raw_qp = None
-        if (GN_RAW_OUTPUTS and raw_for is not None and _accel(raw_for)
+        if (GN_RAW_OUTPUTS and raw_for is not None and getattr(raw_for, "valid_for_acceleration", False)
+                and not getattr(raw_for, "bos", False)
                 and raw_for.split == (0 if x2 is None else x.shape[1])):
             raw_qp = [(raw_for.act_scales_inv, raw_for.act_zero_points)]
             if x2 is not None:
