@@ -164,7 +164,7 @@ def roofline_sweep(run_eager, device, reps):
         elif kind == "linear_attn":      # to_q + cross-attention: always the 64x128 8-wave tile
             cid = 41
         else:
-            cid = C.igemm_select_id(M, N, k_align, K, w4=w4)
+            cid = C.igemm_select_id(M, N, k_align, K, w4=w4, geglu=kind == "linear_geglu")
         bm, bn, bk, st = C.IGEMM_CONFIGS.get(cid, (0, 0, 0, 0))
         kname = f"igemm_kernel<{bm},{bn},{bk},{st},{kind}{',w4' if w4 else ''}>#cfg{cid}"
         g_ = groups.setdefault(kname, dict(fns=[], ops=0.0, bytes=0.0))

@@ -340,6 +340,9 @@ int mixdq_igemm_select(int64_t M, int N, int k_align, int k_total, int* bm, int*
 int mixdq_igemm_select_id(int64_t M, int N, int k_align, int k_total);
 /* The same for a packed-W4 weight operand (MIXDQ_FLAG_W4); -1 = invalid (k_align % 32 != 0). */
 int mixdq_igemm_select_id_w4(int64_t M, int N, int k_align, int k_total);
+/* The same for the GEMM + GEGLU + quantize launch (mixdq_qlinear_w8a8_geglu), whose tiles hold whole
+ * 64-column value / gate groups and which does not take the 256x256 four-phase loop. */
+int mixdq_igemm_select_id_geglu(int64_t M, int N, int k_total, int w4);
 
 #ifdef __cplusplus
 }

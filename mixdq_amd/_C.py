@@ -64,9 +64,16 @@ _lib.mixdq_igemm_select_id_w4.argtypes = [_i64, _i32, _i32, _i32]
 _lib.mixdq_igemm_select_id_w4.restype = _i32
 
 
-def igemm_select_id(M: int, N: int, k_align: int, k_total: int = 0, w4: bool = False) -> int:
+_lib.mixdq_igemm_select_id_geglu.argtypes = [_i64, _i32, _i32, _i32]
+_lib.mixdq_igemm_select_id_geglu.restype = _i32
+
+
+def igemm_select_id(M: int, N: int, k_align: int, k_total: int = 0, w4: bool = False,
+                    geglu: bool = False) -> int:
     """Configuration id (IGEMM_CONFIGS key) the automatic choice makes for this problem
-    (`w4`: for packed 4-bit weights, MIXDQ_FLAG_W4)."""
+    (`w4`: for packed 4-bit weights, MIXDQ_FLAG_W4; `geglu`: for the GEMM + GEGLU launch)."""
+    if geglu:
+        return int(_lib.mixdq_igemm_select_id_geglu(M, N, k_total or k_align, int(w4)))
     if w4:
         return int(_lib.mixdq_igemm_select_id_w4(M, N, k_align, k_total or k_align))
     return int(_lib.mixdq_igemm_select_id(M, N, k_align, k_total or k_align))

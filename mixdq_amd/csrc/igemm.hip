@@ -1808,6 +1808,12 @@ extern "C" int mixdq_igemm_select_id_w4(int64_t M, int N, int k_align, int k_tot
   return select_cfg_w4(M, N, k_total);
 }
 
+extern "C" int mixdq_igemm_select_id_geglu(int64_t M, int N, int k_total, int w4) {
+  if (M <= 0 || N <= 0 || N % 64 != 0 || k_total % (w4 ? 32 : 16) != 0) return -1;
+  return w4 ? select_cfg_w4(M, N, k_total, true)
+            : select_cfg(M, N, k_total, true, linear_fast(M, N, k_total, k_total));
+}
+
 extern "C" int mixdq_igemm_select(int64_t M, int N, int k_align, int k_total, int* bm, int* bn,
                                   int* bk, int* stages) {
   if (!bm || !bn || !bk || !stages || M <= 0 || N <= 0) return MIXDQ_ERR_INVALID_ARG;
