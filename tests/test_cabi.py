@@ -67,3 +67,33 @@ def test_product_path_has_no_oracle_or_cpu_fallback():
     for path in glob.glob(os.path.join(ROOT, "mixdq_amd", "**", "*.py"), recursive=True):
         src = open(path).read()
         assert "import oracle" not in src and "from oracle" not in src, path
+
+
+def test_tile_choice_is_a_host_function_of_the_shape():
+    """The automatic tile choice (host code, no GPU): UNet shapes at batch 1 and batch 8, the
+    Linear-only four-phase loop, the GEMM+GEGLU launch and the packed-W4 rule."""
+    from mixdq_amd.build import build
+    lib = ctypes.CDLL(build())
+    i64, i32 = ctypes.c_int64, ctypes.c_int
+    for fn in (lib.mixdq_igemm_select_id, lib.mixdq_igemm_select_id_w4):
+        fn.argtypes, fn.restype = [i64, i32, i32, i32], i32
+    lib.mixdq_igemm_select_id_geglu.argtypes, lib.mixdq_igemm_select_id_geglu.restype = [i64, i32, i32, i32], i32
+    sel = lib.mixdq_igemm_select_id
+    # batch 1: exactly one workgroup per CU (64x80), six stages for cold K <= 2048, four beyond
+    assert sel(1024, 1280, 1280, 1280) == 56 and sel(1024, 1280, 5120, 5120) == 45
+    assert sel(1024, 10240, 1280, 1280) == 25 and sel(4096, 640, 2560, 2560) == 44
+    # batch 8: the four-phase 256x256 loop for plain Linear launches from 1.5 workgroups per CU on ...
+    assert sel(8192, 10240, 1280, 1280) == 70 and sel(8192, 3840, 1280, 1280) == 70
+    assert sel(32768, 1920, 640, 640) == 70
+    # ... not for convolutions (k_align = C != k_total: the gather needs the general staging) ...
+    assert sel(32768, 640, 640, 5760) != 70 and sel(8192, 10240, 1280, 11520) != 70
+    # ... nor a K that is not whole 128-byte tiles, nor GEMM + GEGLU (one workgroup per CU: the GELU
+    # epilogue of a 256x256 tile runs uncovered)
+    assert sel(8192, 10240, 1296, 1296) != 70
+    assert lib.mixdq_igemm_select_id_geglu(8192, 10240, 1280, 0) == 13
+    assert lib.mixdq_igemm_select_id_geglu(1024, 10240, 1280, 0) == 25
+    assert lib.mixdq_igemm_select_id_geglu(1024, 10240 + 32, 1280, 0) == -1      # N % 64 != 0
+    # packed W4: 32x32x32 tiles (every wave unpacks what it multiplies)
+    assert lib.mixdq_igemm_select_id_w4(1024, 1280, 1280, 1280) == 41
+    assert lib.mixdq_igemm_select_id_w4(1024, 1280, 1281, 1281) == -1             # K % 32 != 0
+    assert sel(64, 8, 20, 20) == 0 and sel(64, 6, 16, 16) == -1                   # generic / invalid
