@@ -31,7 +31,8 @@
 #include "../../include/mixdq_math.h"
 
 // MIXDQ_ABLATE (diagnostic builds only, tools/ablate.sh): 1 = no MFMA, 2 = no LDS fragment reads,
-// 3 = no LDS-DMA in the main loop, 4 = no output stores.  Results are garbage; the timing shows what the loop waits for.
+// 3 = no LDS-DMA in the main loop, 4 = no output stores, 5 = no counted DMA waits in the phased loops.
+// Results are garbage; the timing shows what the loop waits for.
 #define NWAVES_OF(WM, WN, KSPLIT) ((WM) * (WN) * (KSPLIT))
 #ifndef MIXDQ_ABLATE
 #define MIXDQ_ABLATE 0
