@@ -256,7 +256,9 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
-template <bool UNFUSED>
+// NQ: quantizers in use (0..3), WANT_H: the FP16 copy is written -- compile-time, so a launch with one
+// consumer does not run the other two quantizers' arithmetic on its one-wave-per-SIMD critical path
+template <bool UNFUSED, int NQ, bool WANT_H>
 __global__ __launch_bounds__(256) void ln_quant_kernel(
     const __half* __restrict__ x, const __half* __restrict__ gamma, const __half* __restrict__ beta,
     float eps, int64_t M, int C, const float* __restrict__ s_inv0, const float* __restrict__ zp0,
@@ -281,9 +283,9 @@ __global__ __launch_bounds__(256) void ln_quant_kernel(
       btv[i] = *reinterpret_cast<const Half8*>(beta + 8 * c);
     }
   }
-  const float si0 = q0 ? *s_inv0 : 0.f, z0 = q0 ? *zp0 : 0.f;
-  const float si1 = q1 ? *s_inv1 : 0.f, z1 = q1 ? *zp1 : 0.f;
-  const float si2 = q2 ? *s_inv2 : 0.f, z2 = q2 ? *zp2 : 0.f;
+  const float si0 = NQ > 0 ? *s_inv0 : 0.f, z0 = NQ > 0 ? *zp0 : 0.f;
+  const float si1 = NQ > 1 ? *s_inv1 : 0.f, z1 = NQ > 1 ? *zp1 : 0.f;
+  const float si2 = NQ > 2 ? *s_inv2 : 0.f, z2 = NQ > 2 ? *zp2 : 0.f;
   float s = 0.f;
 #pragma unroll
   for (int i = 0; i < kLnMaxChunks; ++i) {
@@ -320,16 +322,16 @@ __global__ __launch_bounds__(256) void ln_quant_kernel(
       for (int j = 0; j < 8; ++j) {
         const float nrm = __fmul_rn(__fsub_rn(half_at(h[i], j), mean), rstd);
         const float y = round_f16(__builtin_fmaf(nrm, half_at(gm, j), half_at(bt, j)));
-        put_half(oh, j, y);
-        put_q(a, j, quantize_one<UNFUSED>(y, si0, z0));
-        put_q(b, j, quantize_one<UNFUSED>(y, si1, z1));
-        put_q(d, j, quantize_one<UNFUSED>(y, si2, z2));
+        if constexpr (WANT_H) put_half(oh, j, y);
+        if constexpr (NQ > 0) put_q(a, j, quantize_one<UNFUSED>(y, si0, z0));
+        if constexpr (NQ > 1) put_q(b, j, quantize_one<UNFUSED>(y, si1, z1));
+        if constexpr (NQ > 2) put_q(d, j, quantize_one<UNFUSED>(y, si2, z2));
       }
       const int64_t off = row * C + 8 * c;
-      if (q0) *reinterpret_cast<Char8*>(q0 + off) = a;
-      if (q1) *reinterpret_cast<Char8*>(q1 + off) = b;
-      if (q2) *reinterpret_cast<Char8*>(q2 + off) = d;
-      if (out_h) *reinterpret_cast<Half8*>(out_h + off) = oh;
+      if constexpr (NQ > 0) *reinterpret_cast<Char8*>(q0 + off) = a;
+      if constexpr (NQ > 1) *reinterpret_cast<Char8*>(q1 + off) = b;
+      if constexpr (NQ > 2) *reinterpret_cast<Char8*>(q2 + off) = d;
+      if constexpr (WANT_H) *reinterpret_cast<Half8*>(out_h + off) = oh;
     }
   }
 }
@@ -495,14 +497,25 @@ extern "C" int mixdq_layernorm_quantize(const void* x, const void* gamma, const 
     return MIXDQ_ERR_ALIGNMENT;
   const int grid = (int)((M + 3) / 4);
   hipStream_t stream = (hipStream_t)stream_;
-  if (flags & MIXDQ_FLAG_UNFUSED)
-    ln_quant_kernel<true><<<grid, 256, 0, stream>>>(
-        (const __half*)x, (const __half*)gamma, (const __half*)beta, eps, M, C, si[0], zp[0], q[0],
-        si[1], zp[1], q[1], si[2], zp[2], q[2], (__half*)out_f16_or_null);
-  else
-    ln_quant_kernel<false><<<grid, 256, 0, stream>>>(
-        (const __half*)x, (const __half*)gamma, (const __half*)beta, eps, M, C, si[0], zp[0], q[0],
-        si[1], zp[1], q[1], si[2], zp[2], q[2], (__half*)out_f16_or_null);
+  const bool unfused = flags & MIXDQ_FLAG_UNFUSED, want_h = out_f16_or_null != nullptr;
+#define LN_LAUNCH(U, NQ, H)                                                                          \
+  ln_quant_kernel<U, NQ, H><<<grid, 256, 0, stream>>>(                                               \
+      (const __half*)x, (const __half*)gamma, (const __half*)beta, eps, M, C, si[0], zp[0], q[0],    \
+      si[1], zp[1], q[1], si[2], zp[2], q[2], (__half*)out_f16_or_null)
+#define LN_BY_H(U, NQ) do { if (want_h) LN_LAUNCH(U, NQ, true); else LN_LAUNCH(U, NQ, false); } while (0)
+#define LN_BY_NQ(U)                                                                \
+  do {                                                                             \
+    switch (n_out) {                                                               \
+      case 0: LN_LAUNCH(U, 0, true); break;   /* n_out == 0 implies the FP16 copy */ \
+      case 1: LN_BY_H(U, 1); break;                                                \
+      case 2: LN_BY_H(U, 2); break;                                                \
+      default: LN_BY_H(U, 3); break;                                               \
+    }                                                                              \
+  } while (0)
+  if (unfused) LN_BY_NQ(true); else LN_BY_NQ(false);
+#undef LN_BY_NQ
+#undef LN_BY_H
+#undef LN_LAUNCH
   return launch_status();
 }
 
