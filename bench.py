@@ -4,7 +4,11 @@ Conv2d running  quantize (HIP) -> INT8 GEMM / implicit-GEMM conv + epilogue (HIP
 inputs resident in HBM, captured in a hipGraph (the reference measures with CUDA graphs too:
 kernels/README.md:94, quantize_sdxl.py:184-286).
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one process per GPU.  Under a launcher (torch.distributed.run: RANK / WORLD_SIZE set) this
+process is one rank; without one, bench.py starts the N ranks itself as child processes (before any
+GPU call in the parent) and relays rank 0's JSON line.  WORLD_SIZE != --gpus is an error.
 
 N = 1 workload: BASELINE.json configs[1] -- W8A8 SDXL-Turbo UNet, 1024x1024 (latent 128), batch 1,
 1 step, one MI355X.  N > 1 (default): weak scaling, the same per-GPU batch on every rank
@@ -37,7 +41,9 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 import torch.nn as nn  # noqa: E402
 
-INT8_MFMA_PEAK_TOPS = 5000.0   # dense, ~2x the 2.5 PF bf16 figure (MI355X_MICROARCH.md)
+# dense INT8 MFMA: 2x the BF16 rate per clock (MI355X_MICROARCH.md, Matrix cores table: "I8 ... 2x BF16
+# per clock") x its ~2.5 PF dense BF16 figure (Chip-level parameters)
+INT8_MFMA_PEAK_TOPS = 5000.0
 HBM_PEAK_GBS = 8000.0
 
 
@@ -77,6 +83,15 @@ def parse_args():
     ap.add_argument("--forwards-per-image", type=int, default=1,
                     help="UNet forwards one image needs (sampling steps); images/s = UNet-batch "
                          "throughput / this")
+    ap.add_argument("--vary-timestep", action="store_true",
+                    help="a sampling loop as the pipeline runs it: every step replays the ONE captured "
+                         "graph with a different timestep VALUE (quantize_sdxl.py:184-286 keys its "
+                         "graph cache on shapes / dtypes only)")
+    ap.add_argument("--host-only", action="store_true",
+                    help="harness check without a GPU: rendezvous, sharding, module swap on the CPU "
+                         "and the weight broadcast; no forward, no timing (value = null)")
+    ap.add_argument("--unet-rows-per-image", type=int, default=1,
+                    help="UNet batch rows one image occupies (2 with classifier-free guidance)")
     ap.add_argument("--profile-ranges", action="store_true",
                     help="after the timed region: 3 eager iterations with roctx ranges per block "
                          "(quantize_sdxl.py:387-429), for rocprofv3 --marker-trace")
@@ -86,7 +101,9 @@ def parse_args():
     elif args.baseline_config == 3:
         args.global_batch, args.forwards_per_image = 64, 4
     elif args.baseline_config == 4:
-        args.batch = 16
+        args.batch, args.unet_rows_per_image = 16, 2     # 8 images x classifier-free guidance
+        if args.forwards_per_image > 1:      # the named config: 20 sampling steps per image
+            args.vary_timestep = True
     return args
 
 
@@ -244,24 +261,107 @@ def cpu_fake_quant_baseline(seconds_budget):
         macs_done += float(M) * N * K
         if t_total > seconds_budget or time.perf_counter() - t_begin > 4 * seconds_budget:
             break
-    est_forward_s = t_total * (len(layers) / max(n_done, 1))
+    # scaled by multiply-accumulates, not by layer count (the sample is spread uniformly over the
+    # model, but layers differ by 1000x in work); a fast host times the whole inventory: factor 1
+    est_forward_s = t_total * (macs_all / max(macs_done, 1.0))
     return dict(value=1.0 / est_forward_s, unit="images/s", cores=torch.get_num_threads(),
                 kind="port", seconds_per_forward_est=est_forward_s,
                 sample=f"qdiff fake-quant (Path A) W8A8 512px bs1 FP32 on CPU: {n_done} of "
                        f"{len(layers)} layers (uniformly spread over the model, "
                        f"{100 * macs_done / macs_all:.1f}% of the MACs) in {t_total:.1f} s, "
-                       f"scaled by layer count; host os.cpu_count()={os.cpu_count()}")
+                       f"scaled by MACs; host os.cpu_count()={os.cpu_count()}")
+
+
+def spawn_ranks(n: int) -> int:
+    """`--gpus N` without a launcher: start the N ranks as fresh child processes (one per GPU,
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) BEFORE this process has made
+    any GPU call -- it never does -- relay rank 0's JSON line, and return non-zero if any rank
+    failed.  (Never re-exec a process that has touched the GPU.)"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                      env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"bench.py: ranks failed (rank, exit code): {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
+def host_only(args, rank, world):
+    """Harness check on the CPU (tests/test_bench_cpu.py): the N > 1 plumbing of this file --
+    rendezvous, batch sharding, module swap, the one-time weight broadcast -- with no forward and
+    no timing.  The JSON line says so: value = null."""
+    from mixdq_amd import shard
+    from mixdq_amd.calib import calibrate, precompute_bos
+    from mixdq_amd.quantize_sdxl import example_inputs, quantize_unet
+    from mixdq_amd.unet import SDXLUNet, init_synthetic_weights, quantizable_layers
+    assert args.tiny, "--host-only builds the network on the CPU: --tiny only"
+    strong = args.global_batch is not None
+    if strong:
+        lo, hi = shard.shard_range(args.global_batch, rank, world)
+        B, global_batch = hi - lo, args.global_batch
+    else:
+        B, global_batch = args.batch, world * args.batch
+    unet = init_synthetic_weights(SDXLUNet(TINY_CFG)).eval()
+    inputs = example_inputs(1, 8, "cpu", seed=42 + rank)
+    inputs = {k: (v.float() if torch.is_tensor(v) else {a: b.float() for a, b in v.items()})
+              for k, v in inputs.items()}
+    ckpt = calibrate(unet, [inputs])
+    bos_dict = precompute_bos(unet.half(), inputs["encoder_hidden_states"].half())
+    names = list(quantizable_layers(unet))
+    quantize_unet(unet, Cfg({n: 8 for n in names},
+                            {n: 8 for n in names if n not in ("conv_in", "conv_out")}),
+                  ckpt, bos=True, bos_dict=bos_dict)
+    bcast = shard.broadcast_module_state(unet, src=0)
+    shard.barrier()
+    if rank == 0:
+        fpi = max(1, args.forwards_per_image)
+        print(json.dumps({
+            "metric": "sdxl_turbo_unet_w8a8_images_per_sec", "value": None, "unit": "images/s",
+            "n_gpus": world, "steps": 0, "warmup": 0, "ms_per_step": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak",
+            "vs_baseline": None, "dtype": "int8", "data": "synthetic", "host_only": True,
+            "config": {"workload": "harness check (no forward)", "global_batch": global_batch,
+                       "per_gpu_batch": B, "unet_forwards_per_image": fpi,
+                       "parallelism": f"dp{world} (batch-sharded replicas, no step-loop collective)"},
+            "weight_broadcast_bytes": bcast}))
+
+
+TINY_CFG = dict(block_out_channels=(32, 64, 128), transformer_layers_per_block=(0, 1, 2),
+                mid_transformer_layers=1, head_dim=16, cross_attention_dim=2048,
+                time_embed_dim=128, addition_time_embed_dim=16,
+                projection_class_embeddings_input_dim=1280 + 96, norm_num_groups=8)
 
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))      # this process makes no GPU call
     from mixdq_amd import shard
-    assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU fallback)"
+    if not args.host_only:
+        assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU fallback)"
     # MIXDQ_DIST_BACKEND=gloo + MIXDQ_SHARE_DEVICE=1: several ranks on ONE GPU, to exercise the
     # N > 1 code path on a single-GPU box (harness test only).
     share = os.environ.get("MIXDQ_SHARE_DEVICE") == "1"
-    rank, local_rank, world = shard.init_distributed(os.environ.get("MIXDQ_DIST_BACKEND"))
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    rank, local_rank, world = shard.init_distributed(
+        os.environ.get("MIXDQ_DIST_BACKEND") or ("gloo" if args.host_only else None))
+    if world != args.gpus:      # never report an N-GPU request as a 1-GPU number
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.host_only:
+        return host_only(args, rank, world)
     device = torch.device("cuda", 0 if share else local_rank)
     torch.cuda.set_device(device)
 
@@ -283,21 +383,27 @@ def main():
         B, global_batch = args.batch, world * args.batch
     fpi = max(1, args.forwards_per_image)
     t_setup = time.perf_counter()
-    tiny_cfg = None
-    if args.tiny:
-        tiny_cfg = dict(block_out_channels=(32, 64, 128), transformer_layers_per_block=(0, 1, 2),
-                        mid_transformer_layers=1, head_dim=16, cross_attention_dim=2048,
-                        time_embed_dim=128, addition_time_embed_dim=16,
-                        projection_class_embeddings_input_dim=1280 + 96, norm_num_groups=8)
-    unet = build_unet(device, cfg=tiny_cfg)
+    unet = build_unet(device, cfg=TINY_CFG if args.tiny else None)
     fp16_meter = MemoryMeter(device)              # static = the FP16 network, resident
     inputs = example_inputs(B, L, device, seed=42 + rank)
     ckpt = calibrate(unet, [inputs], bos=not args.no_bos)
     bos_dict = precompute_bos(unet, inputs["encoder_hidden_states"])
 
+    # --vary-timestep: the pipeline's sampling loop -- each step hands the UNet another timestep
+    # VALUE (a 0-dim device tensor, as the scheduler does); the graph cache keys on shapes and
+    # dtypes, so all steps replay ONE captured graph after copying the value into its input
+    n_ts = max(2, fpi) if args.vary_timestep else 1
+    timesteps = [torch.tensor(999.0 - i * (998.0 / max(1, n_ts - 1)), device=device)
+                 for i in range(n_ts)]
+    step_no = [0]
+
     def run_once():
+        if args.vary_timestep:
+            inputs["timestep"] = timesteps[step_no[0] % n_ts]
+            step_no[0] += 1
         return unet(**inputs)[0]
 
+    rows_per_image = max(1, args.unet_rows_per_image)
     fp16, memory = None, {}
     if not args.no_fp16:
         # (a) the reference's comparison point: the same graph, stock PyTorch FP16 ops throughout
@@ -305,7 +411,7 @@ def main():
             hip_graph_opt(unet)
         dt = time_steps(run_once, args.steps, args.warmup, device)
         fp16 = dict(ms_per_step=1e3 * dt / args.steps,
-                    images_per_s=global_batch * args.steps / dt / fpi)
+                    images_per_s=global_batch * args.steps / dt / fpi / rows_per_image)
         memory["fp16"] = fp16_meter.report()
         if not args.no_graph:
             unet.forward = unet.forward.__wrapped__   # drop the FP16 graph
@@ -356,7 +462,8 @@ def main():
     setup_s = time.perf_counter() - t_setup
     dt = time_steps(run_once, args.steps, args.warmup, device)
     ms = 1e3 * dt / args.steps
-    value = global_batch * args.steps / dt / fpi
+    value = global_batch * args.steps / dt / fpi / rows_per_image
+    graphs_cached = None if args.no_graph else len(unet.forward._cached)
     memory["w4a8_mixed" if args.w4_kernel else "w8a8"] = q_meter.report()
 
     roof_stats = None
@@ -386,7 +493,8 @@ def main():
             "workload": f"sdxl_turbo_unet_{kind}_{args.px}px_bs{global_batch if strong else B}"
                         f"_{fpi}step" + ("_sharded" if strong else ""),
             "global_batch": global_batch, "per_gpu_batch": B, "px": args.px, "latent": L,
-            "unet_forwards_per_image": fpi,
+            "unet_forwards_per_image": fpi, "unet_rows_per_image": rows_per_image,
+            "vary_timestep": bool(args.vary_timestep), "graphs_cached": graphs_cached,
             "w_config": args.w_config, "a_config": args.a_config, "bos": not args.no_bos,
             "parallelism": f"dp{world} (batch-sharded replicas, no step-loop collective)",
             "hip_graph": not args.no_graph, "producer_fusions": not args.no_fuse,
@@ -415,15 +523,19 @@ def main():
         achieved = s["ops"] / (s["ms"] * 1e-3) / 1e12
         tot_ops = sum(v["ops"] for v in roof_stats.values())
         tot_ms = sum(v["ms"] for v in roof_stats.values())
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # from rocprofv3 --pmc passes
-        if os.path.exists(pmc) and args.px == 1024 and B == 1:       # (tools/pmc_probe.py)
+        # HBM-side bytes per launch and MFMA-busy fraction of THIS instantiation, from the rocprofv3
+        # --pmc passes of tools/pmc_probe.py (separate FETCH_SIZE / WRITE_SIZE / SQ runs; FETCH_SIZE
+        # x2 on gfx950) -- keyed by the kernel's own name, null when it was not collected
+        traffic = mfma_util = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc) and args.px == 1024 and B == 1:
             with open(pmc) as f:
-                key = dom.split("#")[0].replace(",linear_geglu>", ",linear>")
-                traffic = json.load(f).get(key, {}).get("hbm_bytes_per_launch")
+                entry = json.load(f).get(dom.split("#")[0], {})
+            traffic, mfma_util = entry.get("hbm_bytes_per_launch"), entry.get("mfma_util")
         out["roofline"] = {
             "bound": "mfma", "kernel": dom, "achieved": achieved, "peak": INT8_MFMA_PEAK_TOPS,
             "unit": "TFLOP/s", "frac": achieved / INT8_MFMA_PEAK_TOPS, "traffic": traffic,
+            "mfma_util": mfma_util,
             "launches_per_step": s["launches"] // args.sweep_reps,
             "avg_launch_us": 1e3 * s["ms"] / s["launches"],
             "ops_per_launch": s["ops"] / s["launches"],
