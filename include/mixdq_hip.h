@@ -29,7 +29,10 @@
 extern "C" {
 #endif
 
-#define MIXDQ_ABI_VERSION 1
+/* 1: round 1.  2: status codes 5..9 returned where 1 returned MIXDQ_ERR_UNSUPPORTED; structs and
+ * entry points added since (grouped / GEGLU / attention launches, FP16 layers, producer fusions).
+ * Bumped whenever an existing entry point changes its signature or its error behaviour. */
+#define MIXDQ_ABI_VERSION 2
 
 typedef void* mixdq_stream_t; /* hipStream_t */
 

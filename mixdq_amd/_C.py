@@ -282,7 +282,15 @@ class GemmGroupTable:
             bias = None if bias is None else bias.contiguous()
             _check(b0.numel() == N and sc.numel() == N and (bias is None or bias.numel() == N),
                    "member epilogue vectors should have N elements")
-            _check(out.dtype == torch.float16 and out.data_ptr() % 16 == 0, "member output: fp16")
+            # the kernel cannot validate a device-side table: row stride == the member's N, whole
+            # 8-byte output quads, 16-byte aligned operands
+            _check(out.dtype == torch.float16 and out.data_ptr() % 16 == 0 and out.is_contiguous()
+                   and out.dim() >= 1 and out.shape[-1] == N and N > 0 and out.numel() % N == 0,
+                   "member output: contiguous fp16 [..., N], 16-byte aligned")
+            _check(N % 4 == 0, "Int8 kernel with input or output alignment not to 4 is not supported.")
+            _check(w.data_ptr() % 16 == 0 and (bias is None or bias.data_ptr() % 8 == 0)
+                   and (bias is None or bias.dtype == torch.float16),
+                   "member weight / bias: 16- / 8-byte aligned, bias fp16")
             keep.append((w, b0, sc, bias, out))
             rows.append([w.data_ptr(), b0.data_ptr(), sc.data_ptr(),
                          0 if bias is None else bias.data_ptr(), out.data_ptr(), N])

@@ -1279,7 +1279,7 @@ inline const std::vector<TuneEntry>& tune_overrides() {
     while (e && *e) {
       long long m; int n, k, c, used = 0;
       if (sscanf(e, "%lldx%dx%d=%d%n", &m, &n, &k, &c, &used) == 4) t.push_back({m, n, k, c});
-      else break;
+      else { fprintf(stderr, "mixdq: MIXDQ_IGEMM_TUNE: cannot parse \"%s\" (MxNxK=cfg,...); ignored from there\n", e); break; }
       e += used;
       if (*e == ',') ++e;
     }
@@ -1288,11 +1288,24 @@ inline const std::vector<TuneEntry>& tune_overrides() {
   return table;
 }
 
+// An override applies to the INT8 launches of that shape only (the FP16 layers count K in bytes and
+// have their own list), and only if the launch's constraints admit the tile: GEMM+GEGLU needs
+// BN % 64 == 0 -- an entry meant for a plain Linear of the same shape is ignored there.
+inline int tuned_cfg(int64_t M, int N, int Ktot, bool whole64) {
+  for (const TuneEntry& t : tune_overrides()) {
+    if (t.M != M || t.N != N || t.K != Ktot) continue;
+    for (const TileCfg& c : kTileCfgs)
+      if (c.id == t.cfg && (!whole64 || c.bn % 64 == 0)) return t.cfg;
+  }
+  return 0;
+}
+
 // whole64: the launch needs BN % 64 == 0 (GEMM+GEGLU: whole value/gate groups per tile)
 // phased_ok: a Linear launch on the fast staging path (K % 128 == 0, 32-bit operand offsets)
-inline int select_cfg(int64_t M, int N, int Ktot, bool whole64 = false, bool phased_ok = false) {
-  for (const TuneEntry& t : tune_overrides())
-    if (t.M == M && t.N == N && t.K == Ktot) return t.cfg;
+// tune: consult MIXDQ_IGEMM_TUNE (off for the FP16 layers' rule, which reuses this one on bytes)
+inline int select_cfg(int64_t M, int N, int Ktot, bool whole64 = false, bool phased_ok = false,
+                      bool tune = true) {
+  if (tune) if (const int c = tuned_cfg(M, N, Ktot, whole64)) return c;
   auto blocks = [&](int tm, int tn) {
     return ((M + tm - 1) / tm) * (int64_t)((N + tn - 1) / tn);
   };
@@ -1337,8 +1350,7 @@ inline int select_cfg(int64_t M, int N, int Ktot, bool whole64 = false, bool pha
 // rather than the 16-row exact-fit ones (tools/bench_gemm.py --w4: (1024, 1280, 5120) 17.1 us on
 // the k-split 64x64 tile vs 18.3 on 64x80; (1024, 10240, 1280) 26.7 on 128x128 vs 29.9 on 128x320).
 inline int select_cfg_w4(int64_t M, int N, int Ktot, bool whole64 = false) {
-  for (const TuneEntry& t : tune_overrides())
-    if (t.M == M && t.N == N && t.K == Ktot) return t.cfg;
+  if (const int c = tuned_cfg(M, N, Ktot, whole64)) return c;
   auto blocks = [&](int tm, int tn) {
     return ((M + tm - 1) / tm) * (int64_t)((N + tn - 1) / tn);
   };
@@ -1437,7 +1449,7 @@ int dispatch_grouped(IgemmParams& p, int ngroups, hipStream_t stream, int cfg) {
   X(56, 64, 80, 128, 6, 4, 1, 2, 16)
 
 inline int select_cfg_f16(int64_t M, int N, int k_bytes) {
-  const int c = select_cfg(M, N, k_bytes);
+  const int c = select_cfg(M, N, k_bytes, false, false, /*tune=*/false);
   switch (c) {
 #define X(ID, BM, BN, BK, ST, WM, WN, KS, MT) case ID:
     MIXDQ_F16_CONFIGS(X)

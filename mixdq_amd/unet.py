@@ -92,12 +92,20 @@ _PACK_VECS = (("wscale", "weight_scales"), ("wsum", "weight_sum_by_input_channel
 
 
 def _uniform_storage(layers) -> bool:
-    """Layers that are to share one GEMM must store their weights alike.  In a mixed-precision
-    config to_q / to_k / to_v may be a mix of int8 and packed 4-bit layers: the packed ones are then
-    widened to int8 storage (the VALUES stay the 4-bit integers, so every output is unchanged) --
-    one launch instead of three is worth more than those layers' halved bytes."""
-    kinds = {bool(m.w_packed4) for m in layers}
-    if len(kinds) == 1:
+    """Layers that are to share one GEMM must store their weights alike (all int8 or all packed
+    4-bit).  A pure check: the forward never changes a module's buffers -- mixed groups are
+    unified once, by `unify_packed_storage_` from `SDXLUNet.set_fused`, or run unpacked."""
+    return len({bool(m.w_packed4) for m in layers}) == 1
+
+
+def unify_packed_storage_(layers) -> bool:
+    """Explicit post-conversion step (SDXLUNet.set_fused -> prepare_fused_): in a mixed-precision
+    config to_q / to_k / to_v (or to_k / to_v) may be a mix of int8 and packed 4-bit layers; the
+    packed ones are widened to int8 STORAGE (the values stay the 4-bit integers, so every output
+    is unchanged) -- one launch instead of three is worth more than those layers' halved bytes.
+    Replaces the `weight_int4` buffer by `weight_int`: state-dict keys change HERE, once, on every
+    rank alike, never inside a forward.  Returns whether the group is uniform afterwards."""
+    if _uniform_storage(layers):
         return True
     if any(getattr(m, "weight_int4", None) is None and m.w_packed4 for m in layers):
         return False
@@ -803,34 +811,39 @@ class SDXLUNet(nn.Module):
             if bos_w8a8(lk) and bos_w8a8(lv) and gid[id(lk)] == gid[id(lv)]:
                 pack = self._kv_pack(blk, context)
             if pack is not None:        # to_k | to_v as ONE GEMM against [2C, K] (cf. _qkv_fused)
-                # persistent [B, T, 2C] buffer, BOS row written once (it is a constant)
-                key = (B, T, context.device, lk.bos_pre_computed.data_ptr(),
-                       lk.bos_pre_computed._version, lv.bos_pre_computed.data_ptr(),
-                       lv.bos_pre_computed._version)
-                if pack.get("key") != key:
-                    o = torch.empty((B, T, 2 * pack["C"]), dtype=torch.float16,
-                                    device=context.device)
-                    o[:, :1, :] = torch.cat([lk.bos_pre_computed, lv.bos_pre_computed], dim=-1)
-                    pack["key"], pack["out"] = key, o
-                o = pack["out"]
+                # persistent [B, T, 2C] buffer PER SHAPE (a captured graph keeps raw pointers into
+                # it: a buffer is never dropped while its pack lives), BOS row written once -- it is
+                # a constant -- and rewritten in place if the BOS tensors changed
+                bos_key = (lk.bos_pre_computed.data_ptr(), lk.bos_pre_computed._version,
+                           lv.bos_pre_computed.data_ptr(), lv.bos_pre_computed._version)
+                slot = pack.setdefault("outs", {}).get((B, T, context.device))
+                if slot is None:
+                    slot = pack["outs"][(B, T, context.device)] = [None, torch.empty(
+                        (B, T, 2 * pack["C"]), dtype=torch.float16, device=context.device)]
+                if slot[0] != bos_key:
+                    slot[1][:, :1, :] = torch.cat([lk.bos_pre_computed, lv.bos_pre_computed], dim=-1)
+                    slot[0] = bos_key
+                o = slot[1]
                 blk._kv = (o[..., :pack["C"]], o[..., pack["C"]:], None)
-                grouped.setdefault((gid[id(lk)], lk.in_features, pack["w4"]), []).append((lk, pack))
+                grouped.setdefault((gid[id(lk)], lk.in_features, pack["w4"]), []).append(
+                    (lk, pack, o))
                 continue
             outs = []
             for layer in (lk, lv):
                 if not bos_w8a8(layer):
                     outs.append(layer(context))
                     continue
-                # persistent K / V buffer per layer, BOS row written once
-                key = (B, T, context.device, layer.bos_pre_computed.data_ptr(),
-                       layer.bos_pre_computed._version)
-                buf = layer.__dict__.get("_kv_buf")
-                if buf is None or buf[0] != key:
-                    o = torch.empty((B, T, layer.out_features), dtype=torch.float16,
-                                    device=context.device)
-                    o[:, :1, :] = layer.bos_pre_computed
-                    buf = layer.__dict__["_kv_buf"] = (key, o)
-                outs.append(layer.forward_bos_quantized(ctx_int8(layer), B, T, out=buf[1]))
+                # persistent K / V buffer per layer and shape (never dropped: see above)
+                bos_key = (layer.bos_pre_computed.data_ptr(), layer.bos_pre_computed._version)
+                bufs = layer.__dict__.setdefault("_kv_buf", {})
+                slot = bufs.get((B, T, context.device))
+                if slot is None:
+                    slot = bufs[(B, T, context.device)] = [None, torch.empty(
+                        (B, T, layer.out_features), dtype=torch.float16, device=context.device)]
+                if slot[0] != bos_key:
+                    slot[1][:, :1, :] = layer.bos_pre_computed
+                    slot[0] = bos_key
+                outs.append(layer.forward_bos_quantized(ctx_int8(layer), B, T, out=slot[1]))
             blk._kv = (outs[0], outs[1], None)
         from mixdq_amd import _C
         from mixdq_amd.op.qlinear import qlinear
@@ -838,13 +851,13 @@ class SDXLUNet(nn.Module):
             lk0 = members[0][0]
             x_int = ctx_int8(lk0)
             if len(members) == 1:
-                pack = members[0][1]
+                pack, o = members[0][1], members[0][2]
                 qlinear(x_int, pack["w"], pack["wscale"], lk0.act_scales, lk0.act_zero_points,
-                        pack["wsum"], pack["scale"], pack["bias0"], None, _out=pack["out"],
+                        pack["wsum"], pack["scale"], pack["bias0"], None, _out=o,
                         _row_map=(T - 1, T, 1), _w4=w4)
                 continue
             table = self._grouped("kv", (g, K, w4, B, T), [
-                (pk["w"], pk["bias0"], pk["scale"], None, pk["out"]) for _, pk in members], w4)
+                (pk["w"], pk["bias0"], pk["scale"], None, o) for _, pk, o in members], w4)
             _C.qlinear_grouped(x_int, table, _row_map=(T - 1, T, 1))
 
     @staticmethod
@@ -863,7 +876,7 @@ class SDXLUNet(nn.Module):
         if len(set(_quantizer_groups(_memo(blk), "kv", layers))) != 1:
             return None
         if not _uniform_storage(layers):
-            return None
+            return None                         # mixed int8 / packed storage: see prepare_fused_
         pack = blk.__dict__.get("_kvpack")
         if not _pack_valid(pack, layers):
             pack = blk.__dict__["_kvpack"] = _pack_rows(layers)
@@ -889,25 +902,28 @@ class SDXLUNet(nn.Module):
             if not (_accel(layer) and ok):
                 res._t = (layer(s), None)
                 continue
-            buf = layer.__dict__.get("_t_out")
-            if buf is None or buf.shape[0] != B or buf.device != s.device:
-                buf = layer.__dict__["_t_out"] = torch.empty((B, layer.out_features),
-                                                             dtype=torch.float16, device=s.device)
+            # persistent output per batch size: a graph captured at another batch keeps raw
+            # pointers to ITS buffer, so none is ever dropped or reused for a different shape
+            bufs = layer.__dict__.setdefault("_t_out", {})
+            buf = bufs.get((B, s.device))
+            if buf is None:
+                buf = bufs[(B, s.device)] = torch.empty((B, layer.out_features),
+                                                        dtype=torch.float16, device=s.device)
             res._t = (buf, None)
             grouped.setdefault((gid[id(layer)], layer.in_features, bool(layer.w_packed4)),
-                               []).append(layer)
+                               []).append((layer, buf))
         from mixdq_amd import _C
-        for (g, K, w4), layers in grouped.items():
+        for (g, K, w4), members in grouped.items():
             from mixdq_amd.nn.Linear import quant_op
             if g not in shared:
-                shared[g] = quant_op(s, *_qp(layers[0]))
+                shared[g] = quant_op(s, *_qp(members[0][0]))
             x_int = shared[g]
-            if len(layers) == 1:
-                layers[0]._gemm(x_int, out=layers[0]._t_out)
+            if len(members) == 1:
+                members[0][0]._gemm(x_int, out=members[0][1])
                 continue
             table = self._grouped("temb", (g, K, w4, B), [
-                (m.weight_int4 if w4 else m.weight_int, m.bias0, m.scale, m.bias, m._t_out)
-                for m in layers], w4)
+                (m.weight_int4 if w4 else m.weight_int, m.bias0, m.scale, m.bias, buf)
+                for m, buf in members], w4)
             _C.qlinear_grouped(x_int, table)
 
     def refresh_derived_(self):
@@ -920,16 +936,46 @@ class SDXLUNet(nn.Module):
             for m in self.modules():
                 if m is not self and hasattr(m, "refresh_derived_"):
                     m.refresh_derived_()
-                buf = m.__dict__.get("_kv_buf")
-                if buf is not None and torch.is_tensor(getattr(m, "bos_pre_computed", None)):
-                    buf[1][:, :1, :] = m.bos_pre_computed
+                bufs = m.__dict__.get("_kv_buf")
+                if bufs and torch.is_tensor(getattr(m, "bos_pre_computed", None)):
+                    for slot in bufs.values():
+                        slot[1][:, :1, :] = m.bos_pre_computed.to(slot[1].device)
+                        slot[0] = None          # re-keyed on the next forward
                 pack = m.__dict__.get("_kvpack")
-                if pack is not None and pack.get("out") is not None:
+                if pack is not None and pack.get("outs"):
                     lk, lv = (r() for r in pack["layers"])
                     if lk is None or lv is None:
                         continue
-                    pack["out"][:, :1, :] = torch.cat([lk.bos_pre_computed, lv.bos_pre_computed],
-                                                      dim=-1)
+                    for slot in pack["outs"].values():
+                        slot[1][:, :1, :] = torch.cat(
+                            [lk.bos_pre_computed, lv.bos_pre_computed], dim=-1).to(slot[1].device)
+                        slot[0] = None
+        return self
+
+    def prepare_fused_(self):
+        """Explicit post-conversion step of the fused graph (called by `set_fused(True)`): whatever
+        changes a module's BUFFERS happens here, once, never inside a forward -- mixed int8 / packed
+        4-bit q|k|v and k|v groups are widened to one storage kind (`unify_packed_storage_`) and
+        their row-concatenated GEMM operands are built (`_pack_rows`: the layers' buffers become
+        views of the pack).  After it, state-dict keys and shapes are final: a checkpoint saved now
+        loads strictly later, and every rank holds the same set of buffers before
+        `shard.broadcast_module_state`."""
+        for blk in self.modules():
+            if not isinstance(blk, BasicTransformerBlock):
+                continue
+            a = blk.attn1
+            qkv = [a.to_q, a.to_k, a.to_v]
+            if (all(_accel(m) and m.bias is None for m in qkv)
+                    and len(set(_quantizer_groups(_memo(blk), "qkv", qkv))) == 1
+                    and unify_packed_storage_(qkv)):
+                blk._qkv_fused()
+            kv = [blk.attn2.to_k, blk.attn2.to_v]
+            if (all(getattr(m, "valid_for_acceleration", False) and getattr(m, "bos", False)
+                    and m.bias is None for m in kv)
+                    and kv[0].out_features == kv[1].out_features
+                    and len(set(_quantizer_groups(_memo(blk), "kv", kv))) == 1
+                    and unify_packed_storage_(kv)):
+                self._kv_pack(blk)
         return self
 
     def set_fused(self, enabled: bool = True):
@@ -939,6 +985,8 @@ class SDXLUNet(nn.Module):
                 m.fused = bool(enabled)
             if isinstance(m, FeedForward):
                 m.set_interleaved(bool(enabled))
+        if enabled:
+            self.prepare_fused_()
         return self
 
     def forward(self, sample, timestep, encoder_hidden_states, added_cond_kwargs=None,

@@ -36,7 +36,7 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared_symbols():
         assert hasattr(lib, name), f"{name} declared in include/ but not exported"
     lib.mixdq_abi_version.restype = ctypes.c_int
-    assert lib.mixdq_abi_version() == 1
+    assert lib.mixdq_abi_version() == 2
     lib.mixdq_status_string.restype = ctypes.c_char_p
     assert lib.mixdq_status_string(0) == b"ok"
     assert b"alignment not to 4" in lib.mixdq_status_string(2)

@@ -487,6 +487,41 @@ def test_packed_qkv_is_storage_not_a_copy_and_is_retaken_after_a_module_swap():
     assert blk._qkv_fused() is not None
 
 
+def test_mixed_w4_w8_groups_are_unified_by_set_fused_never_by_a_forward():
+    """widening a packed 4-bit layer to int8 storage changes state-dict keys; it is an
+    explicit step of set_fused (prepare_fused_), not a side effect of the first fused forward."""
+    import mixdq_amd.unet as U
+    from mixdq_amd.calib import calibrate, precompute_bos
+    from mixdq_amd.quantize_sdxl import quantize_unet
+    from mixdq_amd.unet import quantizable_layers
+    unet = tiny_unet()
+    inp = tiny_inputs()
+    ckpt = calibrate(unet, [inp])
+    bos = precompute_bos(unet.half(), inp["encoder_hidden_states"].half())
+    names = list(quantizable_layers(unet))
+    mixed = lambda n: 4 if (n.endswith("attn1.to_k") or n.endswith("attn2.to_v")) else 8   # noqa: E731
+    quantize_unet(unet, Args({"model." + n: mixed(n) for n in names},
+                             {"model." + n: 8 for n in names}), ckpt, bos=True, bos_dict=bos,
+                  w4_kernel=True)
+    blk = next(m for m in unet.modules() if isinstance(m, U.BasicTransformerBlock))
+    assert blk.attn1.to_k.w_packed4 and not blk.attn1.to_q.w_packed4
+    keys0 = sorted(unet.state_dict())
+    assert any(k.endswith("attn1.to_k.weight_int4") for k in keys0)
+    # the forward-side queries are pure: a mixed group is simply not packed
+    assert blk._qkv_fused() is None and U.SDXLUNet._kv_pack(blk) is None
+    assert sorted(unet.state_dict()) == keys0
+    values = blk.attn1.to_k._weight_values().clone()
+    unet.set_fused(True)                        # the explicit step
+    keys1 = sorted(unet.state_dict())
+    assert keys1 != keys0 and not any(k.endswith("to_k.weight_int4") or k.endswith("to_v.weight_int4")
+                                      for k in keys1 if "attn1.to_k" in k or "attn2.to_v" in k)
+    assert not blk.attn1.to_k.w_packed4 and torch.equal(blk.attn1.to_k.weight_int, values)
+    assert blk._qkv_fused() is not None and U.SDXLUNet._kv_pack(blk) is not None
+    assert sorted(unet.state_dict()) == keys1   # ... and stable from here on
+    unet.set_fused(True)
+    assert sorted(unet.state_dict()) == keys1
+
+
 def test_fused_flags_on_plain_float_network_do_not_stick():
     import mixdq_amd.unet as U
     unet = tiny_unet()
