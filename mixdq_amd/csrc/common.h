@@ -59,4 +59,112 @@ __device__ __forceinline__ __half epilogue_one(int acc, float bias0, float scale
   return f32_to_f16_rn(r);
 }
 
+// ---- GELU on two values at a time (packed-FP32 VALU: v_pk_mul / v_pk_fma / v_pk_add_f32) ----------
+// Each half performs EXACTLY the IEEE operations of the scalar specification include/mixdq_math.h
+// (mixdq_geluf -> mixdq_erff -> mixdq_expf), in the same order; the two erf branches are both
+// evaluated and selected per element (a wave of gate values takes both anyway), so the result is
+// the specification's bit for bit -- at about half the vector instructions per element.  It is the
+// epilogue arithmetic of the largest launch of the step (ff.net.0.proj + GEGLU: ~5 of its ~25 us).
+typedef int v2i __attribute__((ext_vector_type(2)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, float c) { return __builtin_elementwise_fma(a, b, v2f{c, c}); }
+__device__ __forceinline__ v2f pk_fma(float a, v2f b, float c) { return __builtin_elementwise_fma(v2f{a, a}, b, v2f{c, c}); }
+
+// mixdq_expf for arguments <= 0 (or -inf): erf's large branch never passes anything else, so the
+// NaN / overflow / e > 127 cases of the specification cannot occur and are not evaluated
+__device__ __forceinline__ v2f expf2_nonpos(v2f x) {
+  const v2f n = __builtin_elementwise_rint(x * 1.44269504088896341f);
+  v2f r = pk_fma(n, v2f{-0.693359375f, -0.693359375f}, x);
+  r = pk_fma(n, v2f{2.12194440e-4f, 2.12194440e-4f}, r);
+  v2f p = v2f{1.9875691500e-4f, 1.9875691500e-4f};
+  p = pk_fma(p, r, 1.3981999507e-3f);
+  p = pk_fma(p, r, 8.3334519073e-3f);
+  p = pk_fma(p, r, 4.1665795894e-2f);
+  p = pk_fma(p, r, 1.6666665459e-1f);
+  p = pk_fma(p, r, 5.0000001201e-1f);
+  p = pk_fma(p * r, r, r) + 1.0f;
+  const v2i e = __builtin_convertvector(n, v2i);                 // -126 .. 0 where the result is used
+  const v2u sb = __builtin_bit_cast(v2u, e + 127) << 23;
+  v2f y = p * __builtin_bit_cast(v2f, sb);
+  y[0] = x[0] < -87.33654f ? 0.0f : y[0];
+  y[1] = x[1] < -87.33654f ? 0.0f : y[1];
+  return y;
+}
+
+__device__ __forceinline__ v2f erff2(v2f a) {
+  const v2u ua = __builtin_bit_cast(v2u, a);
+  const v2f t = __builtin_bit_cast(v2f, ua & 0x7fffffffu);
+  const v2f s = a * a;
+  v2f r = pk_fma(-1.72853470e-5f, t, 3.83197126e-4f);
+  const v2f u = pk_fma(-3.88396438e-3f, t, 2.42546219e-2f);
+  r = pk_fma(r, s, u);
+  r = pk_fma(r, t, -1.06777877e-1f);
+  r = pk_fma(r, t, -6.34846687e-1f);
+  r = pk_fma(r, t, -1.28717512e-1f);
+  r = pk_fma(r, t, -t);
+  r = 1.0f - expf2_nonpos(r);
+  const v2u ur = __builtin_bit_cast(v2u, r);
+  const v2f big = __builtin_bit_cast(v2f, (ur & 0x7fffffffu) | (ua & 0x80000000u));
+  v2f q = v2f{-5.96761703e-4f, -5.96761703e-4f};
+  q = pk_fma(q, s, 4.99119423e-3f);
+  q = pk_fma(q, s, -2.67681349e-2f);
+  q = pk_fma(q, s, 1.12819925e-1f);
+  q = pk_fma(q, s, -3.76125336e-1f);
+  q = pk_fma(q, s, 1.28379166e-1f);
+  q = pk_fma(q, a, a);
+  v2f out;
+  out[0] = t[0] >= 0.921875f ? big[0] : q[0];      // NaN compares false: the small branch propagates it
+  out[1] = t[1] >= 0.921875f ? big[1] : q[1];
+  return out;
+}
+
+__device__ __forceinline__ v2f geluf2(v2f x) {
+  return (0.5f * x) * (1.0f + erff2(x * 0.70710678118654752440f));
+}
+
+// ---- weight prefetch beside a latency-bound producer kernel -------------------------------------
+// At batch 1 every INT8 GEMM / conv of the step starts with its weights cold in HBM, and its main
+// loop is bound by outstanding requests x latency.  The small kernel that runs just before it (the
+// LayerNorm / GroupNorm / attention launch that produces its INT8 operand) is a latency chain with
+// idle memory pipes: it touches that consumer's weight bytes, so they sit in the 256 MiB Infinity
+// Cache when the consumer starts.  Block `b` of `nb` reads slice b of [ptr, ptr + bytes) with 16-byte
+// loads whose results are only kept alive (never used): pf_issue() at the start of the kernel,
+// pf_retire() at its end.
+constexpr int kPfMax = 16;                   // loads in flight per thread (64 VGPRs)
+struct PfState { uint4 v[kPfMax]; };
+
+__device__ __forceinline__ void pf_issue(PfState& st, const void* ptr, size_t bytes, int b, int nb,
+                                         int tid, int nthreads) {
+#pragma unroll
+  for (int i = 0; i < kPfMax; ++i) st.v[i] = make_uint4(0, 0, 0, 0);
+  if (ptr == nullptr) return;
+  const size_t chunks = bytes >> 4;                                   // 16-byte units
+  const size_t per = (chunks + nb - 1) / nb;
+  const size_t lo = (size_t)b * per;
+  const size_t hi = lo + per < chunks ? lo + per : chunks;
+  const uint4* src = reinterpret_cast<const uint4*>(ptr);
+  size_t c = lo + tid;
+  // slices beyond kPfMax rounds (above 64 KB per 256-thread block): whole batches are read and
+  // retired up front, the last batch stays in flight beside the kernel's own work
+  while (c + (size_t)kPfMax * nthreads < hi) {
+    uint4 t[kPfMax];
+#pragma unroll
+    for (int i = 0; i < kPfMax; ++i) t[i] = src[c + (size_t)i * nthreads];
+#pragma unroll
+    for (int i = 0; i < kPfMax; ++i) asm volatile("" ::"v"(t[i].x), "v"(t[i].y), "v"(t[i].z), "v"(t[i].w));
+    c += (size_t)kPfMax * nthreads;
+  }
+#pragma unroll
+  for (int i = 0; i < kPfMax; ++i, c += nthreads)
+    if (c < hi) st.v[i] = src[c];
+}
+
+__device__ __forceinline__ void pf_retire(const PfState& st) {
+#pragma unroll
+  for (int i = 0; i < kPfMax; ++i)
+    asm volatile("" ::"v"(st.v[i].x), "v"(st.v[i].y), "v"(st.v[i].z), "v"(st.v[i].w));
+}
+
 }  // namespace mixdq

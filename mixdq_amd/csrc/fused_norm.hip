@@ -173,7 +173,7 @@ __global__ void gn_apply_kernel(const __half* __restrict__ x, const __half* __re
   const Half8 bt = *reinterpret_cast<const Half8*>(beta + 8 * o);
   float2 st0, st1;
   if (stats == nullptr) {
-    // at most 64 partials per group (batch >= 8): every block reduces its image's partials itself
+    // at most 64 partials per group (small images): every block reduces its image's partials itself
     // (one per lane, then the fixed butterfly) -- cheaper than the kernel boundary of a separate
     // finalize launch; with more partials per group the finalize kernel ran first (stats != null)
     const int nfull = (int)blockDim.x >> 6, wave = t >> 6;   // complete waves only
@@ -232,9 +232,11 @@ inline bool make_gn_geom(int N, int64_t HW, int C, int G, GnGeom& g) {
     if ((8 * o + 7) / g.cg - (8 * o) / g.cg > 1) return false;
   g.PP = g.OC >= 256 ? 1 : 256 / g.OC;
   if (G > g.OC * g.PP) return false;              // the block reduces with G threads
-  // Blocks per image: about 512 blocks in total, a whole number of block-iterations each.
-  // (Fixed rule: the oracle restates it, because it fixes the summation order.)
-  const int64_t target = (512 + N - 1) / N;
+  // Blocks per IMAGE: about 512, a whole number of block-iterations each -- a function of the image
+  // alone, never of the batch: the summation order, hence every bit of the result, is the same
+  // whether an image runs alone or as one row of a batch (what makes batch sharding over GPUs
+  // exact).  (Fixed rule: the oracle restates it, because it fixes the summation order.)
+  const int64_t target = 512;
   int64_t ppb = (HW + target - 1) / target;
   ppb = ((ppb + g.PP - 1) / g.PP) * g.PP;
   g.ppb = (int)ppb;
@@ -264,10 +266,13 @@ __global__ __launch_bounds__(256) void ln_quant_kernel(
     float eps, int64_t M, int C, const float* __restrict__ s_inv0, const float* __restrict__ zp0,
     int8_t* __restrict__ q0, const float* __restrict__ s_inv1, const float* __restrict__ zp1,
     int8_t* __restrict__ q1, const float* __restrict__ s_inv2, const float* __restrict__ zp2,
-    int8_t* __restrict__ q2, __half* __restrict__ out_h) {
+    int8_t* __restrict__ q2, __half* __restrict__ out_h, const void* __restrict__ pf_ptr,
+    size_t pf_bytes) {
+  PfState pf;
+  pf_issue(pf, pf_ptr, pf_bytes, blockIdx.x, gridDim.x, threadIdx.x, 256);
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
+  if (row >= M) { pf_retire(pf); return; }
   const int nch = C / 8;
   const __half* xr = x + row * C;
   Half8 h[kLnMaxChunks], gmv[kLnMaxChunks], btv[kLnMaxChunks];
@@ -334,6 +339,7 @@ __global__ __launch_bounds__(256) void ln_quant_kernel(
       if constexpr (WANT_H) *reinterpret_cast<Half8*>(out_h + off) = oh;
     }
   }
+  pf_retire(pf);
 }
 
 // ------------------------------------------------------------------------------- GEGLU
@@ -357,11 +363,15 @@ __global__ __launch_bounds__(256) void geglu_quant_kernel(
     oq.w[0] = oq.w[1] = 0;
     oh.w[0] = oh.w[1] = oh.w[2] = oh.w[3] = 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float ge = round_f16(mixdq_geluf(half_at(gv, j)));
-      const float y = round_f16(__fmul_rn(half_at(xv, j), ge));
-      put_half(oh, j, y);
-      put_q(oq, j, quantize_one<UNFUSED>(y, s_inv, zp));
+    for (int j = 0; j < 8; j += 2) {       // two gate values at a time (packed FP32: geluf2)
+      const v2f g2 = geluf2(v2f{half_at(gv, j), half_at(gv, j + 1)});
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const float ge = round_f16(g2[e]);
+        const float y = round_f16(__fmul_rn(half_at(xv, j + e), ge));
+        put_half(oh, j + e, y);
+        put_q(oq, j + e, quantize_one<UNFUSED>(y, s_inv, zp));
+      }
     }
     if (want_q) *reinterpret_cast<Char8*>(out_q + m * D + 8 * c) = oq;
     if (out_h) *reinterpret_cast<Half8*>(out_h + m * D + 8 * c) = oh;
@@ -480,6 +490,19 @@ extern "C" int mixdq_layernorm_quantize(const void* x, const void* gamma, const 
                                         const float* const* scale_inv,
                                         const float* const* zero_point, int8_t* const* out_q,
                                         void* out_f16_or_null, int flags, mixdq_stream_t stream_) {
+  return mixdq_layernorm_quantize_pf(x, gamma, beta, eps, M, C, n_out, scale_inv, zero_point, out_q,
+                                     out_f16_or_null, nullptr, 0, flags, stream_);
+}
+
+extern "C" int mixdq_layernorm_quantize_pf(const void* x, const void* gamma, const void* beta,
+                                           float eps, int64_t M, int C, int n_out,
+                                           const float* const* scale_inv,
+                                           const float* const* zero_point, int8_t* const* out_q,
+                                           void* out_f16_or_null, const void* prefetch,
+                                           size_t prefetch_bytes, int flags,
+                                           mixdq_stream_t stream_) {
+  if (((uintptr_t)prefetch & 15) || (prefetch == nullptr && prefetch_bytes != 0))
+    return MIXDQ_ERR_INVALID_ARG;
   if (M < 0 || C <= 0 || n_out < 0 || n_out > 3) return MIXDQ_ERR_INVALID_ARG;
   if (C % 8 != 0 || C / 8 > 64 * kLnMaxChunks) return MIXDQ_ERR_SHAPE;
   if (M == 0) return MIXDQ_OK;
@@ -501,7 +524,7 @@ extern "C" int mixdq_layernorm_quantize(const void* x, const void* gamma, const 
 #define LN_LAUNCH(U, NQ, H)                                                                          \
   ln_quant_kernel<U, NQ, H><<<grid, 256, 0, stream>>>(                                               \
       (const __half*)x, (const __half*)gamma, (const __half*)beta, eps, M, C, si[0], zp[0], q[0],    \
-      si[1], zp[1], q[1], si[2], zp[2], q[2], (__half*)out_f16_or_null)
+      si[1], zp[1], q[1], si[2], zp[2], q[2], (__half*)out_f16_or_null, prefetch, prefetch_bytes)
 #define LN_BY_H(U, NQ) do { if (want_h) LN_LAUNCH(U, NQ, true); else LN_LAUNCH(U, NQ, false); } while (0)
 #define LN_BY_NQ(U)                                                                \
   do {                                                                             \

@@ -1007,11 +1007,15 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const Igem
       const __half* gh = reinterpret_cast<const __half*>(&gv);
       uint32_t pk[2] = {0u, 0u};
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float ge = __half2float(f32_to_f16_rn(mixdq_geluf(__half2float(gh[j]))));
-        const float y = __half2float(f32_to_f16_rn(__fmul_rn(__half2float(xh[j]), ge)));
-        const int q = unfused ? quantize_one<true>(y, s_inv, zpq) : quantize_one<false>(y, s_inv, zpq);
-        pk[j >> 2] |= (uint32_t)(q & 0xff) << (8 * (j & 3));
+      for (int j = 0; j < 8; j += 2) {     // two gate values at a time (packed FP32: geluf2)
+        const v2f g2 = geluf2(v2f{__half2float(gh[j]), __half2float(gh[j + 1])});
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const float ge = __half2float(f32_to_f16_rn(g2[e]));
+          const float y = __half2float(f32_to_f16_rn(__fmul_rn(__half2float(xh[j + e]), ge)));
+          const int q = unfused ? quantize_one<true>(y, s_inv, zpq) : quantize_one<false>(y, s_inv, zpq);
+          pk[(j + e) >> 2] |= (uint32_t)(q & 0xff) << (8 * ((j + e) & 3));
+        }
       }
       *reinterpret_cast<uint2*>(p.Dq + m * Dh + oc) = make_uint2(pk[0], pk[1]);
     }

@@ -33,7 +33,30 @@ import torch.nn.functional as F
 # arithmetic (include/mixdq_math.h, fixed reduction order) instead of PyTorch's, i.e. at most
 # one FP16 ulp before quantization.  Off by default: the unfused graph is the drop-in path.
 # ---------------------------------------------------------------------------------------------
+# De-fused reference of the fused graph (tests/test_unet_full_gpu.py): with DEFUSE on, the fused
+# forward keeps its structure but every fused launch is replaced by the chain of THIS repo's
+# kernels it stands for -- GroupNorm / LayerNorm / GEGLU / attention with FP16 output followed by
+# the layer's own quantize launch, separate to_q / to_k / to_v and K / V GEMMs, torch half adds in
+# place of the residual epilogues, torch.cat in place of the two-source reads.  Same arithmetic at
+# every rounding point, so the two graphs agree BIT FOR BIT and any difference is a wiring mistake.
+DEFUSE = False
+
+
+class defused:
+    """`with defused(): unet(...)` runs the de-fused reference of the fused graph."""
+
+    def __enter__(self):
+        global DEFUSE
+        self.saved, DEFUSE = DEFUSE, True
+
+    def __exit__(self, *exc):
+        global DEFUSE
+        DEFUSE = self.saved
+
+
 def _accel(m) -> bool:
+    if DEFUSE:
+        return False
     return bool(getattr(m, "valid_for_acceleration", False)) and not getattr(m, "bos", False) \
         and getattr(m, "split", 0) == 0
 
@@ -167,6 +190,8 @@ def _gn_feed(norm: nn.GroupNorm, x, consumer, silu: bool, x2=None, raw_for=None)
     given); the return value gains a third element: the input(s) quantized for it by the same pass
     (a list, one INT8 tensor per source), or None when that pass is not the HIP kernel."""
     from mixdq_amd import _C
+    if DEFUSE and x2 is not None:
+        x, x2 = torch.cat([x, x2], dim=1), None
     N, C, H, W = x.shape
     C += 0 if x2 is None else x2.shape[1]
     if (_fusable_f16(x) and x.is_contiguous(memory_format=torch.channels_last)
@@ -175,7 +200,8 @@ def _gn_feed(norm: nn.GroupNorm, x, consumer, silu: bool, x2=None, raw_for=None)
                                 and x.shape[1] % 8 == 0 and x2.shape[1] % 8 == 0))
             and _C.groupnorm_supported(N, H * W, C, norm.num_groups)):
         raw_qp = None
-        if (GN_RAW_OUTPUTS and raw_for is not None and getattr(raw_for, "valid_for_acceleration", False)
+        if (GN_RAW_OUTPUTS and not DEFUSE and raw_for is not None
+                and getattr(raw_for, "valid_for_acceleration", False)
                 and not getattr(raw_for, "bos", False)
                 and raw_for.split == (0 if x2 is None else x.shape[1])):
             raw_qp = [(raw_for.act_scales_inv, raw_for.act_zero_points)]
@@ -255,7 +281,7 @@ def _run(layer, feed, residual=None):
     t, quantized = feed
     if quantized:
         return layer.forward_quantized(t, residual=residual)
-    if residual is not None and _fp_layer(layer):
+    if residual is not None and _fp_layer(layer) and not DEFUSE:
         return layer.forward_fp(t, residual=residual)       # FP16 kernel, add in its epilogue
     y = layer(t)
     return y if residual is None else y + residual
@@ -271,7 +297,7 @@ def _linear_res(layer, x, residual):
     if _accel(layer) and _fusable_f16(x) and residual.is_contiguous():
         from mixdq_amd.nn.Linear import quant_op
         return layer.forward_quantized(quant_op(x, *_qp(layer)), residual=residual)
-    if _fp_layer(layer) and _fusable_f16(x):
+    if _fp_layer(layer) and _fusable_f16(x) and not DEFUSE:
         return layer.forward_fp(x, residual=residual)
     return layer(x) + residual
 
@@ -345,7 +371,7 @@ class ResnetBlock2D(nn.Module):
         """The (hidden, skip) pair can stay unconcatenated: the shortcut is a W8A8 split layer whose
         split is exactly `hidden`, and both tensors are channels-last with channel counts % 8."""
         sc = self.conv_shortcut
-        return bool(sc is not None and getattr(sc, "valid_for_acceleration", False)
+        return bool(not DEFUSE and sc is not None and getattr(sc, "valid_for_acceleration", False)
                     and getattr(sc, "split", 0) == x.shape[1] and _fusable_f16(skip)
                     and x.is_contiguous(memory_format=torch.channels_last)
                     and skip.is_contiguous(memory_format=torch.channels_last)
@@ -389,7 +415,7 @@ class ResnetBlock2D(nn.Module):
             feed, q = _gn_feed(self.norm1, x, self.conv1, silu=True, x2=skip)
         if q:   # h = conv1(..) + t[:, :, None, None], the add folded into the conv epilogue
             h = self.conv1.forward_quantized(feed, residual=t.contiguous(), residual_per_image=True)
-        elif _fp_layer(self.conv1):
+        elif _fp_layer(self.conv1) and not DEFUSE:
             h = self.conv1.forward_fp(feed, residual=t.contiguous(), residual_per_image=True)
         else:
             h = self.conv1(feed) + t[:, :, None, None]
@@ -401,7 +427,7 @@ class ResnetBlock2D(nn.Module):
         feed, q = _gn_feed(self.norm2, h, self.conv2, silu=True)
         if q and x.is_contiguous(memory_format=torch.channels_last):
             return self.conv2.forward_quantized(feed, residual=x)  # x + conv2(..)
-        if not q and _fp_layer(self.conv2):
+        if not q and _fp_layer(self.conv2) and not DEFUSE:
             return self.conv2.forward_fp(feed, residual=x)
         return x + self.conv2(feed)
 
@@ -457,7 +483,7 @@ class Attention(nn.Module):
         if _accel(out) and residual.is_contiguous():
             o_int = _C.attention_f16(q, k, v, self.heads, *_qp(out))
             return out.forward_quantized(o_int, residual=residual)
-        return out(_C.attention_f16(q, k, v, self.heads)) + residual
+        return _linear_res(out, _C.attention_f16(q, k, v, self.heads), residual)
 
 
 def _cross_fusable(attn, feed, k, v, residual) -> bool:
@@ -465,7 +491,7 @@ def _cross_fusable(attn, feed, k, v, residual) -> bool:
     from mixdq_amd import _C
     q, out = attn.to_q, attn.to_out[0]
     t, quantized = feed
-    return bool(quantized and _accel(q) and q.bias is None and _accel(out) and t.dim() == 3
+    return bool(not DEFUSE and quantized and _accel(q) and q.bias is None and _accel(out) and t.dim() == 3
                 and attn.heads * 64 == q.out_features and residual.is_contiguous()
                 and all(_fusable_f16(z) and z.dim() == 3 and z.stride(-1) == 1
                         and z.stride(0) % 8 == 0 and z.stride(1) % 8 == 0
@@ -516,11 +542,15 @@ class FeedForward(nn.Module):
         folded into net.2's epilogue."""
         from mixdq_amd import _C
         out_layer = self.net[2]
-        if self.__dict__.get("_interleaved"):
+        if self.__dict__.get("_interleaved") and not DEFUSE:
             assert feed[1], "interleaved rows need the quantized feed"
             q = self.net[0].proj.forward_quantized_geglu(feed[0], out_layer)
             return out_layer.forward_quantized(q, residual=residual)
         h = _run(self.net[0].proj, feed)
+        if self.__dict__.get("_interleaved"):     # DEFUSE: columns back to [values | gates]
+            D2 = h.shape[-1]
+            inv = torch.argsort(_C.geglu_row_order(D2 // 2, h.device))
+            h = h.index_select(-1, inv)
         D = h.shape[-1] // 2
         if _fusable_f16(h) and h.is_contiguous() and D % 8 == 0:
             if _accel(out_layer):
@@ -560,7 +590,7 @@ class BasicTransformerBlock(nn.Module):
         or their quantizer tensors change (e.g. quantize_unet after an FP16 run of this graph)."""
         a = self.attn1
         layers = [a.to_q, a.to_k, a.to_v]
-        if not all(_accel(m) and m.bias is None for m in layers):
+        if DEFUSE or not all(_accel(m) and m.bias is None for m in layers):
             return None
         if len(set(_quantizer_groups(_memo(self), "qkv", layers))) != 1:
             return None
@@ -1005,7 +1035,7 @@ class SDXLUNet(nn.Module):
         add = torch.cat([text_embeds, tid.reshape(B, -1).to(dtype)], dim=-1)
         emb = emb + self.add_embedding(add)
 
-        if self.fused and _fusable_f16(sample):
+        if self.fused and _fusable_f16(sample) and not DEFUSE:
             self._project_temb_ahead(emb)
             self._project_context_ahead(encoder_hidden_states)
         x = sample.contiguous(memory_format=torch.channels_last)

@@ -276,7 +276,7 @@ static int gn_geom(int N, int64_t HW, int C, int G, int* cg, int* OC, int* PP, i
     if ((8 * o + 7) / *cg - (8 * o) / *cg > 1) return 0;
   *PP = *OC >= 256 ? 1 : 256 / *OC;
   if (G > *OC * *PP) return 0;
-  int64_t target = (512 + N - 1) / N;
+  int64_t target = 512; /* per image: independent of the batch (N) */
   int64_t p = (HW + target - 1) / target;
   p = ((p + *PP - 1) / *PP) * *PP;
   *ppb = (int)p;

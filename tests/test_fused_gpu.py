@@ -143,6 +143,25 @@ def test_shared_math_spec_matches_on_device(C, oracle):
     assert np.array_equal(o.cpu().numpy().reshape(-1).view(np.uint16), want.view(np.uint16))
 
 
+def test_packed_gelu_equals_the_scalar_specification_on_every_fp16_gate(C, oracle):
+    """The kernels evaluate GELU two values at a time on the packed-FP32 VALU (csrc/common.h
+    geluf2); every half must perform the scalar specification's operations: all 65536 FP16 bit
+    patterns as the gate (NaN / inf included), x = 1, against the host evaluation of
+    include/mixdq_math.h -- and through the GEMM + GEGLU epilogue, whose INT8 output must be the
+    quantizer applied to those values."""
+    L = oracle.lib()
+    v = np.arange(65536, dtype=np.uint32).astype(np.uint16).view(np.float16)
+    hin = np.concatenate([np.ones_like(v), v]).reshape(1, 2 * v.size)
+    _, o = C.geglu_quantize(t(hin), want_f16=True)
+    with np.errstate(all="ignore"):
+        want = np.array([np.float32(L.mixdq_oracle_geluf(float(a))) for a in v.astype(np.float32)],
+                        np.float32).astype(np.float16)
+    got = o.cpu().numpy().reshape(-1)
+    both_nan = np.isnan(got) & np.isnan(want)
+    assert np.array_equal(got.view(np.uint16)[~both_nan], want.view(np.uint16)[~both_nan])
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+
+
 GEGLU_GEMM_CASES = [  # M, D, K, forced tile config (0 = automatic), bias
     (1024, 640, 320, 0, True), (96, 64, 64, 4, True), (77, 32, 48, 4, False),
     (200, 160, 128, 3, True), (200, 160, 128, 41, True), (300, 128, 256, 13, True),
