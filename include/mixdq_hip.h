@@ -239,16 +239,6 @@ int mixdq_layernorm_quantize(const void* x_f16, const void* gamma_f16, const voi
                              int8_t* const* out_q, void* out_f16_or_null, int flags,
                              mixdq_stream_t stream);
 
-/* The same launch that also touches `prefetch_bytes` bytes at `prefetch` (16-byte aligned device
- * pointer, or null / 0): the weights of the layer that consumes this launch's output, so that they
- * are in the Infinity Cache when that layer's kernel starts (the bytes are read and discarded;
- * results are unaffected).  No reference counterpart. */
-int mixdq_layernorm_quantize_pf(const void* x_f16, const void* gamma_f16, const void* beta_f16,
-                                float eps, int64_t M, int C, int n_out,
-                                const float* const* scale_inv, const float* const* zero_point,
-                                int8_t* const* out_q, void* out_f16_or_null, const void* prefetch,
-                                size_t prefetch_bytes, int flags, mixdq_stream_t stream);
-
 /* GEGLU + quantize: h [M, 2D] fp16 (ff.net.0.proj output) -> fp16(h[:, :D] * fp16(gelu(h[:, D:])))
  * -> int8 [M, D] and/or fp16 [M, D].  D % 8 == 0. */
 int mixdq_geglu_quantize(const void* h_f16, int64_t M, int D,

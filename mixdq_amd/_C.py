@@ -670,9 +670,6 @@ _lib.mixdq_groupnorm_silu_quantize3.argtypes = [_vp, _i32, _vp, _vp, _vp, ctypes
 _lib.mixdq_layernorm_quantize.restype = _i32
 _lib.mixdq_layernorm_quantize.argtypes = [_vp, _vp, _vp, ctypes.c_float, _i64, _i32, _i32, _vp, _vp,
                                           _vp, _vp, _i32, _vp]
-_lib.mixdq_layernorm_quantize_pf.restype = _i32
-_lib.mixdq_layernorm_quantize_pf.argtypes = [_vp, _vp, _vp, ctypes.c_float, _i64, _i32, _i32, _vp,
-                                             _vp, _vp, _vp, _vp, _sz, _i32, _vp]
 _lib.mixdq_geglu_quantize.restype = _i32
 _lib.mixdq_geglu_quantize.argtypes = [_vp, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp]
 
@@ -743,24 +740,9 @@ def groupnorm_silu_quantize(x, num_groups, weight, bias, eps, scale_inv=None, ze
     return out_q, out_h
 
 
-def _pf_args(prefetch):
-    """(pointer, bytes) of a tensor whose bytes a producer launch touches for its consumer (the
-    consumer layer's weights); None = no prefetch."""
-    if prefetch is None or not PREFETCH:
-        return None, 0
-    _check(prefetch.is_cuda and prefetch.is_contiguous() and prefetch.data_ptr() % 16 == 0,
-           "prefetch target should be a contiguous, 16-byte aligned GPU tensor")
-    return prefetch.data_ptr(), (prefetch.numel() * prefetch.element_size()) & ~15
-
-
-# MIXDQ_PREFETCH=0 turns the weight prefetch of the producer launches off (A/B runs)
-PREFETCH = os.environ.get("MIXDQ_PREFETCH", "1") != "0"
-
-
-def layernorm_quantize(x, weight, bias, eps, qparams, want_f16=False, prefetch=None):
+def layernorm_quantize(x, weight, bias, eps, qparams, want_f16=False):
     """x: fp16 [..., C] contiguous; qparams: up to three (scale_inv, zero_point) device-scalar
-    pairs.  Returns ([int8 ...], fp16 or None).  `prefetch`: a tensor (the consumer layer's
-    weights) whose bytes the launch also touches, see mixdq_layernorm_quantize_pf."""
+    pairs.  Returns ([int8 ...], fp16 or None)."""
     _check(x.is_cuda and x.dtype == torch.float16 and x.is_contiguous(),
            "x should be a contiguous fp16 GPU tensor")
     C = x.shape[-1]
@@ -776,10 +758,8 @@ def layernorm_quantize(x, weight, bias, eps, qparams, want_f16=False, prefetch=N
     w, b = weight.contiguous(), bias.contiguous()
     _check(w.dtype == torch.float16 and b.dtype == torch.float16, "gamma/beta should be fp16")
     with torch.cuda.device(x.device):
-        pf_ptr, pf_bytes = _pf_args(prefetch)
-        code = _lib.mixdq_layernorm_quantize_pf(x.data_ptr(), w.data_ptr(), b.data_ptr(),
-                                                float(eps), M, C, n, si, zp, oq, _ptr(out_h),
-                                                pf_ptr, pf_bytes, FLAGS, _stream())
+        code = _lib.mixdq_layernorm_quantize(x.data_ptr(), w.data_ptr(), b.data_ptr(), float(eps),
+                                             M, C, n, si, zp, oq, _ptr(out_h), FLAGS, _stream())
     _status(code, "layernorm_quantize")
     return outs, out_h
 

@@ -399,254 +399,6 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2
   }
 }
 
-// ---------------------------------------------------------------------------------------------
-// Key-split variant: 8 waves = 4 row groups x 2 key halves.  Waves w and w + 4 own the same 32
-// query rows and sit on the same SIMD; wave w takes the even key tiles, w + 4 the odd ones, each
-// with its own running (max, sum, O).  A wave issues in order, so one wave alone runs its MFMAs
-// and its softmax back to back; two waves on a SIMD drift half a phase apart and one's MFMAs run
-// under the other's exponentials.  The halves are merged through LDS at the end (no global
-// traffic, no fences).  Rounds of two tiles, three rounds of LDS (one in use, two in flight).
-template <bool QUANT, bool RAGGED>
-__global__ __launch_bounds__(512) void attn_fwd_ks2_kernel(const AttnParams p) {
-  constexpr int NI = 2;                          // 16 DMA pieces per tile over 8 waves
-  constexpr int RSTAGES = 3, RBYTES = 2 * kStageBytes;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int rg = wave & 3, half = wave >> 2;
-  const int l32 = lane & 31, hh = lane >> 5;
-  const int qb = blockIdx.x % p.qblocks;
-  const int head = (blockIdx.x / p.qblocks) % p.heads;
-  const int b = blockIdx.x / (p.qblocks * p.heads);
-  const int q0 = qb * 128 + rg * 32;
-
-  v8h qf[4];
-  {
-    const int qr = min(q0 + l32, p.tq - 1);
-    const __half* qrow = p.q + b * p.q_bs + (long)qr * p.q_rs + head * kHeadDim + hh * 8;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const v8h*>(qrow + ks * 16);
-  }
-
-  // staging (as in attn_fwd_kernel): waves 0..3 stage K, 4..7 stage V, two 1-KiB pieces per tile
-  const int srow = lane >> 3, spos = lane & 7;
-  const bool stage_v = wave * NI >= 8;
-  const __half* sbase = (stage_v ? p.v + b * p.v_bs : p.k + b * p.k_bs) + head * kHeadDim;
-  const int srs = (int)(stage_v ? p.v_rs : p.k_rs);
-  const int last_key = p.tkv - 1;
-  int row_off[NI], col_off[NI];
-#pragma unroll
-  for (int i = 0; i < NI; ++i) {
-    const int krow = ((wave * NI + i) & 7) * 8 + srow;
-    const int sw = stage_v ? ((krow >> 1) & 1) << 2 : (krow >> 1) & 7;
-    col_off[i] = (spos ^ sw) * 8;
-    row_off[i] = krow * srs + col_off[i];
-  }
-  auto stage_round = [&](int rbuf, int r) {      // tiles 2r and 2r + 1
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int t = 2 * r + h;
-      char* dst = smem + rbuf * RBYTES + h * kStageBytes + wave * NI * 1024;
-      if ((t + 1) * kKeys <= p.tkv) {
-        const int tile_off = t * kKeys * srs;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) glds16(sbase + (tile_off + row_off[i]), dst + i * 1024);
-      } else {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-          const int key = min(t * kKeys + ((wave * NI + i) & 7) * 8 + srow, last_key);
-          glds16(sbase + (key * srs + col_off[i]), dst + i * 1024);
-        }
-      }
-    }
-  };
-
-  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-  unsigned k_a[4];
-#pragma unroll
-  for (int ks = 0; ks < 4; ++ks)
-    k_a[ks] = lds0 + half * kStageBytes + l32 * kRow + (((2 * ks + hh) ^ ((l32 >> 1) & 7)) << 4);
-  const int q4 = (lane & 15) >> 2, pp = lane & 3, g16 = (lane >> 4) & 1;
-  const int v_rd0 = kTileBytes + (4 * hh + q4) * kRow +
-                    (((2 * g16 + (pp >> 1)) ^ (((q4 >> 1) & 1) << 2)) << 4) + 8 * (pp & 1);
-  const unsigned v_a0 = lds0 + half * kStageBytes + v_rd0, v_a1 = lds0 + half * kStageBytes + (v_rd0 ^ 64);
-
-  const int ntiles = (p.tkv + kKeys - 1) / kKeys;
-  const int nrounds = (ntiles + 1) / 2;
-
-  v16f o[2], lsum;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; lsum[i] = 0.f; }
-  float m_i = -INFINITY;
-  const float c = p.scale_log2;
-  v8h ones;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) ones[i] = (_Float16)1.f;
-
-  stage_round(0, 0);
-  stage_round(1, 1);                             // rounds past the end re-stage the last key
-  for (int r0 = 0; r0 < nrounds; r0 += RSTAGES) {
-#pragma unroll
-    for (int rb = 0; rb < RSTAGES; ++rb) {       // round r0 + rb lives in buffer rb (compile-time)
-      const int r = r0 + rb;
-      if (r >= nrounds) break;
-      const int t = 2 * r + half;
-      // round r has landed (round r+1 may still fly); every wave is past round r-1
-      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(2 * NI) : "memory");
-      stage_round((rb + 2) % RSTAGES, r + 2);
-      if (t < ntiles) {                          // an odd tile count leaves the last odd slot idle
-        VFrag vf[2][2][2];
-        {
-          const unsigned a0 = v_a0 + rb * RBYTES, a1 = v_a1 + rb * RBYTES;
-          tr_read2_imm<0 * kRow>(vf[0][0][0], a0);
-          tr_read2_imm<0 * kRow>(vf[0][0][1], a1);
-          tr_read2_imm<16 * kRow>(vf[0][1][0], a0);
-          tr_read2_imm<16 * kRow>(vf[0][1][1], a1);
-          tr_read2_imm<32 * kRow>(vf[1][0][0], a0);
-          tr_read2_imm<32 * kRow>(vf[1][0][1], a1);
-          tr_read2_imm<48 * kRow>(vf[1][1][0], a0);
-          tr_read2_imm<48 * kRow>(vf[1][1][1], a1);
-        }
-        v16f sc[2];
-        {
-          v8h kf[2][4];
-#pragma unroll
-          for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-              kf[kb][ks] = *(const __attribute__((address_space(3))) v8h*)(size_t)(
-                  k_a[ks] + (rb * RBYTES + kb * 32 * kRow));
-#pragma unroll
-          for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) sc[kb][i] = 0.f;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-              sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][ks], qf[ks], sc[kb], 0, 0, 0);
-          }
-        }
-        if (RAGGED && t == ntiles - 1) {
-          asm volatile("" ::: "memory");
-          const int lim = p.tkv - t * kKeys - 4 * hh;
-#pragma unroll
-          for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-            for (int rr = 0; rr < 16; ++rr)
-              if (32 * kb + 8 * (rr >> 2) + (rr & 3) >= lim) sc[kb][rr] = -INFINITY;
-        }
-        float mx = sc[0][0];
-#pragma unroll
-        for (int rr = 1; rr < 16; ++rr) mx = fmaxf(mx, sc[0][rr]);
-#pragma unroll
-        for (int rr = 0; rr < 16; ++rr) mx = fmaxf(mx, sc[1][rr]);
-        mx = half_max(mx);
-        const float m_new = fmaxf(m_i, mx);
-        const bool grew = m_new > m_i;
-        const float mc = m_new * c;
-        v8h pf[2][2];
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int rr = 0; rr < 16; ++rr)
-            pf[kb][rr >> 3][rr & 7] =
-                (_Float16)__builtin_amdgcn_exp2f(__builtin_fmaf(sc[kb][rr], c, -mc));
-        if (__builtin_amdgcn_ballot_w64(grew)) {
-          const float alpha = __builtin_amdgcn_exp2f((m_i - m_new) * c);
-#pragma unroll
-          for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
-          lsum[0] *= alpha;
-        }
-        m_i = m_new;
-        s_waitcnt_lgkm0();
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-#pragma unroll
-            for (int db = 0; db < 2; ++db)
-              o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[kb][u][db].h, pf[kb][u], o[db], 0, 0, 0);
-            lsum = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf[kb][u], lsum, 0, 0, 0);
-          }
-      }
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  // ---- merge the two key halves of each row group: the odd half parks (m, l, O) in LDS ----
-  float* Mx = reinterpret_cast<float*>(smem) + rg * (64 * 34) + lane;     // [34][64] per row group
-  if (half == 1) {
-    Mx[0] = m_i;
-    Mx[64] = lsum[0];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { Mx[(2 + i) * 64] = o[0][i]; Mx[(18 + i) * 64] = o[1][i]; }
-  }
-  __syncthreads();
-  char* Os = smem + 4 * 64 * 34 * 4 + rg * (32 * kORow);                  // past the merge area
-  if (half == 0) {
-    const float m1 = Mx[0], l1 = Mx[64];
-    const float m = fmaxf(m_i, m1);
-    // a half that saw no tile has m = -inf, l = 0, O = 0: its factor is exp2(-inf) = 0
-    const float a0 = __builtin_amdgcn_exp2f((m_i - m) * c), a1 = __builtin_amdgcn_exp2f((m1 - m) * c);
-    const float inv = 1.f / (lsum[0] * a0 + l1 * a1);
-    const float f0 = a0 * inv, f1 = a1 * inv;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        v4h w;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          w[j] = (_Float16)(o[db][4 * g + j] * f0 + Mx[(2 + 16 * db + 4 * g + j) * 64] * f1);
-        *reinterpret_cast<v4h*>(Os + l32 * kORow + (32 * db + 8 * g + 4 * hh) * 2) = w;
-      }
-  }
-  __syncthreads();
-  if (half != 0) return;
-  float s_inv = 0.f, zp = 0.f;
-  if constexpr (QUANT) { s_inv = *p.s_inv; zp = *p.zp; }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int id = lane + 64 * i, row = id >> 3, ch = id & 7;
-    if (q0 + row >= p.tq) continue;
-    const uint4 w = *reinterpret_cast<const uint4*>(Os + row * kORow + ch * 16);
-    const long off = b * p.o_bs + (long)(q0 + row) * p.o_rs + head * kHeadDim + ch * 8;
-    if constexpr (!QUANT) {
-      *reinterpret_cast<uint4*>(reinterpret_cast<__half*>(p.out) + off) = w;
-    } else {
-      const __half* hv = reinterpret_cast<const __half*>(&w);
-      uint32_t pk[2] = {0u, 0u};
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float x = __half2float(hv[j]);
-        const int qv = p.unfused ? quantize_one<true>(x, s_inv, zp) : quantize_one<false>(x, s_inv, zp);
-        pk[j >> 2] |= (uint32_t)(qv & 0xff) << (8 * (j & 3));
-      }
-      *reinterpret_cast<uint2*>(reinterpret_cast<int8_t*>(p.out) + off) = make_uint2(pk[0], pk[1]);
-    }
-  }
-}
-
-int launch_attn_ks2(const AttnParams& p, int batch, bool quant, hipStream_t stream) {
-  const int grid = p.qblocks * p.heads * batch;
-  constexpr int smem = 3 * 2 * kStageBytes;      // 96 KiB: three rounds of two K/V tiles
-  static_assert(smem >= 4 * 64 * 34 * 4 + 4 * 32 * kORow, "merge + output staging fit the ring");
-  const bool ragged = (p.tkv & (kKeys - 1)) != 0;
-#define MIXDQ_ATTN_KS2(Q, R)                                                                    \
-  do {                                                                                          \
-    static const hipError_t attr = hipFuncSetAttribute(                                         \
-        reinterpret_cast<const void*>(&attn_fwd_ks2_kernel<Q, R>),                              \
-        hipFuncAttributeMaxDynamicSharedMemorySize, smem);                                      \
-    if (attr != hipSuccess) return MIXDQ_ERR_LAUNCH;                                            \
-    hipLaunchKernelGGL((attn_fwd_ks2_kernel<Q, R>), dim3(grid), dim3(512), smem, stream, p);    \
-  } while (0)
-  if (quant) { if (ragged) MIXDQ_ATTN_KS2(true, true); else MIXDQ_ATTN_KS2(true, false); }
-  else       { if (ragged) MIXDQ_ATTN_KS2(false, true); else MIXDQ_ATTN_KS2(false, false); }
-#undef MIXDQ_ATTN_KS2
-  return launch_status();
-}
-
 constexpr int attn_smem_bytes(int waves, int stages) {
   const int kv = stages * kStageBytes;
   const int os = waves * 32 * kORow;
@@ -709,16 +461,15 @@ extern "C" int mixdq_attention_f16(const void* q, const void* k, const void* v, 
   p.s_inv = out_scale_inv; p.zp = out_zero_point;
   p.unfused = (flags & MIXDQ_FLAG_UNFUSED) ? 1 : 0;
 
-  // 128-query workgroups when they still fill the chip twice over, 64-query ones otherwise
-  const int force = (flags >> 8) & 0xff;         // 8: key-split 8-wave, 4 / 2: waves per workgroup
-  const long blocks128 = (long)((tq + 127) / 128) * heads * batch;
-  // key-split pays only while the grid leaves CUs with a single 4-wave workgroup (its LDS ring
-  // allows one workgroup per CU) and there are enough key tiles to split: 16.3 vs 18.6 us on the
-  // 1024-token layers at batch 1, slower everywhere else (tools/bench_attn.py --cfg 8)
-  if (force == 8 || (force == 0 && blocks128 <= kNumCU && tkv >= 8 * kKeys)) {
-    p.qblocks = (tq + 127) / 128;
-    return launch_attn_ks2(p, batch, quant, stream);
-  }
+  // 128-query workgroups (4 waves x 32 rows) when ONE IMAGE has at least half a chip of them,
+  // 64-query ones otherwise.  The rule looks at the image alone, never at the batch: both kernels
+  // run the same per-wave arithmetic, and a row of a batch gets exactly the launch geometry it
+  // would get alone.  (Round 2's key-split 8-wave kernel for the 1024-token layers at batch 1 is
+  // gone: after the loop was pipelined it no longer won -- 16.9 vs 16.2 us, tools/bench_attn.py --
+  // and, merging two partial softmaxes, it made a batch-1 result differ in its last bits from the
+  // same image inside a batch.)
+  const int force = (flags >> 8) & 0xff;         // 4 / 2: waves per workgroup
+  const long blocks128 = (long)((tq + 127) / 128) * heads;
   const bool big = force ? force == 4 : blocks128 >= kNumCU / 2;
   p.qblocks = big ? (tq + 127) / 128 : (tq + 63) / 64;
   if (big) return launch_attn<4, 4>(p, batch, quant, stream);

@@ -124,47 +124,4 @@ __device__ __forceinline__ v2f geluf2(v2f x) {
   return (0.5f * x) * (1.0f + erff2(x * 0.70710678118654752440f));
 }
 
-// ---- weight prefetch beside a latency-bound producer kernel -------------------------------------
-// At batch 1 every INT8 GEMM / conv of the step starts with its weights cold in HBM, and its main
-// loop is bound by outstanding requests x latency.  The small kernel that runs just before it (the
-// LayerNorm / GroupNorm / attention launch that produces its INT8 operand) is a latency chain with
-// idle memory pipes: it touches that consumer's weight bytes, so they sit in the 256 MiB Infinity
-// Cache when the consumer starts.  Block `b` of `nb` reads slice b of [ptr, ptr + bytes) with 16-byte
-// loads whose results are only kept alive (never used): pf_issue() at the start of the kernel,
-// pf_retire() at its end.
-constexpr int kPfMax = 16;                   // loads in flight per thread (64 VGPRs)
-struct PfState { uint4 v[kPfMax]; };
-
-__device__ __forceinline__ void pf_issue(PfState& st, const void* ptr, size_t bytes, int b, int nb,
-                                         int tid, int nthreads) {
-#pragma unroll
-  for (int i = 0; i < kPfMax; ++i) st.v[i] = make_uint4(0, 0, 0, 0);
-  if (ptr == nullptr) return;
-  const size_t chunks = bytes >> 4;                                   // 16-byte units
-  const size_t per = (chunks + nb - 1) / nb;
-  const size_t lo = (size_t)b * per;
-  const size_t hi = lo + per < chunks ? lo + per : chunks;
-  const uint4* src = reinterpret_cast<const uint4*>(ptr);
-  size_t c = lo + tid;
-  // slices beyond kPfMax rounds (above 64 KB per 256-thread block): whole batches are read and
-  // retired up front, the last batch stays in flight beside the kernel's own work
-  while (c + (size_t)kPfMax * nthreads < hi) {
-    uint4 t[kPfMax];
-#pragma unroll
-    for (int i = 0; i < kPfMax; ++i) t[i] = src[c + (size_t)i * nthreads];
-#pragma unroll
-    for (int i = 0; i < kPfMax; ++i) asm volatile("" ::"v"(t[i].x), "v"(t[i].y), "v"(t[i].z), "v"(t[i].w));
-    c += (size_t)kPfMax * nthreads;
-  }
-#pragma unroll
-  for (int i = 0; i < kPfMax; ++i, c += nthreads)
-    if (c < hi) st.v[i] = src[c];
-}
-
-__device__ __forceinline__ void pf_retire(const PfState& st) {
-#pragma unroll
-  for (int i = 0; i < kPfMax; ++i)
-    asm volatile("" ::"v"(st.v[i].x), "v"(st.v[i].y), "v"(st.v[i].z), "v"(st.v[i].w));
-}
-
 }  // namespace mixdq

@@ -266,13 +266,10 @@ __global__ __launch_bounds__(256) void ln_quant_kernel(
     float eps, int64_t M, int C, const float* __restrict__ s_inv0, const float* __restrict__ zp0,
     int8_t* __restrict__ q0, const float* __restrict__ s_inv1, const float* __restrict__ zp1,
     int8_t* __restrict__ q1, const float* __restrict__ s_inv2, const float* __restrict__ zp2,
-    int8_t* __restrict__ q2, __half* __restrict__ out_h, const void* __restrict__ pf_ptr,
-    size_t pf_bytes) {
-  PfState pf;
-  pf_issue(pf, pf_ptr, pf_bytes, blockIdx.x, gridDim.x, threadIdx.x, 256);
+    int8_t* __restrict__ q2, __half* __restrict__ out_h) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) { pf_retire(pf); return; }
+  if (row >= M) return;
   const int nch = C / 8;
   const __half* xr = x + row * C;
   Half8 h[kLnMaxChunks], gmv[kLnMaxChunks], btv[kLnMaxChunks];
@@ -339,7 +336,6 @@ __global__ __launch_bounds__(256) void ln_quant_kernel(
       if constexpr (WANT_H) *reinterpret_cast<Half8*>(out_h + off) = oh;
     }
   }
-  pf_retire(pf);
 }
 
 // ------------------------------------------------------------------------------- GEGLU
@@ -490,19 +486,6 @@ extern "C" int mixdq_layernorm_quantize(const void* x, const void* gamma, const 
                                         const float* const* scale_inv,
                                         const float* const* zero_point, int8_t* const* out_q,
                                         void* out_f16_or_null, int flags, mixdq_stream_t stream_) {
-  return mixdq_layernorm_quantize_pf(x, gamma, beta, eps, M, C, n_out, scale_inv, zero_point, out_q,
-                                     out_f16_or_null, nullptr, 0, flags, stream_);
-}
-
-extern "C" int mixdq_layernorm_quantize_pf(const void* x, const void* gamma, const void* beta,
-                                           float eps, int64_t M, int C, int n_out,
-                                           const float* const* scale_inv,
-                                           const float* const* zero_point, int8_t* const* out_q,
-                                           void* out_f16_or_null, const void* prefetch,
-                                           size_t prefetch_bytes, int flags,
-                                           mixdq_stream_t stream_) {
-  if (((uintptr_t)prefetch & 15) || (prefetch == nullptr && prefetch_bytes != 0))
-    return MIXDQ_ERR_INVALID_ARG;
   if (M < 0 || C <= 0 || n_out < 0 || n_out > 3) return MIXDQ_ERR_INVALID_ARG;
   if (C % 8 != 0 || C / 8 > 64 * kLnMaxChunks) return MIXDQ_ERR_SHAPE;
   if (M == 0) return MIXDQ_OK;
@@ -524,7 +507,7 @@ extern "C" int mixdq_layernorm_quantize_pf(const void* x, const void* gamma, con
 #define LN_LAUNCH(U, NQ, H)                                                                          \
   ln_quant_kernel<U, NQ, H><<<grid, 256, 0, stream>>>(                                               \
       (const __half*)x, (const __half*)gamma, (const __half*)beta, eps, M, C, si[0], zp[0], q[0],    \
-      si[1], zp[1], q[1], si[2], zp[2], q[2], (__half*)out_f16_or_null, prefetch, prefetch_bytes)
+      si[1], zp[1], q[1], si[2], zp[2], q[2], (__half*)out_f16_or_null)
 #define LN_BY_H(U, NQ) do { if (want_h) LN_LAUNCH(U, NQ, true); else LN_LAUNCH(U, NQ, false); } while (0)
 #define LN_BY_NQ(U)                                                                \
   do {                                                                             \

@@ -38,10 +38,35 @@
 #define MIXDQ_ABLATE 0
 #endif
 
+// MIXDQ_STAMP (diagnostic builds only, tools/stamp_build.sh): every wave of every workgroup records the
+// shader clock (s_memtime) at the phase boundaries of igemm_kernel into a buffer registered with
+// mixdq_debug_stamps(); tools/stamp_report.py turns them into a per-phase time line.
+#ifndef MIXDQ_STAMP
+#define MIXDQ_STAMP 0
+#endif
+
 namespace mixdq {
 namespace {
 
 __device__ uint4 g_zero16;   // the zero page (device globals are zero-initialised)
+#if MIXDQ_STAMP
+__device__ unsigned long long g_stamps;      // address of [workgroup][wave 0..15][8] uint64, or 0
+#define MIXDQ_STAMP_AT(slot)                                                                      \
+  do {                                                                                            \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                   \
+    const unsigned long long r_ = __builtin_amdgcn_s_memrealtime();                               \
+    const unsigned long long a_ = g_stamps;                                                       \
+    if (a_ != 0 && lane == 0) {                                                                   \
+      auto sp_ = (__attribute__((address_space(1))) unsigned long long*)a_ +                      \
+                 ((size_t)blockIdx.x * 16 + wid) * 8;                                             \
+      sp_[slot] = t_;                                                                             \
+      if ((slot) == 0) sp_[6] = r_;                                                               \
+      if ((slot) == 7) sp_[5] = r_;                                                               \
+    }                                                                                             \
+  } while (0)
+#else
+#define MIXDQ_STAMP_AT(slot) do {} while (0)
+#endif
 
 struct IgemmParams {
   const int8_t* A;       // activations: [M,Ktot] (linear) or [N,H,W,C] (conv)
@@ -195,6 +220,7 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const Igem
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int kg = wid / (WM * WN);                 // k-split group (0 when KSPLIT == 1)
   const int wm = (wid % (WM * WN)) / WN, wn = wid % WN;
+  MIXDQ_STAMP_AT(0);
 
   // ---- XCD- and L2-aware tile map.  Blocks are dealt round-robin over the 8 XCDs (bid % 8), each
   //      with its own 4 MiB L2: give every XCD a contiguous run of the tile sequence (bijective
@@ -521,6 +547,7 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const Igem
     for (int u = 0; u < 5; ++u) stage_unit4(u);
   }
 
+  MIXDQ_STAMP_AT(1);
   // ---- per-channel epilogue vectors -> LDS, issued now so their latency hides under the main
   //      loop (read back ~100 cycles away instead of ~1 us away per quad at the end).
   //      P_B0: bias0[n] (table mode: the full-window class row), P_SC: scale[n], P_BS: bias[n].
@@ -668,6 +695,7 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const Igem
       const int kt = kt0 + s;
       if (kt < nk) {
         wait_tile();
+        if (kt == 0) MIXDQ_STAMP_AT(2);
         const char* S0 = smem + s * STAGE;
         if constexpr (KS * (TM + TN) <= 16) {
           // small wave tiles are latency-bound: put every fragment read of the K-tile in flight
@@ -744,6 +772,7 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const Igem
   }
   // the zero-page DMAs staged for tiles >= nk are still in flight: drain before LDS is reused
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  MIXDQ_STAMP_AT(3);
 
   // ---- epilogue: registers -> f16 tile in LDS -> whole-row 16-byte stores --------------------
   __syncthreads();   // every wave is done reading the stage buffers
@@ -840,6 +869,7 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const Igem
     }
   }
   __syncthreads();
+  MIXDQ_STAMP_AT(4);
   if constexpr (ATT) {
     // ---- cross-attention on the staged tile: wave w < 4 owns head (w >> 1) of the pair and 32 of
     //      the 64 query rows; arithmetic and order are those of attn_fwd_kernel (csrc/attention.hip)
@@ -1019,6 +1049,7 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const Igem
       }
       *reinterpret_cast<uint2*>(p.Dq + m * Dh + oc) = make_uint2(pk[0], pk[1]);
     }
+    MIXDQ_STAMP_AT(7);
     return;
   }
   constexpr int CPRO = BN / 8;   // 16-byte chunks per output row of the tile
@@ -1073,6 +1104,7 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const Igem
       if (n + 8 <= p.N) *reinterpret_cast<uint2*>(dst + 4) = make_uint2(v.z, v.w);
     }
   }
+  MIXDQ_STAMP_AT(7);
 }
 
 // ---- small-alignment / generic fallback (K % 16 != 0 or C % 16 != 0): one output per thread.
@@ -1807,6 +1839,14 @@ extern "C" const char* mixdq_status_string(int status) {
 }
 
 extern "C" int mixdq_abi_version(void) { return MIXDQ_ABI_VERSION; }
+
+#if MIXDQ_STAMP
+// diagnostic builds only: register (or clear, with null) the stamp buffer, [grid][16 waves][8] uint64
+extern "C" int mixdq_debug_stamps(void* buffer) {
+  unsigned long long b = (unsigned long long)(uintptr_t)buffer;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &b, sizeof(b)) == hipSuccess ? MIXDQ_OK : MIXDQ_ERR_LAUNCH;
+}
+#endif
 
 // a Linear problem (k_align == k_total: no taps) that takes the fast staging path
 static bool linear_fast(int64_t M, int N, int k_align, int k_total) {

@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Per-phase time line of one igemm launch from in-kernel stamps (diagnostic build, tools/stamp_build.sh):
+
+    MIXDQ_HIP_LIB=$PWD/build/stamp/libmixdq_stamp.so python tools/stamp_report.py M N K [--geglu] [--cfg id] [--res]
+
+Slots: 0 entry | 1 prologue DMA issued | 2 first K-tile landed | 3 main loop done | 4 accumulators ->
+fp16 tile in LDS | 7 stores / GEGLU done.  Printed: median and max over waves of the time since the
+EARLIEST entry stamp of the launch, in us (shader clock / the 100 MHz real-time clock)."""
+import argparse
+import ctypes
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import mixdq_amd._C as C  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("M", type=int)
+    ap.add_argument("N", type=int)
+    ap.add_argument("K", type=int)
+    ap.add_argument("--geglu", action="store_true")
+    ap.add_argument("--res", action="store_true")
+    ap.add_argument("--cfg", type=int, default=0)
+    ap.add_argument("--cold", action="store_true", help="stream 512 MB between launches")
+    a = ap.parse_args()
+    lib = C._lib
+    assert hasattr(lib, "mixdq_debug_stamps"), "not a stamped build (tools/stamp_build.sh)"
+    lib.mixdq_debug_stamps.argtypes = [ctypes.c_void_p]
+    g = torch.Generator().manual_seed(0)
+    x = torch.randint(-128, 128, (a.M, a.K), generator=g, dtype=torch.int8).to(DEV)
+    w = torch.randint(-128, 128, (a.N, a.K), generator=g, dtype=torch.int8).to(DEV)
+    sc = (torch.rand(a.N, generator=g) * 1e-4).to(DEV)
+    one, z = torch.ones((), device=DEV), torch.zeros((), device=DEV)
+    res = torch.randn(a.M, a.N, generator=g).half().to(DEV) if a.res else None
+    flush = torch.empty(512 << 20, dtype=torch.uint8, device=DEV)
+    grid_max = 1 << 16
+    stamps = torch.zeros((grid_max, 16, 8), dtype=torch.int64, device=DEV)
+
+    def launch():
+        if a.geglu:
+            C.qlinear_geglu(x, w, sc, sc, None, one, z, _cfg=a.cfg)
+        else:
+            C.qlinear_w8_a8_ohalf(x, w, sc, z, z, sc, sc, sc, None, _cfg=a.cfg, _residual=res)
+
+    for _ in range(3):
+        launch()
+    torch.cuda.synchronize()
+    rows = []
+    for rep in range(5):
+        if a.cold:
+            flush.zero_()
+        stamps.zero_()
+        torch.cuda.synchronize()
+        lib.mixdq_debug_stamps(ctypes.c_void_p(stamps.data_ptr()))
+        launch()
+        torch.cuda.synchronize()
+        lib.mixdq_debug_stamps(None)
+        s = stamps.cpu().numpy().astype(np.int64)
+        used = s[:, :, 0] != 0
+        t0 = s[:, :, 0][used].min()
+        # shader clock per real-time tick (100 MHz): from the longest-lived wave
+        dt_clk = (s[:, :, 7] - s[:, :, 0])[used]
+        dt_rt = (s[:, :, 5] - s[:, :, 6])[used]
+        ok = dt_rt > 0
+        ghz = float(np.median(dt_clk[ok] / dt_rt[ok])) * 0.1 if ok.any() else 2.0
+        line = {}
+        for slot in (0, 1, 2, 3, 4, 7):
+            v = (s[:, :, slot][used & (s[:, :, slot] != 0)] - t0) / (ghz * 1e3)
+            if v.size:
+                line[slot] = (float(np.median(v)), float(v.max()))
+        rows.append((ghz, int(used.any(axis=1).sum()), line))
+    for ghz, nwg, line in rows:
+        print(f"clock {ghz:.2f} GHz, {nwg} workgroups | " + " | ".join(
+            f"s{k}: med {v[0]:6.2f} max {v[1]:6.2f}" for k, v in line.items()))
+
+
+if __name__ == "__main__":
+    main()
