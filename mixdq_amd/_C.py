@@ -648,7 +648,7 @@ def conv2d_f16(input, weight, bias=None, stride=1, padding=0, *, _residual=None,
     return D
 
 
-F16_CONFIGS = (4, 13, 20, 25, 35, 37, 41, 44, 45, 56)   # csrc/igemm.hip MIXDQ_F16_CONFIGS
+F16_CONFIGS = (4, 13, 20, 25, 35, 41)   # csrc/igemm.hip MIXDQ_F16_CONFIGS (one accumulation order)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -50,7 +50,7 @@ namespace {
 
 __device__ uint4 g_zero16;   // the zero page (device globals are zero-initialised)
 #if MIXDQ_STAMP
-__device__ unsigned long long g_stamps;      // address of [workgroup][wave 0..15][8] uint64, or 0
+__device__ unsigned long long g_stamps;      // address of [workgroup][wave 0..15][16] uint64, or 0
 #define MIXDQ_STAMP_AT(slot)                                                                      \
   do {                                                                                            \
     const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                   \
@@ -58,10 +58,10 @@ __device__ unsigned long long g_stamps;      // address of [workgroup][wave 0..1
     const unsigned long long a_ = g_stamps;                                                       \
     if (a_ != 0 && lane == 0) {                                                                   \
       auto sp_ = (__attribute__((address_space(1))) unsigned long long*)a_ +                      \
-                 ((size_t)blockIdx.x * 16 + wid) * 8;                                             \
+                 ((size_t)blockIdx.x * 16 + wid) * 16;                                            \
       sp_[slot] = t_;                                                                             \
-      if ((slot) == 0) sp_[6] = r_;                                                               \
-      if ((slot) == 7) sp_[5] = r_;                                                               \
+      if ((slot) == 0) sp_[8] = r_;                                                               \
+      if ((slot) == 7) sp_[9] = r_;                                                               \
     }                                                                                             \
   } while (0)
 #else
@@ -776,6 +776,7 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const Igem
 
   // ---- epilogue: registers -> f16 tile in LDS -> whole-row 16-byte stores --------------------
   __syncthreads();   // every wave is done reading the stage buffers
+  MIXDQ_STAMP_AT(4);
   if constexpr (KSPLIT > 1) {
     // groups 1.. park their partial accumulators (behind the fp16 tile's area), group 0 adds them
     constexpr int WREGS = TN * TM * ACC;          // accumulator registers of one wave
@@ -868,8 +869,9 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const Igem
       }
     }
   }
+  MIXDQ_STAMP_AT(5);
   __syncthreads();
-  MIXDQ_STAMP_AT(4);
+  MIXDQ_STAMP_AT(6);
   if constexpr (ATT) {
     // ---- cross-attention on the staged tile: wave w < 4 owns head (w >> 1) of the pair and 32 of
     //      the 64 query rows; arithmetic and order are those of attn_fwd_kernel (csrc/attention.hip)
@@ -1478,12 +1480,12 @@ int dispatch_grouped(IgemmParams& p, int ngroups, hipStream_t stream, int cfg) {
   X(20, 256, 256, 128, 2, 4, 2, 1, 32)    \
   X(25, 128, 320, 128, 2, 4, 2, 1, 32)    \
   X(35, 128, 128, 64, 3, 4, 2, 1, 32)     \
-  X(37, 64, 64, 128, 3, 2, 2, 2, 32)      \
-  X(41, 64, 128, 128, 3, 2, 4, 1, 32)     \
-  X(44, 128, 80, 128, 3, 4, 1, 2, 16)     \
-  X(45, 64, 80, 128, 4, 4, 1, 2, 16)      \
-  X(56, 64, 80, 128, 6, 4, 1, 2, 16)
+  X(41, 64, 128, 128, 3, 2, 4, 1, 32)
 
+// Floating-point accumulation is order-sensitive, and an image must not change in its last bits
+// with the batch it runs in (the tile rule looks at M = batch x rows): every FP16 configuration
+// therefore runs the SAME accumulation -- one MFMA shape (32x32x16), no k-split groups, k ascending
+// -- so that any tile of the list gives bit-identical results (INT8 accumulation is exact: free).
 inline int select_cfg_f16(int64_t M, int N, int k_bytes) {
   const int c = select_cfg(M, N, k_bytes, false, false, /*tune=*/false);
   switch (c) {
@@ -1491,6 +1493,9 @@ inline int select_cfg_f16(int64_t M, int N, int k_bytes) {
     MIXDQ_F16_CONFIGS(X)
 #undef X
       return c;
+    case 37: return 4;              // k-split 64x64 -> the plain 64x64 tile
+    case 45: case 56: case 42: return 41;   // exact-fit 64x80 (16x16 MFMA, k-split) -> 64x128
+    case 70: case 14: case 18: return 20;
     default: return 35;
   }
 }
@@ -1841,7 +1846,7 @@ extern "C" const char* mixdq_status_string(int status) {
 extern "C" int mixdq_abi_version(void) { return MIXDQ_ABI_VERSION; }
 
 #if MIXDQ_STAMP
-// diagnostic builds only: register (or clear, with null) the stamp buffer, [grid][16 waves][8] uint64
+// diagnostic builds only: register (or clear, with null) the stamp buffer, [grid][16 waves][16] uint64
 extern "C" int mixdq_debug_stamps(void* buffer) {
   unsigned long long b = (unsigned long long)(uintptr_t)buffer;
   return hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &b, sizeof(b)) == hipSuccess ? MIXDQ_OK : MIXDQ_ERR_LAUNCH;

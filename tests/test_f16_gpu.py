@@ -64,6 +64,20 @@ def test_linear_and_conv_f16_every_configuration(C, cfg):
           F.conv2d(x.cpu().double(), w.cpu().double(), b.cpu().double(), 2, 1))
 
 
+def test_every_f16_configuration_accumulates_in_the_same_order(C):
+    """One MFMA shape, no k-split, k ascending in every FP16 tile: the results agree bit for bit, so
+    the tile rule (which looks at M = batch x rows) cannot change an image with the batch size."""
+    x, w, b = rnd((331, 2560), 14), rnd((424, 2560), 15, 0.05), rnd((424,), 16)
+    outs = [C.linear_f16(x, w, b, _cfg=cfg) for cfg in C.F16_CONFIGS]
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    assert torch.equal(C.linear_f16(x[:7], w, b), outs[0][:7])          # ... nor with M
+    xc = rnd((2, 64, 13, 11), 17).contiguous(memory_format=torch.channels_last)
+    wc, bc = rnd((72, 64, 3, 3), 18, 0.05), rnd((72,), 19)
+    outs = [C.conv2d_f16(xc, wc, bc, 1, 1, _cfg=cfg) for cfg in C.F16_CONFIGS]
+    assert all(torch.equal(outs[0], o) for o in outs[1:])
+    assert torch.equal(C.conv2d_f16(xc[:1], wc, bc, 1, 1), outs[0][:1])
+
+
 def test_linear_f16_leading_dims_residual_and_errors(C):
     x, w, b = rnd((2, 77, 320), 10), rnd((640, 320), 11, 0.05), rnd((640,), 12)
     res = rnd((2, 77, 640), 13)

@@ -3,9 +3,11 @@
 
     MIXDQ_HIP_LIB=$PWD/build/stamp/libmixdq_stamp.so python tools/stamp_report.py M N K [--geglu] [--cfg id] [--res]
 
-Slots: 0 entry | 1 prologue DMA issued | 2 first K-tile landed | 3 main loop done | 4 accumulators ->
-fp16 tile in LDS | 7 stores / GEGLU done.  Printed: median and max over waves of the time since the
-EARLIEST entry stamp of the launch, in us (shader clock / the 100 MHz real-time clock)."""
+Slots: 0 entry | 1 prologue DMA issued | 2 first K-tile landed | 3 main loop done (this wave) | 4 past
+the barrier behind the main loop | 5 accumulators -> fp16 tile in LDS (this wave) | 6 past the barrier
+behind it | 7 stores / GEGLU done.  The shader clocks of different XCDs are not synchronised, so every
+time is taken relative to the workgroup's own earliest entry stamp; printed per slot: the median over
+workgroups of the FIRST and of the LAST wave to reach it, in us (shader clock / 100 MHz real-time)."""
 import argparse
 import ctypes
 import os
@@ -41,7 +43,7 @@ def main():
     res = torch.randn(a.M, a.N, generator=g).half().to(DEV) if a.res else None
     flush = torch.empty(512 << 20, dtype=torch.uint8, device=DEV)
     grid_max = 1 << 16
-    stamps = torch.zeros((grid_max, 16, 8), dtype=torch.int64, device=DEV)
+    stamps = torch.zeros((grid_max, 16, 16), dtype=torch.int64, device=DEV)
 
     def launch():
         if a.geglu:
@@ -52,8 +54,7 @@ def main():
     for _ in range(3):
         launch()
     torch.cuda.synchronize()
-    rows = []
-    for rep in range(5):
+    for rep in range(4):
         if a.cold:
             flush.zero_()
         stamps.zero_()
@@ -63,22 +64,28 @@ def main():
         torch.cuda.synchronize()
         lib.mixdq_debug_stamps(None)
         s = stamps.cpu().numpy().astype(np.int64)
-        used = s[:, :, 0] != 0
-        t0 = s[:, :, 0][used].min()
-        # shader clock per real-time tick (100 MHz): from the longest-lived wave
+        wg = np.nonzero((s[:, :, 0] != 0).any(axis=1))[0]
+        s = s[wg]
+        used = s[:, :, 0] != 0                                  # [wg, wave]
+        big = np.iinfo(np.int64).max
+        t0 = np.where(used, s[:, :, 0], big).min(axis=1)        # per workgroup
         dt_clk = (s[:, :, 7] - s[:, :, 0])[used]
-        dt_rt = (s[:, :, 5] - s[:, :, 6])[used]
+        dt_rt = (s[:, :, 9] - s[:, :, 8])[used]
         ok = dt_rt > 0
         ghz = float(np.median(dt_clk[ok] / dt_rt[ok])) * 0.1 if ok.any() else 2.0
-        line = {}
-        for slot in (0, 1, 2, 3, 4, 7):
-            v = (s[:, :, slot][used & (s[:, :, slot] != 0)] - t0) / (ghz * 1e3)
-            if v.size:
-                line[slot] = (float(np.median(v)), float(v.max()))
-        rows.append((ghz, int(used.any(axis=1).sum()), line))
-    for ghz, nwg, line in rows:
-        print(f"clock {ghz:.2f} GHz, {nwg} workgroups | " + " | ".join(
-            f"s{k}: med {v[0]:6.2f} max {v[1]:6.2f}" for k, v in line.items()))
+        parts = []
+        for slot in (1, 2, 3, 4, 5, 6, 7):
+            v = s[:, :, slot]
+            have = used & (v != 0)
+            if not have.any():
+                continue
+            first = np.where(have, v, big).min(axis=1) - t0
+            last = np.where(have, v, 0).max(axis=1) - t0
+            sel = have.any(axis=1)
+            parts.append(f"s{slot}: {np.median(first[sel]) / (ghz * 1e3):5.2f}..{np.median(last[sel]) / (ghz * 1e3):5.2f}")
+        span = (np.where(used, s[:, :, 7], 0).max(axis=1) - t0) / (ghz * 1e3)
+        print(f"clock {ghz:.2f} GHz, {len(wg)} workgroups, workgroup life med {np.median(span):.2f} max {span.max():.2f} us | "
+              + " | ".join(parts))
 
 
 if __name__ == "__main__":
