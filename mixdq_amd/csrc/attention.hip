@@ -212,6 +212,9 @@ __device__ __forceinline__ void attn_tile_step(AttnState& st, v16f (&sc)[2], v16
 
 template <int WAVES, int STAGES, bool QUANT, bool RAGGED>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd_kernel(const AttnParams p) {
+  MIXDQ_ARGS_NOW(p.q, p.k, p.v, p.out, p.q_bs, p.q_rs, p.k_bs, p.k_rs, p.v_bs, p.v_rs, p.o_bs, p.o_rs,
+                 p.tq, p.tkv, p.heads, p.qblocks);
+  MIXDQ_ARGS_NOW(p.scale_log2, p.s_inv, p.zp, p.unfused);
   constexpr int NI = 16 / WAVES;                 // LDS-DMA wave-instructions per wave per tile
   constexpr int PRE = STAGES - 1;                // tiles staged ahead of the one whose V is consumed
   static_assert(STAGES >= 3, "tiles t (V) and t+1 (K) are read while t+2.. are in flight");

@@ -59,6 +59,36 @@ __device__ __forceinline__ __half epilogue_one(int acc, float bias0, float scale
   return f32_to_f16_rn(r);
 }
 
+// ---- kernel arguments, all at once ---------------------------------------------------------------
+// hipcc loads a kernel's arguments lazily, next to their first uses: several DEPENDENT round trips to
+// a scalar cache that is cold at kernel start (~0.5 us each, tools/stamp_report.py), in front of the
+// first useful memory request of every launch of the batch-1 chain.  MIXDQ_ARGS_NOW(a, b, ...) as
+// the first statement of a kernel makes every listed argument live in scalar registers at that
+// point, so that all of them are requested together behind one wait (at most 16 per statement).
+#define MIXDQ_ARG1_(x) "s"(x)
+#define MIXDQ_ARGS_NOW(...) asm volatile("" ::MIXDQ_FOR_EACH_(MIXDQ_ARG1_, __VA_ARGS__))
+#define MIXDQ_FE_1(m, a) m(a)
+#define MIXDQ_FE_2(m, a, ...) m(a), MIXDQ_FE_1(m, __VA_ARGS__)
+#define MIXDQ_FE_3(m, a, ...) m(a), MIXDQ_FE_2(m, __VA_ARGS__)
+#define MIXDQ_FE_4(m, a, ...) m(a), MIXDQ_FE_3(m, __VA_ARGS__)
+#define MIXDQ_FE_5(m, a, ...) m(a), MIXDQ_FE_4(m, __VA_ARGS__)
+#define MIXDQ_FE_6(m, a, ...) m(a), MIXDQ_FE_5(m, __VA_ARGS__)
+#define MIXDQ_FE_7(m, a, ...) m(a), MIXDQ_FE_6(m, __VA_ARGS__)
+#define MIXDQ_FE_8(m, a, ...) m(a), MIXDQ_FE_7(m, __VA_ARGS__)
+#define MIXDQ_FE_9(m, a, ...) m(a), MIXDQ_FE_8(m, __VA_ARGS__)
+#define MIXDQ_FE_10(m, a, ...) m(a), MIXDQ_FE_9(m, __VA_ARGS__)
+#define MIXDQ_FE_11(m, a, ...) m(a), MIXDQ_FE_10(m, __VA_ARGS__)
+#define MIXDQ_FE_12(m, a, ...) m(a), MIXDQ_FE_11(m, __VA_ARGS__)
+#define MIXDQ_FE_13(m, a, ...) m(a), MIXDQ_FE_12(m, __VA_ARGS__)
+#define MIXDQ_FE_14(m, a, ...) m(a), MIXDQ_FE_13(m, __VA_ARGS__)
+#define MIXDQ_FE_15(m, a, ...) m(a), MIXDQ_FE_14(m, __VA_ARGS__)
+#define MIXDQ_FE_16(m, a, ...) m(a), MIXDQ_FE_15(m, __VA_ARGS__)
+#define MIXDQ_FE_N_(_1, _2, _3, _4, _5, _6, _7, _8, _9, _10, _11, _12, _13, _14, _15, _16, N, ...) N
+#define MIXDQ_FOR_EACH_(m, ...)                                                                     \
+  MIXDQ_FE_N_(__VA_ARGS__, MIXDQ_FE_16, MIXDQ_FE_15, MIXDQ_FE_14, MIXDQ_FE_13, MIXDQ_FE_12,        \
+              MIXDQ_FE_11, MIXDQ_FE_10, MIXDQ_FE_9, MIXDQ_FE_8, MIXDQ_FE_7, MIXDQ_FE_6, MIXDQ_FE_5, \
+              MIXDQ_FE_4, MIXDQ_FE_3, MIXDQ_FE_2, MIXDQ_FE_1)(m, __VA_ARGS__)
+
 // ---- GELU on two values at a time (packed-FP32 VALU: v_pk_mul / v_pk_fma / v_pk_add_f32) ----------
 // Each half performs EXACTLY the IEEE operations of the scalar specification include/mixdq_math.h
 // (mixdq_geluf -> mixdq_erff -> mixdq_expf), in the same order; the two erf branches are both

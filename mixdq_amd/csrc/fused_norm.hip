@@ -77,6 +77,7 @@ struct GnRaw {
 
 __global__ void gn_stats_kernel(const __half* __restrict__ x, const __half* __restrict__ x2,
                                 float2* __restrict__ partial, GnGeom g) {
+  MIXDQ_ARGS_NOW(x, x2, partial, g.C, g.G, g.cg, g.OC, g.PP, g.HW, g.ppb, g.nchunk, g.C1);
   extern __shared__ float lds[];   // [blockDim][4]: s0, q0, s1, q1
   const int t = threadIdx.x;
   const int o = t % g.OC, pp = t / g.OC;
@@ -163,6 +164,9 @@ __global__ void gn_apply_kernel(const __half* __restrict__ x, const __half* __re
                                 const float* __restrict__ s_inv_p, const float* __restrict__ zp_p,
                                 int8_t* __restrict__ out_q, __half* __restrict__ out_h, GnGeom g,
                                 GnRaw raw) {
+  MIXDQ_ARGS_NOW(x, x2, partial, stats, eps, gamma, beta, s_inv_p, zp_p, out_q, out_h);
+  MIXDQ_ARGS_NOW(g.C, g.G, g.cg, g.OC, g.PP, g.HW, g.ppb_apply, g.nchunk, g.C1, raw.s_inv[0],
+                 raw.s_inv[1], raw.zp[0], raw.zp[1], raw.q[0], raw.q[1]);
   __shared__ float2 s_stats[1024];   // G <= OC * PP <= 1024
   const int t = threadIdx.x;
   const int o = t % g.OC, pp = t / g.OC;
@@ -267,6 +271,7 @@ __global__ __launch_bounds__(256) void ln_quant_kernel(
     int8_t* __restrict__ q0, const float* __restrict__ s_inv1, const float* __restrict__ zp1,
     int8_t* __restrict__ q1, const float* __restrict__ s_inv2, const float* __restrict__ zp2,
     int8_t* __restrict__ q2, __half* __restrict__ out_h) {
+  MIXDQ_ARGS_NOW(x, gamma, beta, eps, M, C, s_inv0, zp0, q0, s_inv1, zp1, q1, s_inv2, zp2, q2, out_h);
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;

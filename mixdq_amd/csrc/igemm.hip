@@ -170,7 +170,8 @@ __device__ __forceinline__ uint32_t add_f16x2(uint32_t a, uint32_t b) {
 // Used for the layers the reference leaves in FP16 (no activation quantizer: conv_in / conv_out,
 // the act-protected ff.net.2 ..., nn/Linear.py:155-156): D = f16(acc + bias) [+ residual].
 template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool CONV, bool FAST, bool W4,
-          int KSPLIT = 1, int MT = 32, bool F16 = false, bool ATT = false, bool PHASED = false>
+          int KSPLIT = 1, int MT = 32, bool F16 = false, bool ATT = false, bool PHASED = false,
+          bool GROUPED = false>
 __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const IgemmParams p_in) {
   static_assert(!PHASED || (BM == 256 && BN == 256 && ((BK == 128 && STAGES == 2) || (BK == 64 && STAGES == 4)) &&
                             WM == 2 && WN == 4 && KSPLIT == 1 && MT == 16 && FAST && !CONV && !W4 &&
@@ -180,9 +181,20 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const Igem
   static_assert(!ATT || (BM == 64 && BN == 128 && NWAVES_OF(WM, WN, KSPLIT) == 8 && MT == 32 && !CONV &&
                          !F16), "the attention epilogue is written for the 64x128 8-wave tile");
   static_assert(!(CONV && FAST), "the fast staging path is for Linear");
+  // every argument requested at once (common.h): 1.2-2.6 us from wave start to the first DMA before
+  MIXDQ_ARGS_NOW(p_in.A, p_in.Wt, p_in.bias0, p_in.scale, p_in.bias, p_in.table, p_in.zp, p_in.D,
+                 p_in.M, p_in.N, p_in.Ktot, p_in.tiles_m, p_in.tiles_n, p_in.groups, p_in.Dq, p_in.res);
+  MIXDQ_ARGS_NOW(p_in.H, p_in.W, p_in.C, p_in.R, p_in.S, p_in.P, p_in.Q, p_in.stride, p_in.pad,
+                 p_in.grp_rows, p_in.grp_stride, p_in.grp_off, p_in.res_div, p_in.unfused,
+                 p_in.g_sinv, p_in.g_zp);
+  if constexpr (ATT) {
+    MIXDQ_ARGS_NOW(p_in.att_k, p_in.att_v, p_in.att_k_bs, p_in.att_v_bs, p_in.att_k_rs, p_in.att_v_rs,
+                   p_in.att_tkv, p_in.att_tq, p_in.att_scale_log2, p_in.att_out, p_in.att_sinv,
+                   p_in.att_zp);
+  }
   IgemmParams p = p_in;
-  int nwg = gridDim.x;
-  if (p_in.groups != nullptr) {     // one member of a grouped launch (wave-uniform scalar loads)
+  int nwg = p_in.tiles_m * p_in.tiles_n;   // == gridDim.x (which would be one more dependent load)
+  if constexpr (GROUPED) {          // one member of a grouped launch (wave-uniform scalar loads)
     const mixdq_gemm_group g = p_in.groups[blockIdx.y];
     p.Wt = g.W; p.bias0 = g.bias0; p.scale = g.scale; p.bias = (const __half*)g.bias_f16_or_null;
     p.D = (__half*)g.D_f16; p.N = g.N;
@@ -564,7 +576,8 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const Igem
     uint2 bs = make_uint2(0u, 0u);
     if (n < p.N) {
       if constexpr (!F16) {
-        const float* b0src = use_table ? p.table + (int64_t)full_cls * p.N : p.bias0;
+        const float* b0src = p.bias0;
+        if constexpr (CONV) if (use_table) b0src = p.table + (int64_t)full_cls * p.N;
         b0 = *reinterpret_cast<const v4f*>(b0src + n);
         sc = *reinterpret_cast<const v4f*>(p.scale + n);
       }
@@ -810,55 +823,72 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const Igem
   char* Cs = smem;
   const bool unfused = p.unfused != 0;
   const float zpv = use_table ? *p.zp : 0.f;
+  // The accumulator -> fp16 pass is straight-line code per wave: the uniform choices (bias or not,
+  // fused multiply-add or not) are taken ONCE, outside (MODE), the per-channel vectors come from LDS
+  // (zero-filled past N, so there is no column test: a quad past N computes zeros into a part of the
+  // tile that is never stored), and only a padded conv's BORDER pixels read anything from memory.
+  // (Round 2 selected between the LDS row and the border-class row by POINTER: hipcc turned that
+  // into one flat_load per register quad followed by vmcnt(0) -- twenty serial memory round trips,
+  // 4.4 of the 26 us of the (1024, 10240, 1280) launch and ~1 us of every small GEMM; tools/
+  // stamp_report.py.)
+  auto to_tile = [&](auto mode_c) {
+    constexpr int MODE = decltype(mode_c)::value;   // 0: no bias, 1: bias (FMA / FP16 add), 2: bias, mul then add
 #pragma unroll
-  for (int tm = 0; tm < TM; ++tm) {
-    if (KSPLIT > 1 && kg != 0) break;             // group 0 holds the sums
-    const int ml = wm * WTM + tm * MT + lrow;
-    // table mode: border class of this output pixel = its valid tap rectangle [rlo,rhi]x[slo,shi];
-    // interior pixels (the full window) use the row staged in LDS, border pixels read theirs.
-    const float* b0row = nullptr;
-    if (use_table) {
-      int64_t m = m0 + ml;
-      if (m >= p.M) m = 0;
-      const int pq = p.P * p.Q;
-      const int rem = (int)(m % pq);
-      const int pp = rem / p.Q, qq = rem - pp * p.Q;
-      const int hb = pp * p.stride - p.pad, wb = qq * p.stride - p.pad;
-      const int rlo = max(0, -hb), rhi = max(min(p.R - 1, p.H - 1 - hb), 0);
-      const int slo = max(0, -wb), shi = max(min(p.S - 1, p.W - 1 - wb), 0);
-      const int cls = ((min(rlo, p.R - 1) * p.R + rhi) * p.S + min(slo, p.S - 1)) * p.S + shi;
-      if (cls != full_cls) b0row = p.table + (int64_t)cls * p.N;
-    }
+    for (int tm = 0; tm < TM; ++tm) {
+      const int ml = wm * WTM + tm * MT + lrow;
+      // table mode (padded convs only): border class of this output pixel = its valid tap rectangle
+      // [rlo,rhi]x[slo,shi]; interior pixels (the full window) use the row staged in LDS, border
+      // pixels read theirs from the table
+      const __attribute__((address_space(1))) float* b0row = nullptr;
+      if constexpr (CONV) {
+        if (use_table) {
+          int64_t m = m0 + ml;
+          if (m >= p.M) m = 0;
+          const int pq = p.P * p.Q;
+          const int rem = (int)(m % pq);
+          const int pp = rem / p.Q, qq = rem - pp * p.Q;
+          const int hb = pp * p.stride - p.pad, wb = qq * p.stride - p.pad;
+          const int rlo = max(0, -hb), rhi = max(min(p.R - 1, p.H - 1 - hb), 0);
+          const int slo = max(0, -wb), shi = max(min(p.S - 1, p.W - 1 - wb), 0);
+          const int cls = ((min(rlo, p.R - 1) * p.R + rhi) * p.S + min(slo, p.S - 1)) * p.S + shi;
+          if (cls != full_cls)
+            b0row = (const __attribute__((address_space(1))) float*)(p.table + (int64_t)cls * p.N);
+        }
+      }
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
+      for (int tn = 0; tn < TN; ++tn) {
 #pragma unroll
-      for (int g = 0; g < ACC / 4; ++g) {     // register quads: 4 consecutive output channels each
-        const int nl = wn * WTN + tn * MT + (MT == 32 ? 8 * g + 4 * lkq : 4 * lkq);
-        const int n = n0 + nl;
-        if (n < p.N) {   // N % 4 == 0: the quad is all-valid or all-invalid
+        for (int g = 0; g < ACC / 4; ++g) {     // register quads: 4 consecutive output channels each
+          const int nl = wn * WTN + tn * MT + (MT == 32 ? 8 * g + 4 * lkq : 4 * lkq);
           v4f b0 = *reinterpret_cast<const v4f*>(P_B0 + nl);
-          if (b0row != nullptr) b0 = *reinterpret_cast<const v4f*>(b0row + n);
-          if (use_table) b0 = b0 * zpv;                      // f32(sum of taps) * zp, one rounding
+          if constexpr (CONV) {
+            if (b0row != nullptr && n0 + nl < p.N) {         // border pixels only (a real branch)
+              b0 = *reinterpret_cast<const __attribute__((address_space(1))) v4f*>(b0row + n0 + nl);
+              asm volatile("" : "+v"(b0));
+            }
+            if (use_table) b0 = b0 * zpv;                    // f32(sum of taps) * zp, one rounding
+          }
           v4f sc = *reinterpret_cast<const v4f*>(P_SC + nl);
           if constexpr (W4) { b0 = b0 * 16.0f; sc = sc * 0.0625f; }   // exact: the MFMA ran on 16*q
-          const v4h hb4 = *reinterpret_cast<const v4h*>(P_BS + nl);
-          const v4f bs = __builtin_convertvector(hb4, v4f);  // exact
+          v4f bs = {0.f, 0.f, 0.f, 0.f};
+          if constexpr (MODE != 0)
+            bs = __builtin_convertvector(*reinterpret_cast<const v4h*>(P_BS + nl), v4f);   // exact
           uint32_t packed[2];
 #pragma unroll
           for (int e2 = 0; e2 < 2; ++e2) {
-            // two outputs at a time on the packed-FP32 VALU: (f32(acc) - bias0) * scale [+ bias]
+            // two outputs at a time: (f32(acc) - bias0) * scale [+ bias]
             v2f x = {(float)acc[tn][tm][4 * g + 2 * e2], (float)acc[tn][tm][4 * g + 2 * e2 + 1]};
             const v2f b0e = {b0[2 * e2], b0[2 * e2 + 1]};
             const v2f sce = {sc[2 * e2], sc[2 * e2 + 1]};
             const v2f bse = {bs[2 * e2], bs[2 * e2 + 1]};
             v2f r;
             if constexpr (F16) {
-              r = has_bias ? x + bse : x;                    // fp32 accumulator + bias, one rounding
+              r = MODE != 0 ? x + bse : x;                   // fp32 accumulator + bias, one rounding
             } else {
-            x = x - b0e;
-            if (!has_bias) r = x * sce;
-            else if (unfused) r = x * sce + bse;             // -ffp-contract=off: mul, then add
-            else r = __builtin_elementwise_fma(x, sce, bse);
+              x = x - b0e;
+              if constexpr (MODE == 0) r = x * sce;
+              else if constexpr (MODE == 2) r = x * sce + bse;   // -ffp-contract=off: mul, then add
+              else r = __builtin_elementwise_fma(x, sce, bse);
             }
             asm("" : "+v"(r));   // keep the FP32 rounding: no fold into a single-rounding fma_mix
             const v2h h = __builtin_convertvector(r, v2h);    // v_cvt_pk_f16_f32, RNE
@@ -868,6 +898,11 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const Igem
         }
       }
     }
+  };
+  if (KSPLIT == 1 || kg == 0) {                     // group 0 holds the sums
+    if (!has_bias) to_tile(std::integral_constant<int, 0>{});
+    else if (F16 || !unfused) to_tile(std::integral_constant<int, 1>{});
+    else to_tile(std::integral_constant<int, 2>{});
   }
   MIXDQ_STAMP_AT(5);
   __syncthreads();
@@ -1229,7 +1264,7 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const __half* __restrict_
 }
 
 template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool CONV, bool FAST, bool W4, int KSPLIT,
-          int MT, bool F16 = false, bool PHASED = false>
+          int MT, bool F16 = false, bool PHASED = false, bool GROUPED = false>
 int launch_kernel(IgemmParams& p, hipStream_t stream) {
   constexpr int SMEM = igemm_smem_bytes<BM, BN, BK, STAGES>();
   static_assert(SMEM <= 160 * 1024, "LDS is 160 KiB per CU");
@@ -1237,7 +1272,7 @@ int launch_kernel(IgemmParams& p, hipStream_t stream) {
   if constexpr (SMEM > 64 * 1024) {   // opt in to > 64 KiB of dynamic LDS, once per instantiation
     static const hipError_t attr = hipFuncSetAttribute(
         reinterpret_cast<const void*>(
-            &igemm_kernel<BM, BN, BK, STAGES, WM, WN, CONV, FAST, W4, KSPLIT, MT, F16, false, PHASED>),
+            &igemm_kernel<BM, BN, BK, STAGES, WM, WN, CONV, FAST, W4, KSPLIT, MT, F16, false, PHASED, GROUPED>),
         hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
     if (attr != hipSuccess) return MIXDQ_ERR_LAUNCH;
   }
@@ -1245,14 +1280,15 @@ int launch_kernel(IgemmParams& p, hipStream_t stream) {
   p.tiles_n = (p.N + BN - 1) / BN;
   const int64_t grid = (int64_t)p.tiles_m * p.tiles_n;
   if (grid <= 0 || grid > 0x7fffffff) return MIXDQ_ERR_INVALID_ARG;
-  const int ny = p.groups != nullptr ? p.ngroups_launch : 1;
-  igemm_kernel<BM, BN, BK, STAGES, WM, WN, CONV, FAST, W4, KSPLIT, MT, F16, false, PHASED>
+  const int ny = GROUPED ? p.ngroups_launch : 1;
+  if (GROUPED != (p.groups != nullptr)) return MIXDQ_ERR_INVALID_ARG;
+  igemm_kernel<BM, BN, BK, STAGES, WM, WN, CONV, FAST, W4, KSPLIT, MT, F16, false, PHASED, GROUPED>
       <<<dim3((unsigned)grid, (unsigned)ny), 64 * WM * WN * KSPLIT, SMEM, stream>>>(p);
   return launch_status();
 }
 
 template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool CONV, bool W4, int KSPLIT, int MT,
-          bool F16 = false, bool PHASED = false>
+          bool F16 = false, bool PHASED = false, bool GROUPED = false>
 int launch_tile(IgemmParams& p, hipStream_t stream) {
   if constexpr (!CONV) {
     const bool fits32 = (uint64_t)p.M * (uint64_t)p.Ktot < (1ull << 32) &&
@@ -1261,13 +1297,13 @@ int launch_tile(IgemmParams& p, hipStream_t stream) {
       if constexpr (PHASED && !W4 && !F16)
         return launch_kernel<BM, BN, BK, STAGES, WM, WN, false, true, false, KSPLIT, MT, false, true>(p, stream);
       else if constexpr (!PHASED)
-        return launch_kernel<BM, BN, BK, STAGES, WM, WN, false, true, W4, KSPLIT, MT, F16>(p, stream);
+        return launch_kernel<BM, BN, BK, STAGES, WM, WN, false, true, W4, KSPLIT, MT, F16, false, GROUPED>(p, stream);
     }
   }
   if constexpr (PHASED)   // convs, packed weights, K tails: the same tile on the one-phase loop
     return launch_kernel<BM, BN, BK, STAGES, 4, 2, CONV, false, W4, 1, 32, F16>(p, stream);
   else
-    return launch_kernel<BM, BN, BK, STAGES, WM, WN, CONV, false, W4, KSPLIT, MT, F16>(p, stream);
+    return launch_kernel<BM, BN, BK, STAGES, WM, WN, CONV, false, W4, KSPLIT, MT, F16, false, GROUPED>(p, stream);
 }
 
 // Kernel configurations.  id 0 = automatic choice; ids 1.. can be forced through bits 8..15 of
@@ -1459,13 +1495,23 @@ int launch_att(IgemmParams& p, hipStream_t stream) {
   return launch_status();
 }
 
+// The grouped launch is its own instantiation (GROUPED: the member's operands come from the device
+// table, everything else of the argument block stays in scalar registers), built for the tiles a
+// set of small independent problems wants.
+#define MIXDQ_GROUPED_CONFIGS(X)          \
+  X(4, 64, 64, 128, 3, 2, 2, 1, 32)       \
+  X(35, 128, 128, 64, 3, 4, 2, 1, 32)     \
+  X(37, 64, 64, 128, 3, 2, 2, 2, 32)      \
+  X(41, 64, 128, 128, 3, 2, 4, 1, 32)     \
+  X(56, 64, 80, 128, 6, 4, 1, 2, 16)
+
 template <bool W4>
 int dispatch_grouped(IgemmParams& p, int ngroups, hipStream_t stream, int cfg) {
   p.ngroups_launch = ngroups;
   switch (cfg) {
-#define X(ID, BM, BN, BK, ST, WM, WN, KS, MT, PH) \
-  case ID: return launch_tile<BM, BN, BK, ST, WM, WN, false, W4, KS, MT, false, PH>(p, stream);
-    MIXDQ_IGEMM_CONFIGS(X)
+#define X(ID, BM, BN, BK, ST, WM, WN, KS, MT) \
+  case ID: return launch_tile<BM, BN, BK, ST, WM, WN, false, W4, KS, MT, false, false, true>(p, stream);
+    MIXDQ_GROUPED_CONFIGS(X)
 #undef X
     default: return MIXDQ_ERR_INVALID_ARG;
   }
