@@ -130,6 +130,22 @@ constexpr int igemm_smem_bytes() {   // + the per-channel epilogue vectors: bias
   return igemm_main_bytes<BM, BN, BK, STAGES>() + BN * 12;
 }
 
+// Waves per SIMD a tile configuration is meant to run at (second argument of __launch_bounds__): as
+// many workgroups as its LDS lets a CU hold -- the co-resident workgroups are what hides one's epilogue
+// under another's main loop -- unless the accumulators alone would not fit the registers that leaves.
+// Without the bound the register allocator spends whatever makes the (straight-line) epilogue fastest:
+// the 256x128 tile went from 104 to 170 VGPRs and lost its second workgroup per CU (batch 8:
+// GEMM+GEGLU 177 -> 207 us, tools/stamp_report.py + same-box A/B).
+template <int BM, int BN, int BK, int STAGES, int NWAVES, int ACC_REGS>
+constexpr int igemm_waves_per_simd() {
+  int wg = (160 * 1024) / (igemm_main_bytes<BM, BN, BK, STAGES>() + BN * 12);
+  int w = wg * NWAVES / 4;
+  if (w > 8) w = 8;
+  if (w < 1) w = 1;
+  while (w > 1 && ACC_REGS + 48 > 512 / w) --w;
+  return w;
+}
+
 // two packed fp16 + two packed fp16, each lane as torch's half add: f32 add, one rounding
 __device__ __forceinline__ uint32_t add_f16x2(uint32_t a, uint32_t b) {
   const v2h ah = *reinterpret_cast<const v2h*>(&a), bh = *reinterpret_cast<const v2h*>(&b);
@@ -172,7 +188,11 @@ __device__ __forceinline__ uint32_t add_f16x2(uint32_t a, uint32_t b) {
 template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool CONV, bool FAST, bool W4,
           int KSPLIT = 1, int MT = 32, bool F16 = false, bool ATT = false, bool PHASED = false,
           bool GROUPED = false>
-__global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const IgemmParams p_in) {
+__global__ __launch_bounds__(
+    64 * WM * WN * KSPLIT,
+    (ATT ? 2 : igemm_waves_per_simd<BM, BN, BK, STAGES, WM * WN * KSPLIT,
+                                    (BM / WM / MT) * (BN / WN / MT) * (MT == 32 ? 16 : 4)>()))
+void igemm_kernel(const IgemmParams p_in) {
   static_assert(!PHASED || (BM == 256 && BN == 256 && ((BK == 128 && STAGES == 2) || (BK == 64 && STAGES == 4)) &&
                             WM == 2 && WN == 4 && KSPLIT == 1 && MT == 16 && FAST && !CONV && !W4 &&
                             !F16 && !ATT),
@@ -895,6 +915,10 @@ __global__ __launch_bounds__(64 * WM * WN * KSPLIT) void igemm_kernel(const Igem
             packed[e2] = *reinterpret_cast<const uint32_t*>(&h);
           }
           *reinterpret_cast<uint2*>(Cs + ml * CS_STRIDE + nl * 2) = make_uint2(packed[0], packed[1]);
+          // four quads' worth of LDS reads in flight at a time: without the fence the scheduler
+          // hoists every quad's reads to the top and the pass costs ~100 registers (spills, or the
+          // co-resident workgroup)
+          if ((tn * (ACC / 4) + g) % 4 == 3) __builtin_amdgcn_sched_barrier(0);
         }
       }
     }
