@@ -273,6 +273,50 @@ void igemm_kernel(const IgemmParams p_in) {
   const int64_t m0 = (int64_t)tile_m * BM;
   const int n0 = tile_n * BN;
 
+  // ---- residual operand of the epilogue, requested NOW on the small tiles: it comes cold (another
+  //      kernel just wrote it), and read inside the store loop its ~1 us of latency sat at the very
+  //      end of every to_out / ff.net.2 / conv2 launch of the batch-1 chain.  These loads are older
+  //      than every DMA piece, so the counted waits of the main loop cover them.
+  constexpr int RES_ITERS = (BM * (BN / 8) + 64 * WM * WN * KSPLIT - 1) / (64 * WM * WN * KSPLIT);
+  constexpr bool RES_PRE = !ATT && !GROUPED && RES_ITERS <= 2;
+  uint4 res_pre[RES_PRE ? RES_ITERS : 1];
+  const bool res_pre_on = RES_PRE && p.res != nullptr && (p.N & 7) == 0;
+  if constexpr (RES_PRE) {
+    if (res_pre_on) {     // wave-uniform; addresses clamped into the tensor instead of predicated, so
+#pragma unroll            // that no select sits between the load and its use after the main loop
+      for (int it = 0; it < RES_ITERS; ++it) {
+        const int idx = min(tid + it * (64 * WM * WN * KSPLIT), BM * (BN / 8) - 1);
+        const int row = idx / (BN / 8), cc = idx - row * (BN / 8);
+        const int64_t m = min(m0 + row, p.M - 1);
+        const int n = n0 + cc * 8 < p.N ? n0 + cc * 8 : 0;
+        res_pre[it] = *reinterpret_cast<const uint4*>(
+            p.res + (p.res_div == 1 ? m : m / p.res_div) * p.N + n);
+      }
+    }
+  }
+  // ---- this thread's slice of the per-channel epilogue vectors (threads < BN / 4), requested now
+  //      too and parked in registers: they go to LDS behind the main loop.  (Stored to LDS right
+  //      here, as round 2 did, the store's vmcnt(0) made the first waves wait for EVERY prologue
+  //      stage -- five K-tiles on the six-stage tile -- before the first K-tile could be computed.)
+  //      P_B0: bias0[n] (table mode: the full-window class row), P_SC: scale[n], P_BS: bias[n].
+  const bool has_bias = p.bias != nullptr;
+  const bool use_table = p.table != nullptr;
+  const int full_cls = (((p.R - 1)) * p.S) * p.S + (p.S - 1);   // rlo=0, rhi=R-1, slo=0, shi=S-1
+  v4f pre_b0, pre_sc;
+  uint2 pre_bs;
+  const bool pre_on = tid < BN / 4;
+  const bool pre_in = n0 + tid * 4 < p.N;
+  if (pre_on) {
+    const int n = pre_in ? n0 + tid * 4 : 0;
+    if constexpr (!F16) {
+      const float* b0src = p.bias0;
+      if constexpr (CONV) if (use_table) b0src = p.table + (int64_t)full_cls * p.N;
+      pre_b0 = *reinterpret_cast<const v4f*>(b0src + n);
+      pre_sc = *reinterpret_cast<const v4f*>(p.scale + n);
+    }
+    if (has_bias) pre_bs = *reinterpret_cast<const uint2*>(p.bias + n);
+  }
+
   const char* zero = reinterpret_cast<const char*>(&g_zero16);
   const int Ktot = p.Ktot;
 
@@ -580,33 +624,10 @@ void igemm_kernel(const IgemmParams p_in) {
   }
 
   MIXDQ_STAMP_AT(1);
-  // ---- per-channel epilogue vectors -> LDS, issued now so their latency hides under the main
-  //      loop (read back ~100 cycles away instead of ~1 us away per quad at the end).
-  //      P_B0: bias0[n] (table mode: the full-window class row), P_SC: scale[n], P_BS: bias[n].
   constexpr int PARAM_OFF = igemm_main_bytes<BM, BN, BK, STAGES>();
   float* P_B0 = reinterpret_cast<float*>(smem + PARAM_OFF);
   float* P_SC = P_B0 + BN;
   __half* P_BS = reinterpret_cast<__half*>(P_SC + BN);
-  const bool has_bias = p.bias != nullptr;
-  const bool use_table = p.table != nullptr;
-  const int full_cls = (((p.R - 1)) * p.S) * p.S + (p.S - 1);   // rlo=0, rhi=R-1, slo=0, shi=S-1
-  if (tid < BN / 4) {
-    const int n = n0 + tid * 4;
-    v4f b0 = {0.f, 0.f, 0.f, 0.f}, sc = {0.f, 0.f, 0.f, 0.f};
-    uint2 bs = make_uint2(0u, 0u);
-    if (n < p.N) {
-      if constexpr (!F16) {
-        const float* b0src = p.bias0;
-        if constexpr (CONV) if (use_table) b0src = p.table + (int64_t)full_cls * p.N;
-        b0 = *reinterpret_cast<const v4f*>(b0src + n);
-        sc = *reinterpret_cast<const v4f*>(p.scale + n);
-      }
-      if (has_bias) bs = *reinterpret_cast<const uint2*>(p.bias + n);
-    }
-    *reinterpret_cast<v4f*>(P_B0 + tid * 4) = b0;
-    *reinterpret_cast<v4f*>(P_SC + tid * 4) = sc;
-    *reinterpret_cast<uint2*>(P_BS + tid * 4) = bs;
-  }
 
   if constexpr (PHASED && BK == 64) {
     const int a_lane = (wm * WTM + lrow) * BK + ((lkq ^ swz<BK>(lrow)) << 4);
@@ -806,6 +827,17 @@ void igemm_kernel(const IgemmParams p_in) {
   // the zero-page DMAs staged for tiles >= nk are still in flight: drain before LDS is reused
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   MIXDQ_STAMP_AT(3);
+  if (pre_on) {      // the epilogue vectors -> LDS (their own region: no one reads it before the barrier)
+    v4f b0 = {0.f, 0.f, 0.f, 0.f}, sc = {0.f, 0.f, 0.f, 0.f};
+    uint2 bs = make_uint2(0u, 0u);
+    if (pre_in) {
+      if constexpr (!F16) { b0 = pre_b0; sc = pre_sc; }
+      if (has_bias) bs = pre_bs;
+    }
+    *reinterpret_cast<v4f*>(P_B0 + tid * 4) = b0;
+    *reinterpret_cast<v4f*>(P_SC + tid * 4) = sc;
+    *reinterpret_cast<uint2*>(P_BS + tid * 4) = bs;
+  }
 
   // ---- epilogue: registers -> f16 tile in LDS -> whole-row 16-byte stores --------------------
   __syncthreads();   // every wave is done reading the stage buffers
@@ -1118,11 +1150,14 @@ void igemm_kernel(const IgemmParams p_in) {
   const bool identity_rows = p.grp_rows <= 0;
   const bool res_full = p.res != nullptr && p.res_div == 1;
   // thread -> (row, chunk): chunk-fastest, so the lanes of a wave write whole output rows
-  for (int idx = tid; idx < BM * CPRO; idx += NTHREADS) {
+  constexpr int ST_ITERS = (BM * CPRO + NTHREADS - 1) / NTHREADS;
+  static_assert(ST_ITERS == RES_ITERS, "the residual was requested with this loop's mapping");
+  auto store_chunk = [&](auto it_c, int idx) {
+    constexpr int it = decltype(it_c)::value;     // compile-time slot of the requested residual
     const int row = idx / CPRO, cc = idx - row * CPRO;
     const int n = n0 + cc * 8;
     const int64_t m = m0 + row;
-    if (m >= p.M || n >= p.N) continue;
+    if (m >= p.M || n >= p.N) return;
     int64_t drow = m;
     if (!identity_rows) {
       const int64_t gq = m / p.grp_rows;
@@ -1134,7 +1169,9 @@ void igemm_kernel(const IgemmParams p_in) {
       const __half* rp = p.res + rrow * p.N + n;
       uint32_t rw[4];
       if (n8) {
-        const uint4 r = *reinterpret_cast<const uint4*>(rp);
+        uint4 r;
+        if constexpr (RES_PRE) r = res_pre[it];     // requested before the main loop
+        else r = *reinterpret_cast<const uint4*>(rp);
         rw[0] = r.x; rw[1] = r.y; rw[2] = r.z; rw[3] = r.w;
       } else {
         const uint2 r0 = *reinterpret_cast<const uint2*>(rp);
@@ -1164,6 +1201,14 @@ void igemm_kernel(const IgemmParams p_in) {
       *reinterpret_cast<uint2*>(dst) = make_uint2(v.x, v.y);
       if (n + 8 <= p.N) *reinterpret_cast<uint2*>(dst + 4) = make_uint2(v.z, v.w);
     }
+  };
+  if constexpr (RES_PRE) {
+    static_assert(ST_ITERS <= 2, "one compile-time slot per requested residual chunk");
+    if (tid < BM * CPRO) store_chunk(std::integral_constant<int, 0>{}, tid);
+    if constexpr (ST_ITERS == 2)
+      if (tid + NTHREADS < BM * CPRO) store_chunk(std::integral_constant<int, 1>{}, tid + NTHREADS);
+  } else {
+    for (int idx = tid; idx < BM * CPRO; idx += NTHREADS) store_chunk(std::integral_constant<int, 0>{}, idx);
   }
   MIXDQ_STAMP_AT(7);
 }
