@@ -184,6 +184,9 @@ def roofline_sweep(run_eager, device, reps):
             cid = C.igemm_select_id(M, N, k_align, K, w4=w4, geglu=kind == "linear_geglu")
         bm, bn, bk, st = C.IGEMM_CONFIGS.get(cid, (0, 0, 0, 0))
         kname = f"igemm_kernel<{bm},{bn},{bk},{st},{kind}{',w4' if w4 else ''}>#cfg{cid}"
+        if kind.startswith("conv_halo"):        # 3x3 conv with the input halo resident in LDS
+            th, tw, bn = C.HALO_TILES[int(kind[9:])]
+            kname = f"conv3x3_halo_kernel<{th},{tw},{bn}>"
         g_ = groups.setdefault(kname, dict(fns=[], ops=0.0, bytes=0.0))
         g_["fns"].append(replay)
         g_["ops"] += 2.0 * M * N * K

@@ -347,6 +347,12 @@ int mixdq_igemm_select_id_w4(int64_t M, int N, int k_align, int k_total);
  * 64-column value / gate groups and which does not take the 256x256 four-phase loop. */
 int mixdq_igemm_select_id_geglu(int64_t M, int N, int k_total, int w4);
 
+/* Tile id of the LDS-resident-halo kernel (csrc/iconv.hip) that mixdq_qconv2d_w8a8[_table] runs this
+ * INT8 conv on when no tile is forced -- 90: 8 x 16 output pixels x 80 channels per workgroup, 91:
+ * 8 x 8 x 80 -- or 0 when the implicit-GEMM family runs it (not 3x3 / stride 1 / pad 1, C % 64 != 0,
+ * H or W % 8 != 0, packed-W4 weights).  Ids 90 / 91 can be forced through bits 8..15 of `flags`. */
+int mixdq_conv_halo_select(int N, int H, int W, int C, int K, int R, int S, int stride, int pad);
+
 #ifdef __cplusplus
 }
 #endif

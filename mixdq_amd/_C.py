@@ -411,6 +411,17 @@ def qlinear_geglu(input_int8, weight_int8, scale, bias0, bias, out_scale_inv, ou
     return out
 
 
+_lib.mixdq_conv_halo_select.argtypes = [_i32] * 9
+_lib.mixdq_conv_halo_select.restype = _i32
+HALO_TILES = {90: (8, 16, 80), 91: (8, 8, 80)}   # csrc/iconv.hip: output pixels (rows, columns), channels
+
+
+def conv_halo_select(N, H, W, C, K, R, S, stride, padding) -> int:
+    """Tile id (HALO_TILES key) of the LDS-resident-halo kernel an unforced INT8 conv of this shape
+    runs on, or 0 (the implicit-GEMM family)."""
+    return int(_lib.mixdq_conv_halo_select(N, H, W, C, K, R, S, stride, padding))
+
+
 def _conv_geometry(input_int8, weight_int8, stride, padding, dilation):
     N, C, H, W = input_int8.shape
     K, _, R, S = weight_int8.shape
@@ -478,7 +489,11 @@ def qconv2d_w8_a8_ohalf(input_int8, weight_int8, weight_scale, input_scale, inpu
                     memory_format=torch.channels_last)
     sc = _f32vec(scale)
     bs = None if bias is None else bias.contiguous()
-    _record("conv", N * P * Q, K, R * S * C, C, _w4, qconv2d_w8_a8_ohalf,
+    kind = "conv"
+    if RECORD is not None and _cfg in (0, 90, 91) and not _w4 and dilation == 1:
+        tile = _cfg or conv_halo_select(N, H, W, C, K, R, S, stride, padding)
+        kind = f"conv_halo{tile}" if tile else "conv"
+    _record(kind, N * P * Q, K, R * S * C, C, _w4, qconv2d_w8_a8_ohalf,
             (input_int8, weight_int8, weight_scale, input_scale, input_zero_point, scale,
              weight_sum_by_input_channels, bias0, bias, stride, padding, dilation),
             dict(_table=_table, _cfg=_cfg, _residual=_residual,

@@ -11,8 +11,8 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libmixdq_hip.so")
-SOURCES = ["quantize.hip", "igemm.hip", "fused_norm.hip", "attention.hip"]
-HEADERS = ["common.h", "attn_core.h", os.path.join("..", "..", "include", "mixdq_hip.h"),
+SOURCES = ["quantize.hip", "igemm.hip", "iconv.hip", "fused_norm.hip", "attention.hip"]
+HEADERS = ["common.h", "attn_core.h", "iconv.h", os.path.join("..", "..", "include", "mixdq_hip.h"),
            os.path.join("..", "..", "include", "mixdq_math.h")]
 # -ffp-contract=off: every fused multiply-add in the arithmetic specification is written
 # explicitly (__builtin_fmaf); the compiler must not introduce others.

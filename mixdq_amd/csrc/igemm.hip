@@ -28,6 +28,7 @@
 
 #include "common.h"
 #include "attn_core.h"
+#include "iconv.h"
 #include "../../include/mixdq_math.h"
 
 // MIXDQ_ABLATE (diagnostic builds only, tools/ablate.sh): 1 = no MFMA, 2 = no LDS fragment reads,
@@ -1833,6 +1834,34 @@ extern "C" int mixdq_qconv2d_w8a8_table(const int8_t* X, const int8_t* Wt, const
   const int P = (H + 2 * pad - (R - 1) - 1) / stride + 1;
   const int Q = (W + 2 * pad - (S - 1) - 1) / stride + 1;
   if (P <= 0 || Q <= 0 || N == 0) return MIXDQ_OK;
+  // 3x3 / stride 1 / pad 1 with the input halo resident in LDS (csrc/iconv.hip): the automatic choice
+  // wherever it applies; tile ids 90 / 91 force it, any other forced id keeps the implicit-GEMM family
+  // (MIXDQ_HALO_CONV=0: off, for A/B runs)
+  {
+    static const bool halo_on = [] { const char* e = getenv("MIXDQ_HALO_CONV"); return !(e && e[0] == '0'); }();
+    const int forced = (flags >> 8) & 0xff;
+    const bool aligned = !(((uintptr_t)X | (uintptr_t)Wt | (uintptr_t)scale | (uintptr_t)table_or_null |
+                            (uintptr_t)D | (uintptr_t)residual_f16_or_null) & 15) &&
+                         !((uintptr_t)bias_f16_or_null & 7);
+    int tile = 0;
+    if (!(flags & MIXDQ_FLAG_W4) && aligned && (forced == 90 || forced == 91 || (forced == 0 && halo_on)))
+      tile = halo_conv_select(N, H, W, C, K, R, S, stride, pad);
+    if (forced == 90 || forced == 91) {
+      if (tile == 0 || (forced == 90 && W % 16 != 0)) return MIXDQ_ERR_SHAPE;
+      tile = forced;
+    }
+    if (tile != 0) {
+      HaloConvArgs a{};
+      a.X = X; a.Wt = Wt; a.scale = scale; a.bias = (const __half*)bias_f16_or_null;
+      a.table = table_or_null; a.zp = zero_point; a.D = (__half*)D;
+      a.res = (const __half*)residual_f16_or_null;
+      a.res_div = residual_row_div > 0 ? residual_row_div : 1;
+      if (a.res && a.res_div != 1 && a.res_div != (int64_t)H * W) return MIXDQ_ERR_INVALID_ARG;
+      a.NI = N; a.H = H; a.W = W; a.C = C; a.K = K;
+      a.unfused = (flags & MIXDQ_FLAG_UNFUSED) ? 1 : 0;
+      return halo_conv_launch(a, tile, (hipStream_t)stream);
+    }
+  }
   IgemmParams p{};
   p.A = X; p.Wt = Wt; p.scale = scale; p.bias = (const __half*)bias_f16_or_null;
   p.bias0 = pad > 0 ? nullptr : bias0_or_null;
@@ -1978,6 +2007,13 @@ extern "C" int mixdq_igemm_select_id(int64_t M, int N, int k_align, int k_total)
   if (M <= 0 || N <= 0 || k_align % 4 != 0 || N % 4 != 0) return -1;
   if (k_align % 16 != 0) return 0;   // generic kernel
   return select_cfg(M, N, k_total, false, linear_fast(M, N, k_align, k_total));
+}
+
+extern "C" int mixdq_conv_halo_select(int N, int H, int W, int C, int K, int R, int S, int stride,
+                                      int pad) {
+  const char* e = getenv("MIXDQ_HALO_CONV");
+  if (e && e[0] == '0') return 0;
+  return halo_conv_select(N, H, W, C, K, R, S, stride, pad);
 }
 
 extern "C" int mixdq_igemm_select_id_w4(int64_t M, int N, int k_align, int k_total) {

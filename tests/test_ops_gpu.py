@@ -453,6 +453,64 @@ def test_qconv2d_residual_epilogue(C, oracle):
                        plain + per_img[:, :, None, None])
 
 
+HALO_CASES = [  # n, h, w, c, k, bias, residual ("", "full", "image"), forced tile (0 = automatic)
+    (2, 16, 16, 320, 320, True, "", 0),          # = conv_res_320's shape: C = 2.5 chunks, automatic
+    (1, 16, 32, 128, 80, True, "full", 90),      # 8 x 16 patches, one whole chunk, conv2's residual
+    (1, 16, 16, 64, 72, False, "", 91),          # half a chunk, N tail (72 < 80), 8 x 8 patches
+    (2, 8, 16, 192, 168, True, "image", 90),     # 1.5 chunks, N tail in the third tile, temb add
+    (1, 8, 8, 448, 84, True, "full", 91),        # a single patch: every pixel a border class; N % 8 == 4
+    (1, 24, 48, 256, 160, False, "full", 0),     # several patches per row / column, two chunks
+    (3, 32, 32, 640, 96, True, "image", 0),      # batch 3, five chunks
+]
+
+
+@pytest.mark.parametrize("case", HALO_CASES, ids=[f"n{c[0]}_{c[1]}x{c[2]}_c{c[3]}_k{c[4]}_{c[6] or 'plain'}_t{c[7]}"
+                                                  for c in HALO_CASES])
+def test_qconv2d_halo_kernel_bit_exact(C, oracle, case):
+    """csrc/iconv.hip (3x3 / stride 1 / pad 1 with the input halo resident in LDS): the oracle's bits,
+    and the implicit-GEMM family's, for partial channel chunks, N tails, patches that are all
+    border, both residual forms and both patch shapes."""
+    n, h, w_, c, k, has_bias, res_kind, tile = case
+    x = dd.int8(901, (n, h, w_, c))
+    wt = dd.int8(902, (k, 3, 3, c))
+    scale = dd.f32(903, (k,), 1e-4, 6e-4)
+    in_zp = -11.0
+    bias = dd.f16(904, (k,), -1, 1) if has_bias else None
+    wsum = wt.astype(np.float32).sum(axis=3, dtype=np.float32)
+    assert C.conv_halo_select(n, h, w_, c, k, 3, 3, 1, 1) in (90, 91)
+    args = (t(x).permute(0, 3, 1, 2), t(wt).permute(0, 3, 1, 2), t(scale), scal(1.0), scal(in_zp),
+            t(scale), t(wsum.reshape(k, 1, 3, 3)), None, None if bias is None else t(bias), 1, 1)
+    kw = {}
+    add = None
+    if res_kind == "full":
+        r = t(dd.normal_f16(905, (n, h, w_, k), 2.0)).permute(0, 3, 1, 2)
+        kw, add = dict(_residual=r), r
+    elif res_kind == "image":
+        r = t(dd.normal_f16(906, (n, k), 2.0))
+        kw, add = dict(_residual=r, _residual_per_image=True), r[:, :, None, None]
+    got = C.qconv2d_w8_a8_ohalf(*args, _cfg=tile, **kw)
+    want = torch.from_numpy(oracle.qconv2d(x, wt, scale, wsum, in_zp, None, bias, 1, 1, C.FLAGS & 1)
+                            ).to(DEV).permute(0, 3, 1, 2)
+    if add is not None:
+        want = want + add                     # the epilogue add == a following torch half add
+    assert torch.equal(got, want), f"halo kernel != oracle: {int((got != want).sum())} elements"
+    assert torch.equal(got, C.qconv2d_w8_a8_ohalf(*args, _cfg=4, **kw)), "halo != implicit GEMM"
+
+
+def test_qconv2d_halo_kernel_range(C):
+    """Outside its range the automatic choice is the implicit-GEMM family, and forcing it fails."""
+    assert C.conv_halo_select(1, 12, 12, 960, 640, 3, 3, 1, 1) == 0      # H % 8 != 0
+    assert C.conv_halo_select(1, 16, 16, 320, 320, 3, 3, 2, 1) == 0      # stride 2
+    assert C.conv_halo_select(1, 16, 16, 320, 320, 1, 1, 1, 0) == 0      # 1x1
+    assert C.conv_halo_select(1, 16, 16, 48, 320, 3, 3, 1, 1) == 0       # C % 64 != 0
+    x = t(dd.int8(911, (1, 12, 12, 64))).permute(0, 3, 1, 2)
+    w = t(dd.int8(912, (16, 3, 3, 64))).permute(0, 3, 1, 2)
+    v = torch.ones(16, device=DEV)
+    ws = torch.ones(16, 1, 3, 3, device=DEV)
+    with pytest.raises(RuntimeError, match="shape outside"):
+        C.qconv2d_w8_a8_ohalf(x, w, v, scal(1), scal(0), v, ws, None, None, 1, 1, _cfg=90)
+
+
 @pytest.mark.parametrize("cfg", sorted(__import__("mixdq_amd._C", fromlist=["x"]).IGEMM_CONFIGS)
                          if torch.cuda.is_available() else [])
 def test_every_kernel_configuration_is_bit_exact(C, oracle, cfg):

@@ -31,6 +31,8 @@ def main():
     ap.add_argument("--res", action="store_true")
     ap.add_argument("--cfg", type=int, default=0)
     ap.add_argument("--cold", action="store_true", help="stream 512 MB between launches")
+    ap.add_argument("--conv", type=int, default=0, metavar="HW",
+                    help="3x3 pad-1 conv on an HW x HW image instead: M = batch rows (images), K = Cin, N = Cout")
     a = ap.parse_args()
     lib = C._lib
     assert hasattr(lib, "mixdq_debug_stamps"), "not a stamped build (tools/stamp_build.sh)"
@@ -45,8 +47,18 @@ def main():
     grid_max = 1 << 16
     stamps = torch.zeros((grid_max, 16, 16), dtype=torch.int64, device=DEV)
 
+    if a.conv:
+        xc = torch.randint(-128, 128, (a.M, a.conv, a.conv, a.K), generator=g, dtype=torch.int8).to(DEV).permute(0, 3, 1, 2)
+        wc = torch.randint(-128, 128, (a.N, 3, 3, a.K), generator=g, dtype=torch.int8).to(DEV).permute(0, 3, 1, 2)
+        wsum = wc.float().sum(dim=1, keepdim=True)
+        table = C.conv_border_table(wsum)
+        resc = torch.randn(a.M, a.conv, a.conv, a.N, generator=g).half().to(DEV).permute(0, 3, 1, 2) if a.res else None
+
     def launch():
-        if a.geglu:
+        if a.conv:
+            C.qconv2d_w8_a8_ohalf(xc, wc, sc, z, one, sc, wsum, None, None, 1, 1, 1, _table=table,
+                                  _cfg=a.cfg, _residual=resc)
+        elif a.geglu:
             C.qlinear_geglu(x, w, sc, sc, None, one, z, _cfg=a.cfg)
         else:
             C.qlinear_w8_a8_ohalf(x, w, sc, z, z, sc, sc, sc, None, _cfg=a.cfg, _residual=res)
