@@ -349,9 +349,14 @@ int mixdq_igemm_select_id_geglu(int64_t M, int N, int k_total, int w4);
 
 /* Tile id of the LDS-resident-halo kernel (csrc/iconv.hip) that mixdq_qconv2d_w8a8[_table] runs this
  * INT8 conv on when no tile is forced -- 90: 8 x 16 output pixels x 80 channels per workgroup, 91:
- * 8 x 8 x 80 -- or 0 when the implicit-GEMM family runs it (not 3x3 / stride 1 / pad 1, C % 64 != 0,
- * H or W % 8 != 0, packed-W4 weights).  Ids 90 / 91 can be forced through bits 8..15 of `flags`. */
+ * 8 x 8 x 80, 92: 16 x 16 x 80 (64-byte channel chunks) -- or 0 when the implicit-GEMM family runs it (not 3x3 / stride 1 / pad 1, C % 64 != 0,
+ * H or W % 8 != 0, packed-W4 weights).  Ids 90 .. 92 can be forced through bits 8..15 of `flags`. */
 int mixdq_conv_halo_select(int N, int H, int W, int C, int K, int R, int S, int stride, int pad);
+
+/* Introspection (tests): the table the GEMM + GEGLU epilogue of the large tiles looks GELU up in --
+ * 2 x 0x4800 uint16: f16 bits of gelu(g) for the FP16 gate g with bits (sign << 15) | magnitude,
+ * magnitude < 0x4800 (|g| < 8), positive half first -- copied to `out_device` (73 728 bytes). */
+int mixdq_gelu_table(uint16_t* out_device, mixdq_stream_t stream);
 
 #ifdef __cplusplus
 }

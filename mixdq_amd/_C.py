@@ -377,6 +377,17 @@ _lib.mixdq_qlinear_w8a8_geglu.argtypes = [_vp] * 6 + [_i64, _i32, _i32, _vp, _vp
 _lib.mixdq_qlinear_w8a8_geglu.restype = _i32
 
 
+def gelu_table(device="cuda") -> torch.Tensor:
+    """The table the GEMM + GEGLU epilogue of the large tiles looks GELU up in (mixdq_gelu_table):
+    int16 [2, 0x4800] -- row 0: gates +0 .. +8, row 1: -0 .. -8 -- of f16 bit patterns."""
+    _lib.mixdq_gelu_table.argtypes = [_vp, _vp]
+    _lib.mixdq_gelu_table.restype = _i32
+    out = torch.empty((2, 0x4800), dtype=torch.int16, device=device)
+    with torch.cuda.device(out.device):
+        _status(_lib.mixdq_gelu_table(out.data_ptr(), _stream()), "gelu_table")
+    return out
+
+
 def geglu_row_order(D: int, device=None) -> torch.Tensor:
     """Row order of mixdq_qlinear_w8a8_geglu's weight: value/gate groups of 32.  perm[i] = the row
     of the ordinary [2D, K] GEGLU projection (values 0..D-1, gates D..2D-1) stored at row i."""
@@ -411,14 +422,17 @@ def qlinear_geglu(input_int8, weight_int8, scale, bias0, bias, out_scale_inv, ou
     return out
 
 
-_lib.mixdq_conv_halo_select.argtypes = [_i32] * 9
-_lib.mixdq_conv_halo_select.restype = _i32
-HALO_TILES = {90: (8, 16, 80), 91: (8, 8, 80)}   # csrc/iconv.hip: output pixels (rows, columns), channels
+if hasattr(_lib, "mixdq_conv_halo_select"):      # (absent in older builds used for A/B runs)
+    _lib.mixdq_conv_halo_select.argtypes = [_i32] * 9
+    _lib.mixdq_conv_halo_select.restype = _i32
+HALO_TILES = {90: (8, 16, 80), 91: (8, 8, 80), 92: (16, 16, 80)}   # csrc/iconv.hip: output pixels (rows, columns), channels
 
 
 def conv_halo_select(N, H, W, C, K, R, S, stride, padding) -> int:
     """Tile id (HALO_TILES key) of the LDS-resident-halo kernel an unforced INT8 conv of this shape
     runs on, or 0 (the implicit-GEMM family)."""
+    if not hasattr(_lib, "mixdq_conv_halo_select"):
+        return 0
     return int(_lib.mixdq_conv_halo_select(N, H, W, C, K, R, S, stride, padding))
 
 
@@ -490,7 +504,7 @@ def qconv2d_w8_a8_ohalf(input_int8, weight_int8, weight_scale, input_scale, inpu
     sc = _f32vec(scale)
     bs = None if bias is None else bias.contiguous()
     kind = "conv"
-    if RECORD is not None and _cfg in (0, 90, 91) and not _w4 and dilation == 1:
+    if RECORD is not None and _cfg in (0, 90, 91, 92) and not _w4 and dilation == 1:
         tile = _cfg or conv_halo_select(N, H, W, C, K, R, S, stride, padding)
         kind = f"conv_halo{tile}" if tile else "conv"
     _record(kind, N * P * Q, K, R * S * C, C, _w4, qconv2d_w8_a8_ohalf,

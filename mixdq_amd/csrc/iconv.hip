@@ -10,7 +10,8 @@
 // stages the (TH + 2) x (TW + 2) input halo ONCE (22.5 KB for 8 x 16 pixels) and streams only the
 // weights, one filter row (3 taps x BN channels) per step; the nine taps read the same halo at
 // lane-uniform pixel shifts.  Bytes per chunk: 22.5 + 9 x 10 = 113 KB against 9 x 26 = 234 KB
-// (128 x 80 tile).  K order becomes (channel chunk, r, s) instead of (r, s, channel): exact either way.
+// (128 x 80 tile); with 16 x 16 pixels per workgroup (large batches) 65 KB per 128 x 80 outputs.
+// K order becomes (channel chunk, r, s) instead of (r, s, channel): exact either way.
 //
 //   LDS: three weight stages (one filter row each; ring: row r always lives in stage r) + two halo
 //        buffers (chunk parity), images [rows][128 B] with the 16-byte chunk XOR-swizzled by
@@ -42,13 +43,16 @@ __device__ __forceinline__ uint32_t add_f16x2_(uint32_t a, uint32_t b) {
   return *reinterpret_cast<const uint32_t*>(&h);
 }
 
-template <int TH, int TW, int BN>
+// CK: bytes of a channel chunk (a row of the LDS images): 128 with two k-split wave groups (each takes
+// one 64-byte MFMA k-step of a chunk; 4 waves x BM / 4 pixels), or 64 with eight waves x BM / 8 pixels.
+template <int TH, int TW, int BN, int CK>
 struct HaloGeom {
   static constexpr int BM = TH * TW;                                  // output pixels per workgroup
   static constexpr int HWP = TW + 2, HP = (TH + 2) * HWP;             // halo row length, halo pixels
-  static constexpr int CK = 128;                                      // channel chunk (bytes)
-  static constexpr int NWAVES = 8, NTHREADS = 512;
-  static constexpr int H_NI = ((HP + 7) / 8 + NWAVES - 1) / NWAVES;   // 1-KiB pieces (8 pixels) per wave
+  static constexpr int KSPLIT = CK / 64;                              // k-split wave groups
+  static constexpr int NWAVES = 8, NTHREADS = 512, WPX = NWAVES / KSPLIT;   // waves over the pixels
+  static constexpr int PPP = 1024 / CK, LPP = CK / 16;                // pixels per 1-KiB DMA piece; lanes per pixel
+  static constexpr int H_NI = ((HP + PPP - 1) / PPP + NWAVES - 1) / NWAVES;   // halo pieces per wave
   static constexpr int HALO_BYTES = H_NI * NWAVES * 1024;
   static constexpr int W_TAP = BN * CK, W_STAGE = 3 * W_TAP;          // one tap tile; one filter row
   static constexpr int W_PIECES = W_STAGE / 1024;
@@ -56,26 +60,29 @@ struct HaloGeom {
   static constexpr int HALO_OFF = 3 * W_STAGE;
   static constexpr int MAIN_BYTES = HALO_OFF + 2 * HALO_BYTES;
   static constexpr int CS_STRIDE = BN * 2 + 16;                       // epilogue tile row stride
-  static constexpr int WTM = BM / 4, TM = WTM / 16, TN = BN / 16;     // wave tile: WTM pixels x BN channels
-  static constexpr int PART_BYTES = 4 * TM * TN * 4 * 64 * 4;         // k-split partials of group 1
+  static constexpr int WTM = BM / WPX, TM = WTM / 16, TN = BN / 16;   // wave tile: WTM pixels x BN channels
+  static constexpr int PART_BYTES = (KSPLIT - 1) * WPX * TM * TN * 4 * 64 * 4;   // k-split partials
   static constexpr int SMEM = MAIN_BYTES + 9 * BN * 4 + BN * 6;       // + 9 border-class rows, scale, bias
+  static_assert(CK == 64 || CK == 128, "one or two 64-byte MFMA k-steps per chunk");
   static_assert(W_TAP % 1024 == 0 && BN % 16 == 0 && WTM % 16 == 0, "whole DMA pieces / MFMA tiles");
   static_assert(BM * CS_STRIDE + PART_BYTES <= MAIN_BYTES, "epilogue staging overlays the main buffers");
   static_assert(SMEM <= 160 * 1024, "LDS is 160 KiB per CU");
   static_assert(H_NI + 2 * W_NI <= 63, "vmcnt is a 6-bit counter");
+  // 16-byte chunk swizzle of an image row (256-byte LDS bank rows hold 2 or 4 image rows)
+  __device__ static int swz(int row) { return CK == 128 ? (row >> 1) & 7 : (row >> 2) & 3; }
 };
 
-template <int TH, int TW, int BN>
+template <int TH, int TW, int BN, int CK>
 __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloConvArgs p) {
-  using G = HaloGeom<TH, TW, BN>;
-  constexpr int BM = G::BM, HWP = G::HWP, HP = G::HP, CK = G::CK, TM = G::TM, TN = G::TN;
+  using G = HaloGeom<TH, TW, BN, CK>;
+  constexpr int BM = G::BM, HWP = G::HWP, HP = G::HP, TM = G::TM, TN = G::TN;
   constexpr int CS_STRIDE = G::CS_STRIDE;
   MIXDQ_ARGS_NOW(p.X, p.Wt, p.scale, p.bias, p.table, p.zp, p.D, p.res, p.res_div, p.NI, p.H, p.W, p.C,
                  p.K, p.unfused);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kg = wid >> 2, wm = wid & 3;
+  const int kg = wid / G::WPX, wm = wid % G::WPX;     // k-split group (0 when CK == 64), pixel group
   const int lrow = lane & 15, lkq = lane >> 4;
 
   // ---- XCD-aware tile map (as igemm.hip): every XCD gets a contiguous run of the tile sequence,
@@ -125,31 +132,31 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloConvArgs
   }
 
   // ---- per-lane DMA state ---------------------------------------------------------------------
-  // halo piece j of this wave = piece wid + 8 j: 8 halo pixels x 128 B; lane -> (pixel, 16-B slot);
-  // the slot holds source chunk slot ^ swz(pixel)
+  // halo piece j of this wave = piece wid + 8 j: PPP halo pixels x CK bytes; lane -> (pixel, 16-B
+  // slot); the slot holds source chunk slot ^ swz(pixel)
   uint32_t h_off[G::H_NI];
   int h_c16[G::H_NI];
   bool h_ok[G::H_NI];
 #pragma unroll
   for (int j = 0; j < G::H_NI; ++j) {
-    const int h = (wid + 8 * j) * 8 + (lane >> 3);
+    const int h = (wid + 8 * j) * G::PPP + lane / G::LPP;
     const int hy = h / HWP, hx = h - hy * HWP;
     const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
-    const int c16 = ((lane & 7) ^ ((h >> 1) & 7)) << 4;
+    const int c16 = ((lane % G::LPP) ^ G::swz(h)) << 4;
     h_ok[j] = h < HP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
     h_off[j] = h_ok[j] ? (uint32_t)(iy * p.W + ix) * (uint32_t)C + c16 : 0u;
     h_c16[j] = c16;
   }
-  // weight piece j of this wave = piece wid + 8 j of a filter row's stage: tap s = piece / (BN / 8),
-  // 8 output channels x 128 B
+  // weight piece j of this wave = piece wid + 8 j of a filter row's stage: tap s = piece / (pieces
+  // per tap tile), PPP output channels x CK bytes
   uint32_t w_off[G::W_NI];
   int w_c16[G::W_NI];
   bool w_ok[G::W_NI];
 #pragma unroll
   for (int j = 0; j < G::W_NI; ++j) {
     const int q = wid + 8 * j;
-    const int s = q / (BN / 8), row = (q - s * (BN / 8)) * 8 + (lane >> 3);
-    const int c16 = ((lane & 7) ^ ((row >> 1) & 7)) << 4;
+    const int s = q / (BN / G::PPP), row = (q - s * (BN / G::PPP)) * G::PPP + lane / G::LPP;
+    const int c16 = ((lane % G::LPP) ^ G::swz(row)) << 4;
     w_ok[j] = q < G::W_PIECES && n0 + row < p.K;
     w_off[j] = w_ok[j] ? (uint32_t)(n0 + row) * (uint32_t)(9 * C) + (uint32_t)(s * C) + c16 : 0u;
     w_c16[j] = c16;
@@ -200,14 +207,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloConvArgs
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       const int h = hb + (tap / 3) * HWP + (tap % 3);
-      x_rd[t][tap] = G::HALO_OFF + h * CK + (((kg * 4 + lkq) ^ ((h >> 1) & 7)) << 4);
+      x_rd[t][tap] = G::HALO_OFF + h * CK + (((kg * 4 + lkq) ^ G::swz(h)) << 4);
     }
   }
   int w_rd[TN];
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     const int row = tn * 16 + lrow;
-    w_rd[tn] = row * CK + (((kg * 4 + lkq) ^ ((row >> 1) & 7)) << 4);
+    w_rd[tn] = row * CK + (((kg * 4 + lkq) ^ G::swz(row)) << 4);
   }
   v4i acc[TN][TM];
 #pragma unroll
@@ -269,7 +276,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloConvArgs
   }
   __syncthreads();                                   // every wave is done reading the main buffers
   // k-split: group 1 parks its partial accumulators behind the fp16 tile's area, group 0 adds them
-  {
+  if constexpr (G::KSPLIT == 2) {
     constexpr int WREGS = TN * TM * 4;
     int* part = reinterpret_cast<int*>(smem + BM * CS_STRIDE) + (wm * WREGS * 64 + lane);
     if (kg != 0) {
@@ -376,36 +383,42 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloConvArgs
   }
 }
 
-template <int TH, int TW, int BN>
+template <int TH, int TW, int BN, int CK>
 int launch_halo(const HaloConvArgs& a, hipStream_t stream) {
-  using G = HaloGeom<TH, TW, BN>;
+  using G = HaloGeom<TH, TW, BN, CK>;
   static const hipError_t attr = hipFuncSetAttribute(
-      reinterpret_cast<const void*>(&conv3x3_halo_kernel<TH, TW, BN>),
+      reinterpret_cast<const void*>(&conv3x3_halo_kernel<TH, TW, BN, CK>),
       hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM);
   if (attr != hipSuccess) return MIXDQ_ERR_LAUNCH;
   const int64_t grid = (int64_t)a.NI * (a.H / TH) * (a.W / TW) * ((a.K + BN - 1) / BN);
   if (grid <= 0 || grid > 0x7fffffff) return MIXDQ_ERR_INVALID_ARG;
-  conv3x3_halo_kernel<TH, TW, BN><<<dim3((unsigned)grid), 512, G::SMEM, stream>>>(a);
+  conv3x3_halo_kernel<TH, TW, BN, CK><<<dim3((unsigned)grid), 512, G::SMEM, stream>>>(a);
   return launch_status();
 }
 
 }  // namespace
 
+// Patches (tools/bench_gemm.py --conv): the weights are the larger stream (9 x BN x CK bytes per chunk
+// against one halo), so the more pixels share them the fewer bytes per output -- 16 x 16 pixels
+// (65 KB per 128 x 80 outputs and 128-byte chunk against 113 KB for 8 x 16) as soon as that still
+// gives every CU a workgroup (128 x 128 x 320 at batch 1: 21.2 vs 28.8 us; every layer from batch 4
+// on); otherwise the patch that fills the chip: 8 x 16, or 8 x 8 for the 32 x 32 layers at batch 1.
 int halo_conv_select(int NI, int H, int W, int C, int K, int R, int S, int stride, int pad) {
   if (R != 3 || S != 3 || stride != 1 || pad != 1 || NI <= 0) return 0;
   if (C % 64 != 0 || K % 4 != 0 || H % 8 != 0 || W % 8 != 0) return 0;
   // 32-bit per-lane offsets inside one image / the weight tensor
   if ((int64_t)H * W * C >= (1ll << 32) || (int64_t)K * 9 * C >= (1ll << 32)) return 0;
   const int64_t tiles_n = (K + 79) / 80;
-  // 8 x 16 pixel patches when they still give every CU a workgroup, 8 x 8 otherwise
+  if (H % 16 == 0 && W % 16 == 0 && (int64_t)NI * (H / 16) * (W / 16) * tiles_n >= kNumCU) return 92;
   if (W % 16 == 0 && (int64_t)NI * (H / 8) * (W / 16) * tiles_n >= kNumCU) return 90;
   return 91;
 }
 
 int halo_conv_launch(const HaloConvArgs& a, int tile, hipStream_t stream) {
   switch (tile) {
-    case 90: return launch_halo<8, 16, 80>(a, stream);
-    case 91: return launch_halo<8, 8, 80>(a, stream);
+    case 90: return launch_halo<8, 16, 80, 128>(a, stream);
+    case 91: return launch_halo<8, 8, 80, 128>(a, stream);
+    case 92: return launch_halo<16, 16, 80, 64>(a, stream);
     default: return MIXDQ_ERR_INVALID_ARG;
   }
 }

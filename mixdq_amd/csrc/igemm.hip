@@ -121,10 +121,57 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
       (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// ---- GELU by table ------------------------------------------------------------------------------
+// The GEGLU epilogue evaluates GELU on an FP16 gate and rounds the result to FP16: a function of 16
+// bits.  Its arithmetic (include/mixdq_math.h: ~75 FP32 operations per element with both erf branches
+// taken by every wave) is 5.4-8.6 us of the 26 us (1024, 10240, 1280) launch, the largest of the
+// step (tools/stamp_report.py) -- VALU-bound, and packed FP32 buys nothing on CDNA4 (v_pk_fma_f32
+// issues at half the rate of v_fma_f32).  The tiles that have a CU to themselves anyway (LDS > 80 KB)
+// and whose fp16 tile leaves room look the value up instead: f16(gelu(g)) for every |g| < 8 (36 864
+// entries, 72 KB; beyond: g, or -0 / NaN as the specification gives), built ONCE per device by the
+// specification itself (gelu_table_init_kernel), copied into LDS behind the main loop while the
+// accumulators are converted, read with one ds_read_u16 per element.  Bit-identical by construction.
+constexpr int kGeluTabMag = 0x4800;                         // |g| < 8.0
+constexpr int kGeluTabBytes = 2 * kGeluTabMag * 2;          // two signs x 2 bytes
+__device__ uint16_t g_gelu_tab[2 * kGeluTabMag];
+
+__global__ __launch_bounds__(256) void gelu_table_init_kernel() {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 2 * kGeluTabMag) return;
+  const unsigned short bits = (unsigned short)((i >= kGeluTabMag ? 0x8000 : 0) | (i % kGeluTabMag));
+  __half_raw r;
+  r.x = bits;
+  const float g = __half2float(__half(r));
+  g_gelu_tab[i] = __half_as_ushort(f32_to_f16_rn(mixdq_geluf(g)));
+}
+
+// the table is built by the first launch that needs it, on that launch's stream (stream-ordered in
+// front of the consumer; idempotent, so a repeat from a second stream or inside a graph is harmless)
+inline int ensure_gelu_table(hipStream_t stream) {
+  static bool done[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MIXDQ_ERR_LAUNCH;
+  if (!done[dev]) {
+    gelu_table_init_kernel<<<(2 * kGeluTabMag + 255) / 256, 256, 0, stream>>>();
+    if (hipGetLastError() != hipSuccess) return MIXDQ_ERR_LAUNCH;
+    done[dev] = true;
+  }
+  return MIXDQ_OK;
+}
+
 template <int BM, int BN, int BK, int STAGES>
-constexpr int igemm_main_bytes() {   // K-tile stages, overlaid by the epilogue's fp16 tile
-  return (STAGES * (BM + BN) * BK > BM * (BN * 2 + 16)) ? STAGES * (BM + BN) * BK
-                                                        : BM * (BN * 2 + 16);
+constexpr bool igemm_gelu_table_fits() {   // one workgroup per CU anyway, and room behind the fp16 tile
+  return BN % 64 == 0 && STAGES * (BM + BN) * BK > 80 * 1024 &&
+         BM * (BN * 2 + 16) + kGeluTabBytes + BN * 12 <= 160 * 1024;
+}
+
+template <int BM, int BN, int BK, int STAGES>
+constexpr int igemm_main_bytes() {   // K-tile stages, overlaid by the epilogue's fp16 tile (+ GELU table)
+  int m = (STAGES * (BM + BN) * BK > BM * (BN * 2 + 16)) ? STAGES * (BM + BN) * BK
+                                                         : BM * (BN * 2 + 16);
+  if (igemm_gelu_table_fits<BM, BN, BK, STAGES>() && m < BM * (BN * 2 + 16) + kGeluTabBytes)
+    m = BM * (BN * 2 + 16) + kGeluTabBytes;
+  return m;
 }
 template <int BM, int BN, int BK, int STAGES>
 constexpr int igemm_smem_bytes() {   // + the per-channel epilogue vectors: bias0, scale, bias
@@ -843,6 +890,19 @@ void igemm_kernel(const IgemmParams p_in) {
   // ---- epilogue: registers -> f16 tile in LDS -> whole-row 16-byte stores --------------------
   __syncthreads();   // every wave is done reading the stage buffers
   MIXDQ_STAMP_AT(4);
+  constexpr bool GELU_TAB = igemm_gelu_table_fits<BM, BN, BK, STAGES>() && !CONV && !F16 && !ATT &&
+                            !GROUPED && KSPLIT == 1;
+  if constexpr (GELU_TAB) {
+    if (p.Dq != nullptr) {   // GELU table -> LDS behind the fp16 tile, under the accumulator pass
+      constexpr int PIECES = kGeluTabBytes / 1024;
+      const char* src = reinterpret_cast<const char*>(g_gelu_tab);
+#pragma unroll
+      for (int j = 0; j < (PIECES + NWAVES - 1) / NWAVES; ++j) {
+        const int q = wid + NWAVES * j;
+        if (q < PIECES) glds16(src + q * 1024 + lane * 16, smem + BM * CS_STRIDE + q * 1024);
+      }
+    }
+  }
   if constexpr (KSPLIT > 1) {
     // groups 1.. park their partial accumulators (behind the fp16 tile's area), group 0 adds them
     constexpr int WREGS = TN * TM * ACC;          // accumulator registers of one wave
@@ -962,6 +1022,7 @@ void igemm_kernel(const IgemmParams p_in) {
     else to_tile(std::integral_constant<int, 2>{});
   }
   MIXDQ_STAMP_AT(5);
+  if constexpr (GELU_TAB) { if (p.Dq != nullptr) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
   __syncthreads();
   MIXDQ_STAMP_AT(6);
   if constexpr (ATT) {
@@ -1131,8 +1192,22 @@ void igemm_kernel(const IgemmParams p_in) {
       const __half* gh = reinterpret_cast<const __half*>(&gv);
       uint32_t pk[2] = {0u, 0u};
 #pragma unroll
-      for (int j = 0; j < 8; j += 2) {     // two gate values at a time (packed FP32: geluf2)
-        const v2f g2 = geluf2(v2f{__half2float(gh[j]), __half2float(gh[j + 1])});
+      for (int j = 0; j < 8; j += 2) {     // two gate values at a time
+        v2f g2;
+        if constexpr (GELU_TAB) {          // f16(gelu(g)) from the table in LDS
+          const uint16_t* T = reinterpret_cast<const uint16_t*>(smem + BM * CS_STRIDE);
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const unsigned u = __half_as_ushort(gh[j + e]);
+            const unsigned mag = u & 0x7fffu, neg = u >> 15;
+            const float g = __half2float(gh[j + e]);
+            const float tv = __half2float(__ushort_as_half(T[neg * kGeluTabMag + min(mag, (unsigned)kGeluTabMag - 1)]));
+            const float far = neg ? __fmul_rn(0.0f, g) : g;     // |g| >= 8: g, -0; inf / NaN as the formula
+            g2[e] = mag < (unsigned)kGeluTabMag ? tv : far;
+          }
+        } else {
+          g2 = geluf2(v2f{__half2float(gh[j]), __half2float(gh[j + 1])});
+        }
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
           const float ge = __half2float(f32_to_f16_rn(g2[e]));
@@ -1456,8 +1531,11 @@ inline int select_cfg(int64_t M, int N, int Ktot, bool whole64 = false, bool pha
   // exactly one (or two) 128x320 workgroups per CU: no tail round, the fewest L2->LDS bytes per MAC
   // among the tiles that still use every CU (M = 8192, N = 1280: 26.0 vs 28.2 us, K = 5120: 66 vs 78)
   const int64_t b320 = blocks(128, 320);
-  if (N % 320 == 0 && Ktot % 128 == 0 && Ktot >= 1024 && (b320 == kNumCU || b320 == 2 * kNumCU))
-    return 25;   // (K = 640: its two 128-byte-deep stages are too shallow, 128x128 wins)
+  // (K = 640: its two 128-byte-deep stages are too shallow, 128x128 wins -- except for GEMM+GEGLU,
+  // where this tile looks GELU up in LDS: (4096, 5120, 640) 30.3 vs 35.9 us)
+  if (N % 320 == 0 && Ktot % 128 == 0 && (Ktot >= 1024 || whole64) &&
+      (b320 == kNumCU || b320 == 2 * kNumCU))
+    return 25;
   // from 1.5 workgroups of 256x256 per CU on: the four-phase loop (fewest L2->LDS bytes per MAC, the
   // reads and the DMA of one wave group under the other's MFMAs): (8192, 10240, 1280) 135 vs 153 us on
   // 256x128, (8192, 3840, 1280) 56 vs 62, (32768, 1920, 640) 77 vs 84 (tools/bench_gemm.py --bs 8)
@@ -1724,6 +1802,7 @@ extern "C" int mixdq_qlinear_w8a8_geglu(const int8_t* A, const int8_t* W, const 
   if ((uintptr_t)bias_f16_or_null & 7) return MIXDQ_ERR_GEGLU_SHAPE;
   IgemmParams p{};
   p.A = A; p.Wt = W; p.bias0 = bias0; p.scale = scale; p.bias = (const __half*)bias_f16_or_null;
+  if (const int st = ensure_gelu_table((hipStream_t)stream)) return st;
   p.D = nullptr; p.Dq = out_i8; p.g_sinv = out_scale_inv; p.g_zp = out_zero_point;
   p.M = M; p.N = N; p.Ktot = K;
   p.H = p.W = p.P = p.Q = 1; p.C = K; p.R = p.S = 1; p.stride = 1; p.pad = 0;
@@ -1835,7 +1914,7 @@ extern "C" int mixdq_qconv2d_w8a8_table(const int8_t* X, const int8_t* Wt, const
   const int Q = (W + 2 * pad - (S - 1) - 1) / stride + 1;
   if (P <= 0 || Q <= 0 || N == 0) return MIXDQ_OK;
   // 3x3 / stride 1 / pad 1 with the input halo resident in LDS (csrc/iconv.hip): the automatic choice
-  // wherever it applies; tile ids 90 / 91 force it, any other forced id keeps the implicit-GEMM family
+  // wherever it applies; tile ids 90 / 91 / 92 force it, any other forced id keeps the implicit-GEMM family
   // (MIXDQ_HALO_CONV=0: off, for A/B runs)
   {
     static const bool halo_on = [] { const char* e = getenv("MIXDQ_HALO_CONV"); return !(e && e[0] == '0'); }();
@@ -1844,10 +1923,10 @@ extern "C" int mixdq_qconv2d_w8a8_table(const int8_t* X, const int8_t* Wt, const
                             (uintptr_t)D | (uintptr_t)residual_f16_or_null) & 15) &&
                          !((uintptr_t)bias_f16_or_null & 7);
     int tile = 0;
-    if (!(flags & MIXDQ_FLAG_W4) && aligned && (forced == 90 || forced == 91 || (forced == 0 && halo_on)))
+    if (!(flags & MIXDQ_FLAG_W4) && aligned && (forced == 90 || forced == 91 || forced == 92 || (forced == 0 && halo_on)))
       tile = halo_conv_select(N, H, W, C, K, R, S, stride, pad);
-    if (forced == 90 || forced == 91) {
-      if (tile == 0 || (forced == 90 && W % 16 != 0)) return MIXDQ_ERR_SHAPE;
+    if (forced == 90 || forced == 91 || forced == 92) {
+      if (tile == 0 || (forced != 91 && W % 16 != 0) || (forced == 92 && H % 16 != 0)) return MIXDQ_ERR_SHAPE;
       tile = forced;
     }
     if (tile != 0) {
@@ -1988,6 +2067,14 @@ extern "C" const char* mixdq_status_string(int status) {
 }
 
 extern "C" int mixdq_abi_version(void) { return MIXDQ_ABI_VERSION; }
+
+extern "C" int mixdq_gelu_table(uint16_t* out_device, mixdq_stream_t stream) {
+  if (!out_device) return MIXDQ_ERR_INVALID_ARG;
+  if (const int st = ensure_gelu_table((hipStream_t)stream)) return st;
+  return hipMemcpyFromSymbolAsync(out_device, HIP_SYMBOL(g_gelu_tab), kGeluTabBytes, 0,
+                                  hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess
+             ? MIXDQ_OK : MIXDQ_ERR_LAUNCH;
+}
 
 #if MIXDQ_STAMP
 // diagnostic builds only: register (or clear, with null) the stamp buffer, [grid][16 waves][16] uint64

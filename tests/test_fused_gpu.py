@@ -162,6 +162,26 @@ def test_packed_gelu_equals_the_scalar_specification_on_every_fp16_gate(C, oracl
     assert np.array_equal(np.isnan(got), np.isnan(want))
 
 
+def test_gelu_table_of_the_large_tile_epilogue_is_the_specification(C, oracle):
+    """The GEMM + GEGLU epilogue of the one-workgroup-per-CU tiles looks f16(gelu(g)) up in an LDS
+    table for |g| < 8 and uses `g` (g >= 8) or `0 * g` (g <= -8: -0; -inf -> NaN) beyond: both
+    halves against the host evaluation of include/mixdq_math.h, for all 65536 gates."""
+    L = oracle.lib()
+    tab = C.gelu_table(DEV).cpu().numpy().view(np.uint16)              # [2, 0x4800]
+    bits = np.arange(65536, dtype=np.uint32).astype(np.uint16)
+    g = bits.view(np.float16)
+    with np.errstate(all="ignore"):
+        want = np.array([np.float32(L.mixdq_oracle_geluf(float(a))) for a in g.astype(np.float32)],
+                        np.float32).astype(np.float16)
+        mag, neg = bits & 0x7fff, bits >> 15
+        near = mag < 0x4800
+        got = np.where(near, tab[neg, np.minimum(mag, 0x47ff)].view(np.float16),
+                       np.where(neg == 1, (np.float32(0) * g.astype(np.float32)).astype(np.float16), g))
+    both_nan = np.isnan(got) & np.isnan(want)
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.array_equal(got.view(np.uint16)[~both_nan], want.view(np.uint16)[~both_nan])
+
+
 GEGLU_GEMM_CASES = [  # M, D, K, forced tile config (0 = automatic), bias
     (1024, 640, 320, 0, True), (96, 64, 64, 4, True), (77, 32, 48, 4, False),
     (200, 160, 128, 3, True), (200, 160, 128, 41, True), (300, 128, 256, 13, True),

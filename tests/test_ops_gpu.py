@@ -461,6 +461,9 @@ HALO_CASES = [  # n, h, w, c, k, bias, residual ("", "full", "image"), forced ti
     (1, 8, 8, 448, 84, True, "full", 91),        # a single patch: every pixel a border class; N % 8 == 4
     (1, 24, 48, 256, 160, False, "full", 0),     # several patches per row / column, two chunks
     (3, 32, 32, 640, 96, True, "image", 0),      # batch 3, five chunks
+    (1, 16, 32, 320, 168, True, "full", 92),     # 16 x 16 patches, 64-byte chunks (5 of them), N tail
+    (2, 32, 16, 64, 80, False, "image", 92),     # one chunk
+    (1, 16, 16, 192, 72, True, "", 92),          # a single all-border patch
 ]
 
 
@@ -477,7 +480,7 @@ def test_qconv2d_halo_kernel_bit_exact(C, oracle, case):
     in_zp = -11.0
     bias = dd.f16(904, (k,), -1, 1) if has_bias else None
     wsum = wt.astype(np.float32).sum(axis=3, dtype=np.float32)
-    assert C.conv_halo_select(n, h, w_, c, k, 3, 3, 1, 1) in (90, 91)
+    assert C.conv_halo_select(n, h, w_, c, k, 3, 3, 1, 1) in (90, 91, 92)
     args = (t(x).permute(0, 3, 1, 2), t(wt).permute(0, 3, 1, 2), t(scale), scal(1.0), scal(in_zp),
             t(scale), t(wsum.reshape(k, 1, 3, 3)), None, None if bias is None else t(bias), 1, 1)
     kw = {}
