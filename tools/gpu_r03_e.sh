@@ -1,6 +1,6 @@
 #!/bin/bash
 # same-box A/B: round-2 library vs the current one, batch 1 and batch 8
-out=gpurun_out/r03_i
+out=gpurun_out/r03_m
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 for rep in 1; do

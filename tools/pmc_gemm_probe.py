@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
-"""One GEMM shape x a few kernel configurations, a few launches each, for SQ/TCP counter passes.
-    rocprofv3 --pmc <counters> --output-format csv -d out -- python3 tools/pmc_gemm_probe.py M N K cfg,cfg,..
-"""
+"""One launch shape, a few launches, for rocprofv3 --pmc passes (program directly after `--`):
+    rocprofv3 --pmc <counters> --output-format csv -d out -- python3 tools/pmc_gemm_probe.py lin   M N K [cfg]
+                                                              ... python3 tools/pmc_gemm_probe.py geglu M N K [cfg]
+                                                              ... python3 tools/pmc_gemm_probe.py conv  IMG HW CIN COUT [cfg]
+Inputs are made on the CPU and copied; no PyTorch GPU kernel is launched (rocprofv3 --pmc segfaults
+inside some torch reduction launches on this image)."""
 import os
 import sys
 
@@ -10,14 +13,31 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import mixdq_amd._C as C  # noqa: E402
 
-M, N, K = (int(v) for v in sys.argv[1:4])
-cfgs = [int(c) for c in sys.argv[4].split(",")]
+kind = sys.argv[1]
+a1, a2, a3 = (int(v) for v in sys.argv[2:5])
+rest = [int(v) for v in sys.argv[5:]]
 g = torch.Generator().manual_seed(0)
-a = torch.randint(-128, 128, (M, K), generator=g, dtype=torch.int8).to("cuda")
-w = torch.randint(-128, 128, (N, K), generator=g, dtype=torch.int8).to("cuda")
-sc = (torch.rand(N, generator=g) * 1e-4).to("cuda")
-zero = torch.zeros(()).to("cuda")
-for cfg in cfgs:
-    for _ in range(4):
-        C.qlinear_w8_a8_ohalf(a, w, sc, zero, zero, sc, sc, sc, None, _cfg=cfg)
+one, zero = torch.ones(()).to("cuda"), torch.zeros(()).to("cuda")
+REPS = 4
+if kind in ("lin", "geglu"):
+    M, N, K = a1, a2, a3
+    cfg = rest[0] if rest else 0
+    a = torch.randint(-128, 128, (M, K), generator=g, dtype=torch.int8).to("cuda")
+    w = torch.randint(-128, 128, (N, K), generator=g, dtype=torch.int8).to("cuda")
+    sc = (torch.rand(N, generator=g) * 1e-4).to("cuda")
+    for _ in range(REPS):
+        if kind == "geglu":
+            C.qlinear_geglu(a, w, sc, sc, None, one, zero, _cfg=cfg)
+        else:
+            C.qlinear_w8_a8_ohalf(a, w, sc, zero, zero, sc, sc, sc, None, _cfg=cfg)
+else:
+    NI, HW, CIN = a1, a2, a3
+    COUT, cfg = rest[0], (rest[1] if len(rest) > 1 else 0)
+    x = torch.randint(-128, 128, (NI, HW, HW, CIN), generator=g, dtype=torch.int8).to("cuda").permute(0, 3, 1, 2)
+    w = torch.randint(-128, 128, (COUT, 3, 3, CIN), generator=g, dtype=torch.int8).to("cuda").permute(0, 3, 1, 2)
+    wsum = torch.randint(-128, 128, (COUT, 1, 3, 3), generator=g, dtype=torch.int32).float().to("cuda")
+    sc = (torch.rand(COUT, generator=g) * 1e-4).to("cuda")
+    table = C.conv_border_table(wsum)
+    for _ in range(REPS):
+        C.qconv2d_w8_a8_ohalf(x, w, sc, zero, one, sc, wsum, None, None, 1, 1, 1, _table=table, _cfg=cfg)
 torch.cuda.synchronize()

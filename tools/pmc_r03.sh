@@ -1,0 +1,33 @@
+#!/bin/bash
+# Round-3 counter passes of the launches that dominate the benchmarked graphs (batch 1 and 8): FETCH_SIZE
+# and WRITE_SIZE in separate passes (MI355X_MICROARCH.md, HBM section: FETCH_SIZE x2 on gfx950) and one
+# SQ pass (MFMA-busy, CU-busy, wait / issue-stall split).  Run on the GPU box from the repo root:
+#   bash tools/pmc_r03.sh        -> gpurun_out/r03_pmc/{summary.json, *_counter_collection.csv}
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
+out=gpurun_out/r03_pmc
+rm -rf $out; mkdir -p $out
+SQ="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES"
+i=0
+while read SPEC; do
+  [ -z "$SPEC" ] && continue
+  i=$((i+1))
+  for pass in FETCH_SIZE WRITE_SIZE SQ; do
+    ctr=$pass; [ $pass = SQ ] && ctr="$SQ"
+    timeout 240 rocprofv3 --pmc $ctr --output-format csv -d $out/raw/${pass}_$i -o r -- python3 tools/pmc_gemm_probe.py $SPEC > $out/raw_${pass}_$i.log 2>&1
+  done
+  echo "$i $SPEC" >> $out/shapes.txt
+done <<'SHAPES'
+geglu 1024 10240 1280
+lin 1024 1280 1280
+lin 1024 1280 5120
+lin 1024 3840 1280
+conv 1 64 640 640
+conv 1 32 1280 1280
+geglu 8192 10240 1280
+lin 8192 1280 5120
+lin 8192 3840 1280
+conv 8 64 640 640
+SHAPES
+python3 tools/pmc_r03_summary.py $out
+find $out/raw -name "*counter_collection.csv" | while read f; do cp $f $out/$(echo $f | sed 's|.*/raw/||; s|/.*||')_counter_collection.csv; done
+rm -rf $out/raw $out/raw_*.log
