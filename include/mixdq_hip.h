@@ -65,7 +65,13 @@ enum mixdq_flags {
      K % 32 == 0 (conv: C % 32 == 0).  No reference counterpart: the reference's 4-bit layers
      fall back to FP16 (nn/Linear.py:31,133-134); results equal the W8 path run on the unpacked
      values.  bias0 / scale are those of the unpacked integers. */
-  MIXDQ_FLAG_W4 = 2
+  MIXDQ_FLAG_W4 = 2,
+  /* mixdq_qconv2d_w8a8_table only: X is [N, H/2, W/2, C] and the conv runs on its nearest-neighbour
+     2x upsampling (H, W stay the conv's input size) -- Upsample2D's conv(interpolate(x, 2.0)) without
+     the upsampled tensor (quantizing commutes with nearest upsampling: the INT8 values are the same).
+     3x3 / stride 1 / pad 1 shapes of the LDS-halo kernel only (mixdq_conv_halo_select != 0), else
+     MIXDQ_ERR_SHAPE.  No reference counterpart. */
+  MIXDQ_FLAG_UPSAMPLE2X = 4
   /* bits 8..15: force a kernel configuration id (tuning / tests); 0 = automatic */
 };
 

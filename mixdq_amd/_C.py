@@ -102,6 +102,7 @@ IGEMM_CONFIGS = {1: (64, 64, 64, 2), 3: (128, 128, 64, 2), 4: (64, 64, 128, 3),
                  70: (256, 256, 128, 2), 71: (256, 256, 64, 4)}
 
 FLAG_W4 = 2   # MIXDQ_FLAG_W4: the weight tensor holds packed signed 4-bit values
+FLAG_UPSAMPLE2X = 4   # MIXDQ_FLAG_UPSAMPLE2X: the conv input is read through a nearest 2x upsampling
 
 # Rounding variant of the fused multiply-adds: "A" (default) = FMA,
 # "B" = separate multiply and add.  Read once at import; no other global state.
@@ -444,10 +445,17 @@ def _conv_geometry(input_int8, weight_int8, stride, padding, dilation):
     return N, C, H, W, K, R, S, P, Q
 
 
+def conv_upsample2x_supported(x_shape, weight_shape, stride, padding) -> bool:
+    """qconv2d_w8_a8_ohalf(..., _upsample2x=True) takes this conv (the LDS-halo kernel's range)."""
+    N, C, H, W = x_shape
+    K, _, R, S = weight_shape
+    return conv_halo_select(N, 2 * H, 2 * W, C, K, R, S, stride, padding) != 0
+
+
 def qconv2d_w8_a8_ohalf(input_int8, weight_int8, weight_scale, input_scale, input_zero_point,
                         scale, weight_sum_by_input_channels, bias0, bias=None, stride=1,
                         padding=0, dilation=1, *, _table=None, _cfg=0, _residual=None,
-                        _residual_per_image=False, _w4=False):
+                        _residual_per_image=False, _w4=False, _upsample2x=False):
     stride = 1 if stride is None else int(stride)
     padding = 0 if padding is None else int(padding)
     dilation = 1 if dilation is None else int(dilation)
@@ -484,6 +492,10 @@ def qconv2d_w8_a8_ohalf(input_int8, weight_int8, weight_scale, input_scale, inpu
     _check(scale.dtype == torch.float32, "scale should be float32")
     _check(input_int8.dim() == 4 and weight_int8.dim() == 4, "input and weight should be 4-D")
     N, C, H, W, K, R, S, P, Q = _conv_geometry(input_int8, weight_int8, stride, padding, dilation)
+    if _upsample2x:       # the conv runs on the nearest 2x upsampling of the stored input
+        H, W = 2 * H, 2 * W
+        P = (H + 2 * padding - (R - 1) - 1) // stride + 1
+        Q = (W + 2 * padding - (S - 1) - 1) // stride + 1
     _check(weight_int8.size(1) * (2 if _w4 else 1) == C,
            "input and weight channel counts should match")
     _check(weight_scale.numel() == K,
@@ -511,7 +523,7 @@ def qconv2d_w8_a8_ohalf(input_int8, weight_int8, weight_scale, input_scale, inpu
             (input_int8, weight_int8, weight_scale, input_scale, input_zero_point, scale,
              weight_sum_by_input_channels, bias0, bias, stride, padding, dilation),
             dict(_table=_table, _cfg=_cfg, _residual=_residual,
-                 _residual_per_image=_residual_per_image, _w4=_w4))
+                 _residual_per_image=_residual_per_image, _w4=_w4, _upsample2x=_upsample2x))
     with torch.cuda.device(dev):
         res_ptr, res_div = None, 1
         if _residual is not None:
@@ -524,7 +536,7 @@ def qconv2d_w8_a8_ohalf(input_int8, weight_int8, weight_scale, input_scale, inpu
                 _check(tuple(_residual.shape) == (N, K, P, Q) and _residual.is_contiguous(
                     memory_format=torch.channels_last), "residual should be channels-last [N,K,P,Q]")
             res_ptr = _residual.data_ptr()
-        if padding > 0 and _table is None and _residual is None:
+        if padding > 0 and _table is None and _residual is None and not _upsample2x:
             ws_bytes = _lib.mixdq_qconv2d_workspace_bytes(K, R, S, padding)
             workspace = torch.empty(ws_bytes // 4, dtype=torch.float32, device=dev)
             code = _lib.mixdq_qconv2d_w8a8(
@@ -542,7 +554,8 @@ def qconv2d_w8_a8_ohalf(input_int8, weight_int8, weight_scale, input_scale, inpu
                 x.data_ptr(), w.data_ptr(), sc.data_ptr(), _ptr(_table),
                 input_zero_point.data_ptr(), _ptr(b0), _ptr(bs), D.data_ptr(),
                 N, H, W, C, K, R, S, stride, padding, res_ptr, res_div,
-                FLAGS | (_cfg << 8) | (FLAG_W4 if _w4 else 0), _stream())
+                FLAGS | (_cfg << 8) | (FLAG_W4 if _w4 else 0)
+                | (FLAG_UPSAMPLE2X if _upsample2x else 0), _stream())
     _status(code, "qconv2d_w8_a8_ohalf")
     return D
 

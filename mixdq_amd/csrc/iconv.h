@@ -14,8 +14,10 @@ struct HaloConvArgs {
   __half* D;              // [NI, H, W, K]
   const __half* res;      // residual or null: [NI, H, W, K] (res_div == 1) or [NI, K] (res_div == H * W)
   int64_t res_div;
-  int NI, H, W, C, K;
+  int NI, H, W, C, K;     // H, W: the conv's input (= output) size
   int unfused;
+  int ups;                // 1: X is [NI, H / 2, W / 2, C] and the conv reads its nearest-neighbour 2x
+                          //    upsampling (Upsample2D: conv(interpolate(x))) without materialising it
 };
 
 // Tile id the halo kernel would run this problem on (90: 8x16 pixels x 80 channels, 91: 8x8 x 80), or 0

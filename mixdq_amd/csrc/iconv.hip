@@ -78,7 +78,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloConvArgs
   constexpr int BM = G::BM, HWP = G::HWP, HP = G::HP, TM = G::TM, TN = G::TN;
   constexpr int CS_STRIDE = G::CS_STRIDE;
   MIXDQ_ARGS_NOW(p.X, p.Wt, p.scale, p.bias, p.table, p.zp, p.D, p.res, p.res_div, p.NI, p.H, p.W, p.C,
-                 p.K, p.unfused);
+                 p.K, p.unfused, p.ups);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -107,7 +107,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloConvArgs
   const int C = p.C;
   const int nch = (C + CK - 1) / CK;                 // channel chunks (the last may be half empty)
   const char* zero = reinterpret_cast<const char*>(&g_zero_page);
-  const int8_t* ximg = p.X + (int64_t)img * p.H * p.W * C;
+  // ups: the stored image is half the size; halo pixel (iy, ix) reads source pixel (iy / 2, ix / 2)
+  const int sh = p.ups ? 1 : 0, SW = p.W >> sh;
+  const int8_t* ximg = p.X + (int64_t)img * (p.H >> sh) * SW * C;
 
   // ---- epilogue vectors, requested now and parked in registers across the main loop (igemm.hip):
   //      the NINE border-class rows a 3x3 / pad-1 conv can meet (row class x column class: full
@@ -144,7 +146,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloConvArgs
     const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
     const int c16 = ((lane % G::LPP) ^ G::swz(h)) << 4;
     h_ok[j] = h < HP && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-    h_off[j] = h_ok[j] ? (uint32_t)(iy * p.W + ix) * (uint32_t)C + c16 : 0u;
+    h_off[j] = h_ok[j] ? (uint32_t)((iy >> sh) * SW + (ix >> sh)) * (uint32_t)C + c16 : 0u;
     h_c16[j] = c16;
   }
   // weight piece j of this wave = piece wid + 8 j of a filter row's stage: tap s = piece / (pieces

@@ -1929,8 +1929,10 @@ extern "C" int mixdq_qconv2d_w8a8_table(const int8_t* X, const int8_t* Wt, const
       if (tile == 0 || (forced != 91 && W % 16 != 0) || (forced == 92 && H % 16 != 0)) return MIXDQ_ERR_SHAPE;
       tile = forced;
     }
+    if ((flags & MIXDQ_FLAG_UPSAMPLE2X) && (tile == 0 || (H & 1) || (W & 1))) return MIXDQ_ERR_SHAPE;
     if (tile != 0) {
       HaloConvArgs a{};
+      a.ups = (flags & MIXDQ_FLAG_UPSAMPLE2X) ? 1 : 0;
       a.X = X; a.Wt = Wt; a.scale = scale; a.bias = (const __half*)bias_f16_or_null;
       a.table = table_or_null; a.zp = zero_point; a.D = (__half*)D;
       a.res = (const __half*)residual_f16_or_null;

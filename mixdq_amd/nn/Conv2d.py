@@ -205,14 +205,21 @@ class QuantizedConv2d(nn.Module):
             for sfx in ("", "_0") if self.split else ("",):
                 self._border_table(sfx)
 
-    def forward_quantized(self, x_int, residual=None, residual_per_image=False):
+    def forward_quantized(self, x_int, residual=None, residual_per_image=False, upsample2x=False):
         """The conv half of forward() for an input already quantized with this layer's activation
         qparams (not for split shortcuts).  `residual`: fp16 [N,K,P,Q] channels-last, or [N,K] with
-        residual_per_image (the time-embedding add), added after the epilogue's FP16 rounding."""
+        residual_per_image (the time-embedding add), added after the epilogue's FP16 rounding.
+        upsample2x: the conv runs on the nearest 2x upsampling of x_int (never materialised)."""
         assert self.valid_for_acceleration and self.split == 0
-        return self._conv(x_int, "", self.bias, residual, residual_per_image)
+        return self._conv(x_int, "", self.bias, residual, residual_per_image, upsample2x)
 
-    def _conv(self, x_int, sfx, bias, residual=None, residual_per_image=False):
+    def upsample2x_supported(self, x_shape) -> bool:
+        return bool(self.valid_for_acceleration and self.split == 0 and not self.w_packed4
+                    and _C.conv_upsample2x_supported(x_shape, (self.out_channels, self.in_channels)
+                                                     + tuple(self.kernel_size), self.stride[0],
+                                                     self.padding[0]))
+
+    def _conv(self, x_int, sfx, bias, residual=None, residual_per_image=False, upsample2x=False):
         return _C.qconv2d_w8_a8_ohalf(
             x_int, getattr(self, ("weight_int4" if self.w_packed4 else "weight_int") + sfx),
             getattr(self, "weight_scales" + sfx),
@@ -220,7 +227,7 @@ class QuantizedConv2d(nn.Module):
             getattr(self, "scale" + sfx), getattr(self, "weight_sum_by_input_channels" + sfx),
             getattr(self, "bias0" + sfx), bias, self.stride[0], self.padding[0], 1,
             _table=self._border_table(sfx), _residual=residual,
-            _residual_per_image=residual_per_image, _w4=self.w_packed4)
+            _residual_per_image=residual_per_image, _w4=self.w_packed4, _upsample2x=upsample2x)
 
     # FP fallback layers: True = this repo's FP16 MFMA kernel (mixdq_conv2d_f16), False = F.conv2d
     # as in the reference (MIOpen here, whose kernel search costs ~30 s of start-up).

@@ -55,7 +55,8 @@ def oracle_ops(monkeypatch, oracle):
 
     def qconv(x_int, w, ws, a_s, a_zp, scale, wsum, bias0, bias=None, stride=1, padding=0,
               dilation=1, _table=None, _residual=None, _residual_per_image=False, _cfg=0,
-              _w4=False):
+              _w4=False, _upsample2x=False):
+        assert not _upsample2x
         wk = w.permute(0, 2, 3, 1).contiguous().numpy()
         if _w4:
             wk = oracle.unpack_w4(wk)

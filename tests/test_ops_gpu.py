@@ -500,6 +500,27 @@ def test_qconv2d_halo_kernel_bit_exact(C, oracle, case):
     assert torch.equal(got, C.qconv2d_w8_a8_ohalf(*args, _cfg=4, **kw)), "halo != implicit GEMM"
 
 
+@pytest.mark.parametrize("n,h,w_,c,k,tile", [(2, 8, 8, 192, 168, 0), (1, 16, 8, 64, 80, 92), (1, 4, 8, 320, 72, 91),
+                                             (3, 8, 16, 128, 96, 90)])
+def test_qconv2d_upsample2x_reads_the_small_tensor(C, n, h, w_, c, k, tile):
+    """MIXDQ_FLAG_UPSAMPLE2X: conv(nearest-2x-upsample(x)) from the [n, h, w] tensor == the conv on
+    the materialised upsampling, bit for bit (Upsample2D; quantize commutes with nearest upsampling)."""
+    x = t(dd.int8(921, (n, h, w_, c))).permute(0, 3, 1, 2)
+    wt = dd.int8(922, (k, 3, 3, c))
+    scale = t(dd.f32(923, (k,), 1e-4, 6e-4))
+    bias = t(dd.f16(924, (k,), -1, 1))
+    wsum = t(wt.astype(np.float32).sum(axis=3, dtype=np.float32).reshape(k, 1, 3, 3))
+    args = (t(wt).permute(0, 3, 1, 2), scale, scal(1.0), scal(7.0), scale, wsum, None, bias, 1, 1)
+    assert C.conv_upsample2x_supported(tuple(x.shape), (k, c, 3, 3), 1, 1)
+    big = torch.nn.functional.interpolate(x.float(), scale_factor=2.0, mode="nearest").to(torch.int8
+                                          ).contiguous(memory_format=torch.channels_last)
+    want = C.qconv2d_w8_a8_ohalf(big, *args, _cfg=4)
+    got = C.qconv2d_w8_a8_ohalf(x, *args, _cfg=tile, _upsample2x=True)
+    assert got.shape == want.shape and torch.equal(got, want)
+    with pytest.raises(RuntimeError, match="shape outside"):
+        C.qconv2d_w8_a8_ohalf(x, *args, _cfg=4, _upsample2x=True)      # implicit-GEMM tile forced
+
+
 def test_qconv2d_halo_kernel_range(C):
     """Outside its range the automatic choice is the implicit-GEMM family, and forcing it fails."""
     assert C.conv_halo_select(1, 12, 12, 960, 640, 3, 3, 1, 1) == 0      # H % 8 != 0
