@@ -263,8 +263,13 @@ __device__ __forceinline__ float wave_sum(float v) {
 }
 
 // NQ: quantizers in use (0..3), WANT_H: the FP16 copy is written -- compile-time, so a launch with one
-// consumer does not run the other two quantizers' arithmetic on its one-wave-per-SIMD critical path
-template <bool UNFUSED, int NQ, bool WANT_H>
+// consumer does not run the other two quantizers' arithmetic on its one-wave-per-SIMD critical path.
+// ROWS: rows a wave carries through the chain together (all loaded up front).  The kernel is a
+// latency chain per wave (load -> reduce -> reduce -> store); at batch 1 every wave has one row and
+// the chain IS the kernel, from 8192 rows on two rows per wave keep the grid at one round of four
+// waves per SIMD and put twice the bytes in flight per chain (batch 8: 13.0 us per launch at
+// 2.4 TB/s before).  The arithmetic of a row does not depend on ROWS.
+template <bool UNFUSED, int NQ, bool WANT_H, int ROWS>
 __global__ __launch_bounds__(256) void ln_quant_kernel(
     const __half* __restrict__ x, const __half* __restrict__ gamma, const __half* __restrict__ beta,
     float eps, int64_t M, int C, const float* __restrict__ s_inv0, const float* __restrict__ zp0,
@@ -273,19 +278,25 @@ __global__ __launch_bounds__(256) void ln_quant_kernel(
     int8_t* __restrict__ q2, __half* __restrict__ out_h) {
   MIXDQ_ARGS_NOW(x, gamma, beta, eps, M, C, s_inv0, zp0, q0, s_inv1, zp1, q1, s_inv2, zp2, q2, out_h);
   const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
+  if (row0 >= M) return;
   const int nch = C / 8;
-  const __half* xr = x + row * C;
-  Half8 h[kLnMaxChunks], gmv[kLnMaxChunks], btv[kLnMaxChunks];
-  // everything the row needs is requested up front: the kernel is a latency chain (load ->
-  // reduce -> reduce -> store), and gamma / beta / the quantizer scalars would otherwise add a
-  // second memory round trip after the reductions
+  Half8 h[ROWS][kLnMaxChunks], gmv[kLnMaxChunks], btv[kLnMaxChunks];
+  // everything the rows need is requested up front: gamma / beta / the quantizer scalars would
+  // otherwise add a second memory round trip after the reductions
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    const __half* xr = x + (row0 + r < M ? row0 + r : row0) * C;    // a missing last row re-reads row0
+#pragma unroll
+    for (int i = 0; i < kLnMaxChunks; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) h[r][i] = *reinterpret_cast<const Half8*>(xr + 8 * c);
+    }
+  }
 #pragma unroll
   for (int i = 0; i < kLnMaxChunks; ++i) {
     const int c = lane + 64 * i;
     if (c < nch) {
-      h[i] = *reinterpret_cast<const Half8*>(xr + 8 * c);
       gmv[i] = *reinterpret_cast<const Half8*>(gamma + 8 * c);
       btv[i] = *reinterpret_cast<const Half8*>(beta + 8 * c);
     }
@@ -293,52 +304,63 @@ __global__ __launch_bounds__(256) void ln_quant_kernel(
   const float si0 = NQ > 0 ? *s_inv0 : 0.f, z0 = NQ > 0 ? *zp0 : 0.f;
   const float si1 = NQ > 1 ? *s_inv1 : 0.f, z1 = NQ > 1 ? *zp1 : 0.f;
   const float si2 = NQ > 2 ? *s_inv2 : 0.f, z2 = NQ > 2 ? *zp2 : 0.f;
-  float s = 0.f;
+  float mean[ROWS], rstd[ROWS];
 #pragma unroll
-  for (int i = 0; i < kLnMaxChunks; ++i) {
-    const int c = lane + 64 * i;
-    if (c < nch) {
+  for (int r = 0; r < ROWS; ++r) {
+    float s = 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s = __fadd_rn(s, half_at(h[i], j));
-    }
-  }
-  const float mean = wave_sum(s) / (float)C;
-  float v = 0.f;
+    for (int i = 0; i < kLnMaxChunks; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
 #pragma unroll
-  for (int i = 0; i < kLnMaxChunks; ++i) {
-    const int c = lane + 64 * i;
-    if (c < nch) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float d = __fsub_rn(half_at(h[i], j), mean);
-        v = __builtin_fmaf(d, d, v);
+        for (int j = 0; j < 8; ++j) s = __fadd_rn(s, half_at(h[r][i], j));
       }
     }
+    mean[r] = wave_sum(s) / (float)C;
   }
-  const float rstd = 1.0f / sqrtf(__fadd_rn(wave_sum(v) / (float)C, eps));
 #pragma unroll
-  for (int i = 0; i < kLnMaxChunks; ++i) {
-    const int c = lane + 64 * i;
-    if (c < nch) {
-      const Half8 gm = gmv[i], bt = btv[i];
-      Half8 oh;
-      Char8 a, b, d;
-      a.w[0] = a.w[1] = b.w[0] = b.w[1] = d.w[0] = d.w[1] = 0;
-      oh.w[0] = oh.w[1] = oh.w[2] = oh.w[3] = 0;
+  for (int r = 0; r < ROWS; ++r) {
+    float v = 0.f;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float nrm = __fmul_rn(__fsub_rn(half_at(h[i], j), mean), rstd);
-        const float y = round_f16(__builtin_fmaf(nrm, half_at(gm, j), half_at(bt, j)));
-        if constexpr (WANT_H) put_half(oh, j, y);
-        if constexpr (NQ > 0) put_q(a, j, quantize_one<UNFUSED>(y, si0, z0));
-        if constexpr (NQ > 1) put_q(b, j, quantize_one<UNFUSED>(y, si1, z1));
-        if constexpr (NQ > 2) put_q(d, j, quantize_one<UNFUSED>(y, si2, z2));
+    for (int i = 0; i < kLnMaxChunks; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float d = __fsub_rn(half_at(h[r][i], j), mean[r]);
+          v = __builtin_fmaf(d, d, v);
+        }
       }
-      const int64_t off = row * C + 8 * c;
-      if constexpr (NQ > 0) *reinterpret_cast<Char8*>(q0 + off) = a;
-      if constexpr (NQ > 1) *reinterpret_cast<Char8*>(q1 + off) = b;
-      if constexpr (NQ > 2) *reinterpret_cast<Char8*>(q2 + off) = d;
-      if constexpr (WANT_H) *reinterpret_cast<Half8*>(out_h + off) = oh;
+    }
+    rstd[r] = 1.0f / sqrtf(__fadd_rn(wave_sum(v) / (float)C, eps));
+  }
+#pragma unroll
+  for (int r = 0; r < ROWS; ++r) {
+    if (row0 + r >= M) break;
+#pragma unroll
+    for (int i = 0; i < kLnMaxChunks; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        const Half8 gm = gmv[i], bt = btv[i];
+        Half8 oh;
+        Char8 a, b, d;
+        a.w[0] = a.w[1] = b.w[0] = b.w[1] = d.w[0] = d.w[1] = 0;
+        oh.w[0] = oh.w[1] = oh.w[2] = oh.w[3] = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float nrm = __fmul_rn(__fsub_rn(half_at(h[r][i], j), mean[r]), rstd[r]);
+          const float y = round_f16(__builtin_fmaf(nrm, half_at(gm, j), half_at(bt, j)));
+          if constexpr (WANT_H) put_half(oh, j, y);
+          if constexpr (NQ > 0) put_q(a, j, quantize_one<UNFUSED>(y, si0, z0));
+          if constexpr (NQ > 1) put_q(b, j, quantize_one<UNFUSED>(y, si1, z1));
+          if constexpr (NQ > 2) put_q(d, j, quantize_one<UNFUSED>(y, si2, z2));
+        }
+        const int64_t off = (row0 + r) * C + 8 * c;
+        if constexpr (NQ > 0) *reinterpret_cast<Char8*>(q0 + off) = a;
+        if constexpr (NQ > 1) *reinterpret_cast<Char8*>(q1 + off) = b;
+        if constexpr (NQ > 2) *reinterpret_cast<Char8*>(q2 + off) = d;
+        if constexpr (WANT_H) *reinterpret_cast<Half8*>(out_h + off) = oh;
+      }
     }
   }
 }
@@ -506,13 +528,21 @@ extern "C" int mixdq_layernorm_quantize(const void* x, const void* gamma, const 
   }
   if (((uintptr_t)x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)out_f16_or_null) % 16)
     return MIXDQ_ERR_ALIGNMENT;
-  const int grid = (int)((M + 3) / 4);
   hipStream_t stream = (hipStream_t)stream_;
   const bool unfused = flags & MIXDQ_FLAG_UNFUSED, want_h = out_f16_or_null != nullptr;
+  const int rows = M >= 8192 ? 2 : 1;                 // rows per wave (see the kernel)
+  const int grid = (int)((M + 4 * rows - 1) / (4 * rows));
 #define LN_LAUNCH(U, NQ, H)                                                                          \
-  ln_quant_kernel<U, NQ, H><<<grid, 256, 0, stream>>>(                                               \
-      (const __half*)x, (const __half*)gamma, (const __half*)beta, eps, M, C, si[0], zp[0], q[0],    \
-      si[1], zp[1], q[1], si[2], zp[2], q[2], (__half*)out_f16_or_null)
+  do {                                                                                               \
+    if (rows == 2)                                                                                   \
+      ln_quant_kernel<U, NQ, H, 2><<<grid, 256, 0, stream>>>(                                        \
+          (const __half*)x, (const __half*)gamma, (const __half*)beta, eps, M, C, si[0], zp[0], q[0], \
+          si[1], zp[1], q[1], si[2], zp[2], q[2], (__half*)out_f16_or_null);                         \
+    else                                                                                             \
+      ln_quant_kernel<U, NQ, H, 1><<<grid, 256, 0, stream>>>(                                        \
+          (const __half*)x, (const __half*)gamma, (const __half*)beta, eps, M, C, si[0], zp[0], q[0], \
+          si[1], zp[1], q[1], si[2], zp[2], q[2], (__half*)out_f16_or_null);                         \
+  } while (0)
 #define LN_BY_H(U, NQ) do { if (want_h) LN_LAUNCH(U, NQ, true); else LN_LAUNCH(U, NQ, false); } while (0)
 #define LN_BY_NQ(U)                                                                \
   do {                                                                             \

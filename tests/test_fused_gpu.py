@@ -90,7 +90,8 @@ def test_groupnorm_unsupported_shapes_raise(C):
         C.groupnorm_silu_quantize(x, 6, w, w, 1e-5, scal(1), scal(0))
 
 
-LN_CASES = [(1024, 1280, 3), (4096, 640, 1), (77, 640, 2), (5, 64, 3), (3, 2048, 1), (1, 128, 0)]
+LN_CASES = [(1024, 1280, 3), (4096, 640, 1), (77, 640, 2), (5, 64, 3), (3, 2048, 1), (1, 128, 0),
+            (8193, 1280, 1), (8200, 640, 3), (8192, 128, 0)]     # two rows per wave (odd tail: one)
 
 
 @pytest.mark.parametrize("M,Cc,nq", LN_CASES)
