@@ -389,7 +389,16 @@ def main():
     unet = build_unet(device, cfg=TINY_CFG if args.tiny else None)
     fp16_meter = MemoryMeter(device)              # static = the FP16 network, resident
     inputs = example_inputs(B, L, device, seed=42 + rank)
-    ckpt = calibrate(unet, [inputs], bos=not args.no_bos)
+    # static per-tensor scales come from a calibration set, not from the batch that is served
+    # (the reference loads them from a checkpoint): two images of this rank's inputs -- the FP16
+    # calibration forward runs on MIOpen / hipBLASLt, whose per-shape kernel search at batch 64
+    # took longer than everything else in this file together
+    def first_rows(v, n):
+        if torch.is_tensor(v):
+            return v[:n] if v.dim() > 0 and v.shape[0] == B else v
+        return {a: first_rows(b, n) for a, b in v.items()} if isinstance(v, dict) else v
+    calib_inputs = {k: first_rows(v, 2) for k, v in inputs.items()} if B > 2 else inputs
+    ckpt = calibrate(unet, [calib_inputs], bos=not args.no_bos)
     bos_dict = precompute_bos(unet, inputs["encoder_hidden_states"])
 
     # --vary-timestep: the pipeline's sampling loop -- each step hands the UNet another timestep
@@ -493,7 +502,8 @@ def main():
         "scaling": "strong" if strong else "weak",
         "vs_baseline": None, "dtype": "int8", "data": "synthetic",
         "config": {
-            "workload": f"sdxl_turbo_unet_{kind}_{args.px}px_bs{global_batch if strong else B}"
+            "workload": ("TINY harness network (not the SDXL UNet), " if args.tiny else "") +
+                        f"sdxl_turbo_unet_{kind}_{args.px}px_bs{global_batch if strong else B}"
                         f"_{fpi}step" + ("_sharded" if strong else ""),
             "global_batch": global_batch, "per_gpu_batch": B, "px": args.px, "latent": L,
             "unet_forwards_per_image": fpi, "unet_rows_per_image": rows_per_image,

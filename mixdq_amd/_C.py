@@ -397,9 +397,10 @@ def geglu_row_order(D: int, device=None) -> torch.Tensor:
 
 
 def qlinear_geglu(input_int8, weight_int8, scale, bias0, bias, out_scale_inv, out_zero_point, *,
-                  _cfg=0, _w4=False):
+                  _cfg=0, _w4=False, _out=None):
     """int8 [..., K] x value/gate-interleaved W [2D, K] -> int8 [..., D]: ff.net.0.proj + GEGLU +
-    the quantizer of ff.net.2 in one launch (include/mixdq_hip.h: mixdq_qlinear_w8a8_geglu)."""
+    the quantizer of ff.net.2 in one launch (include/mixdq_hip.h: mixdq_qlinear_w8a8_geglu).
+    `_out`: a contiguous int8 tensor of the result's size to write into (8-byte aligned)."""
     _check(input_int8.is_cuda and input_int8.dtype == torch.int8, "input_int8 should be int8 on GPU")
     _check(weight_int8.dtype == torch.int8, "weight_int8 should be int8 type")
     N, K = weight_int8.size(0), weight_int8.size(1) * (2 if _w4 else 1)
@@ -407,7 +408,10 @@ def qlinear_geglu(input_int8, weight_int8, scale, bias0, bias, out_scale_inv, ou
     _check(scale.numel() == N and bias0.numel() == N, "scale and bias0 should have 2D elements")
     a, w = input_int8.contiguous(), weight_int8.contiguous()
     M = a.numel() // K if K else 0
-    out = torch.empty(list(input_int8.shape[:-1]) + [N // 2], dtype=torch.int8, device=a.device)
+    out = _out if _out is not None else torch.empty(list(input_int8.shape[:-1]) + [N // 2],
+                                                    dtype=torch.int8, device=a.device)
+    _check(out.dtype == torch.int8 and out.is_contiguous() and out.numel() == M * (N // 2),
+           "_out should be a contiguous int8 tensor of the result's size")
     sc, b0 = _f32vec(scale), _f32vec(bias0)
     bs = None if bias is None else bias.contiguous()
     _record("linear_geglu", M, N, K, K, _w4, qlinear_geglu,

@@ -159,6 +159,52 @@ inline int ensure_gelu_table(hipStream_t stream) {
   return MIXDQ_OK;
 }
 
+// Two GEGLU outputs at a time from packed fp16 pairs (value xw, gate gw) with the table in LDS:
+// the bytes q0 | q1 << 8 of quantize(f16(x * f16(gelu(g)))).  The epilogue is VALU-bound (one
+// workgroup per CU: nothing runs beside it), so the element chain is kept short:
+//   * NEAR (every |g| < 8, decided per wave for a run of elements): the table entry IS f16(gelu(g));
+//   * the product of two fp16 values is exact in FP32 (22 significant bits), so "FP32 multiply, round
+//     to fp16" is v_pk_mul_f16 -- one instruction for the pair (fp16 denormals are on);
+//   * the clamped integers are packed by v_perm_b32 (low byte of each), no masking.
+// Otherwise (some |g| >= 8 in the run, inf, NaN): g itself, or 0 * g for negative gates (-0; NaN for
+// -inf / NaN) -- the specification's values there -- selected on the bits (a NaN's payload does not
+// matter: the product is NaN and quantizes to 0).
+typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bool geglu_any_far(uint32_t g0, uint32_t g1, uint32_t g2, uint32_t g3) {
+  auto mags = [](uint32_t w) { return __builtin_bit_cast(v2u16, w & 0x7fff7fffu); };
+  const v2u16 m = __builtin_elementwise_max(__builtin_elementwise_max(mags(g0), mags(g1)),
+                                            __builtin_elementwise_max(mags(g2), mags(g3)));
+  return max((uint32_t)m[0], (uint32_t)m[1]) >= (uint32_t)kGeluTabMag;   // eight gates, any |g| >= 8
+}
+template <bool NEAR, bool UNFUSED>
+__device__ __forceinline__ uint32_t geglu_pair(uint32_t xw, uint32_t gw, const char* Tb, float s_inv,
+                                               float zpq) {
+  const uint32_t m0 = gw & 0x7fffu, n0 = (gw >> 15) & 1u, m1 = (gw >> 16) & 0x7fffu, n1 = gw >> 31;
+  const uint32_t i0 = n0 * kGeluTabMag + (NEAR ? m0 : min(m0, (uint32_t)kGeluTabMag - 1));
+  const uint32_t i1 = n1 * kGeluTabMag + (NEAR ? m1 : min(m1, (uint32_t)kGeluTabMag - 1));
+  uint32_t t0 = *reinterpret_cast<const uint16_t*>(Tb + 2 * i0);
+  uint32_t t1 = *reinterpret_cast<const uint16_t*>(Tb + 2 * i1);
+  if constexpr (!NEAR) {   // on the bits, branch-free: g | -0 | NaN (0 * -inf, 0 * NaN)
+    const uint32_t f0 = n0 ? (m0 >= 0x7c00u ? 0xfe00u : 0x8000u) : m0;
+    const uint32_t f1 = n1 ? (m1 >= 0x7c00u ? 0xfe00u : 0x8000u) : m1;
+    t0 = m0 >= (uint32_t)kGeluTabMag ? f0 : t0;
+    t1 = m1 >= (uint32_t)kGeluTabMag ? f1 : t1;
+  }
+  const v2h ge = __builtin_bit_cast(v2h, t0 | (t1 << 16));
+  v2h y = __builtin_bit_cast(v2h, xw) * ge;
+  asm("" : "+v"(y));
+  const int q0 = quantize_one<UNFUSED>((float)y[0], s_inv, zpq);
+  const int q1 = quantize_one<UNFUSED>((float)y[1], s_inv, zpq);
+  return __builtin_amdgcn_perm((uint32_t)q1, (uint32_t)q0, 0x0c0c0400u);
+}
+// four outputs: the bytes of one dword
+template <bool NEAR, bool UNFUSED>
+__device__ __forceinline__ uint32_t geglu_quad(uint2 xq, uint2 gq, const char* Tb, float s_inv, float zpq) {
+  const uint32_t lo = geglu_pair<NEAR, UNFUSED>(xq.x, gq.x, Tb, s_inv, zpq);
+  const uint32_t hi = geglu_pair<NEAR, UNFUSED>(xq.y, gq.y, Tb, s_inv, zpq);
+  return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
+}
+
 template <int BM, int BN, int BK, int STAGES>
 constexpr bool igemm_gelu_table_fits() {   // one workgroup per CU anyway, and room behind the fp16 tile
   return BN % 64 == 0 && STAGES * (BM + BN) * BK > 80 * 1024 &&
@@ -944,6 +990,115 @@ void igemm_kernel(const IgemmParams p_in) {
   // into one flat_load per register quad followed by vmcnt(0) -- twenty serial memory round trips,
   // 4.4 of the 26 us of the (1024, 10240, 1280) launch and ~1 us of every small GEMM; tools/
   // stamp_report.py.)
+  // ---- GEMM+GEGLU on the 256x256 four-phase tile, in registers.  A wave's 128x64 patch is one whole
+  //      value|gate group of 64 columns, and in the 16x16 accumulator layout the lane that holds value
+  //      columns c..c+3 (MFMA tile tn) holds gate columns c+32..c+35 (tile tn+2) of the same row: the
+  //      fp16 tile never goes through LDS.  What LDS holds instead: the GELU table (72 KB, DMA'd under
+  //      the accumulator -> fp16 pass) and the INT8 output tile (whole 128-byte rows for the stores).
+  //      Same rounding points as the staged form: GEMM -> fp16, gelu -> fp16, product -> fp16, quantize.
+  //      ((8192, 10240, 1280): 142 us with the staged arithmetic form on this tile, 152 on 256x128.)
+  if constexpr (PHASED) {
+    if (p.Dq != nullptr) {
+      constexpr int QS = BN / 2 + 16;             // INT8 tile row stride (bytes)
+      static_assert(WTN == 64 && MT == 16 && TN == 4 && ACC == 4, "one value|gate group per wave column");
+      static_assert((BM * QS) % 1024 == 0 && BM * QS + kGeluTabBytes <= STAGES * STAGE,
+                    "INT8 tile + GELU table fit the stage buffers");
+      char* Tb = smem + BM * QS;
+      {
+        constexpr int PIECES = kGeluTabBytes / 1024;
+        const char* src = reinterpret_cast<const char*>(g_gelu_tab);
+#pragma unroll
+        for (int j = 0; j < (PIECES + NWAVES - 1) / NWAVES; ++j) {
+          const int q = wid + NWAVES * j;
+          if (q < PIECES) glds16(src + q * 1024 + lane * 16, Tb + q * 1024);
+        }
+      }
+      const float s_inv = *p.g_sinv, zpq = *p.g_zp;
+      uint2 hq[TM][TN];                           // the wave's patch as packed fp16 quads
+      auto to_regs = [&](auto mode_c) {
+        constexpr int MODE = decltype(mode_c)::value;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) {
+            const int nl = wn * WTN + tn * MT + 4 * lkq;
+            const v4f b0 = *reinterpret_cast<const v4f*>(P_B0 + nl);
+            const v4f sc = *reinterpret_cast<const v4f*>(P_SC + nl);
+            v4f bs = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (MODE != 0)
+              bs = __builtin_convertvector(*reinterpret_cast<const v4h*>(P_BS + nl), v4f);
+            uint32_t packed[2];
+#pragma unroll
+            for (int e2 = 0; e2 < 2; ++e2) {
+              v2f x = {(float)acc[tn][tm][2 * e2], (float)acc[tn][tm][2 * e2 + 1]};
+              const v2f b0e = {b0[2 * e2], b0[2 * e2 + 1]};
+              const v2f sce = {sc[2 * e2], sc[2 * e2 + 1]};
+              const v2f bse = {bs[2 * e2], bs[2 * e2 + 1]};
+              v2f r;
+              x = x - b0e;
+              if constexpr (MODE == 0) r = x * sce;
+              else if constexpr (MODE == 2) r = x * sce + bse;
+              else r = __builtin_elementwise_fma(x, sce, bse);
+              asm("" : "+v"(r));
+              const v2h h = __builtin_convertvector(r, v2h);
+              packed[e2] = *reinterpret_cast<const uint32_t*>(&h);
+            }
+            hq[tm][tn] = make_uint2(packed[0], packed[1]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      if (!has_bias) to_regs(std::integral_constant<int, 0>{});
+      else if (!unfused) to_regs(std::integral_constant<int, 1>{});
+      else to_regs(std::integral_constant<int, 2>{});
+      MIXDQ_STAMP_AT(5);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                            // the table has landed, for every wave
+      MIXDQ_STAMP_AT(6);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int ml = wm * WTM + tm * MT + lrow;
+        const bool far = geglu_any_far(hq[tm][2].x, hq[tm][2].y, hq[tm][3].x, hq[tm][3].y);
+        uint32_t pk[2];
+        auto quads = [&](auto near_c, auto unf_c) {
+          constexpr bool NEAR = decltype(near_c)::value, UNF = decltype(unf_c)::value;
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn)
+            pk[tn] = geglu_quad<NEAR, UNF>(hq[tm][tn], hq[tm][tn + 2], Tb, s_inv, zpq);
+        };
+        if (__builtin_amdgcn_ballot_w64(far) == 0) {       // wave-uniform: the usual case
+          if (unfused) quads(std::true_type{}, std::true_type{}); else quads(std::true_type{}, std::false_type{});
+        } else {
+          if (unfused) quads(std::false_type{}, std::true_type{}); else quads(std::false_type{}, std::false_type{});
+        }
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+          *reinterpret_cast<uint32_t*>(smem + ml * QS + wn * 32 + tn * 16 + 4 * lkq) = pk[tn];
+      }
+      MIXDQ_STAMP_AT(10);
+      __syncthreads();
+      MIXDQ_STAMP_AT(11);
+      const int Dh = p.N >> 1;
+      const bool al16 = ((uintptr_t)p.Dq & 15) == 0;
+#pragma unroll
+      for (int it = 0; it < BM * 8 / NTHREADS; ++it) {
+        const int idx = tid + it * NTHREADS;
+        const int row = idx >> 3, cc = idx & 7;      // 16 outputs per chunk, two chunks per group
+        const int64_t m = m0 + row;
+        if (m >= p.M || n0 + 64 * (cc >> 1) >= p.N) continue;
+        const uint4 v = *reinterpret_cast<const uint4*>(smem + row * QS + cc * 16);
+        int8_t* dst = p.Dq + m * Dh + (n0 >> 1) + cc * 16;
+        if (al16) {
+          *reinterpret_cast<uint4*>(dst) = v;
+        } else {
+          *reinterpret_cast<uint2*>(dst) = make_uint2(v.x, v.y);
+          *reinterpret_cast<uint2*>(dst + 8) = make_uint2(v.z, v.w);
+        }
+      }
+      MIXDQ_STAMP_AT(7);
+      return;
+    }
+  }
   auto to_tile = [&](auto mode_c) {
     constexpr int MODE = decltype(mode_c)::value;   // 0: no bias, 1: bias (FMA / FP16 add), 2: bias, mul then add
 #pragma unroll
@@ -1191,29 +1346,30 @@ void igemm_kernel(const IgemmParams p_in) {
       const __half* xh = reinterpret_cast<const __half*>(&xv);
       const __half* gh = reinterpret_cast<const __half*>(&gv);
       uint32_t pk[2] = {0u, 0u};
+      if constexpr (GELU_TAB) {              // f16(gelu(g)) from the table in LDS (geglu_pair)
+        const char* Tb = smem + BM * CS_STRIDE;
+        const bool far = geglu_any_far(gv.x, gv.y, gv.z, gv.w);
+        auto quads = [&](auto near_c, auto unf_c) {
+          constexpr bool NEAR = decltype(near_c)::value, UNF = decltype(unf_c)::value;
+          pk[0] = geglu_quad<NEAR, UNF>(make_uint2(xv.x, xv.y), make_uint2(gv.x, gv.y), Tb, s_inv, zpq);
+          pk[1] = geglu_quad<NEAR, UNF>(make_uint2(xv.z, xv.w), make_uint2(gv.z, gv.w), Tb, s_inv, zpq);
+        };
+        if (__builtin_amdgcn_ballot_w64(far) == 0) {       // wave-uniform: the usual case
+          if (unfused) quads(std::true_type{}, std::true_type{}); else quads(std::true_type{}, std::false_type{});
+        } else {
+          if (unfused) quads(std::false_type{}, std::true_type{}); else quads(std::false_type{}, std::false_type{});
+        }
+      } else {
 #pragma unroll
-      for (int j = 0; j < 8; j += 2) {     // two gate values at a time
-        v2f g2;
-        if constexpr (GELU_TAB) {          // f16(gelu(g)) from the table in LDS
-          const uint16_t* T = reinterpret_cast<const uint16_t*>(smem + BM * CS_STRIDE);
+        for (int j = 0; j < 8; j += 2) {     // two gate values at a time
+          const v2f g2 = geluf2(v2f{__half2float(gh[j]), __half2float(gh[j + 1])});
 #pragma unroll
           for (int e = 0; e < 2; ++e) {
-            const unsigned u = __half_as_ushort(gh[j + e]);
-            const unsigned mag = u & 0x7fffu, neg = u >> 15;
-            const float g = __half2float(gh[j + e]);
-            const float tv = __half2float(__ushort_as_half(T[neg * kGeluTabMag + min(mag, (unsigned)kGeluTabMag - 1)]));
-            const float far = neg ? __fmul_rn(0.0f, g) : g;     // |g| >= 8: g, -0; inf / NaN as the formula
-            g2[e] = mag < (unsigned)kGeluTabMag ? tv : far;
+            const float ge = __half2float(f32_to_f16_rn(g2[e]));
+            const float y = __half2float(f32_to_f16_rn(__fmul_rn(__half2float(xh[j + e]), ge)));
+            const int q = unfused ? quantize_one<true>(y, s_inv, zpq) : quantize_one<false>(y, s_inv, zpq);
+            pk[(j + e) >> 2] |= (uint32_t)(q & 0xff) << (8 * ((j + e) & 3));
           }
-        } else {
-          g2 = geluf2(v2f{__half2float(gh[j]), __half2float(gh[j + 1])});
-        }
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          const float ge = __half2float(f32_to_f16_rn(g2[e]));
-          const float y = __half2float(f32_to_f16_rn(__fmul_rn(__half2float(xh[j + e]), ge)));
-          const int q = unfused ? quantize_one<true>(y, s_inv, zpq) : quantize_one<false>(y, s_inv, zpq);
-          pk[(j + e) >> 2] |= (uint32_t)(q & 0xff) << (8 * ((j + e) & 3));
         }
       }
       *reinterpret_cast<uint2*>(p.Dq + m * Dh + oc) = make_uint2(pk[0], pk[1]);
@@ -1474,6 +1630,7 @@ int launch_tile(IgemmParams& p, hipStream_t stream) {
   X(44, 128, 80, 128, 3, 4, 1, 2, 16, false)     \
   X(45, 64, 80, 128, 4, 4, 1, 2, 16, false)      \
   X(46, 128, 320, 64, 4, 4, 2, 1, 32, false)     \
+  X(47, 128, 320, 64, 5, 4, 2, 1, 32, false)     \
   X(56, 64, 80, 128, 6, 4, 1, 2, 16, false)  \
   X(70, 256, 256, 128, 2, 2, 4, 1, 16, true)   \
   X(71, 256, 256, 64, 4, 2, 4, 1, 16, true)
@@ -1539,9 +1696,11 @@ inline int select_cfg(int64_t M, int N, int Ktot, bool whole64 = false, bool pha
   // from 1.5 workgroups of 256x256 per CU on: the four-phase loop (fewest L2->LDS bytes per MAC, the
   // reads and the DMA of one wave group under the other's MFMAs): (8192, 10240, 1280) 135 vs 153 us on
   // 256x128, (8192, 3840, 1280) 56 vs 62, (32768, 1920, 640) 77 vs 84 (tools/bench_gemm.py --bs 8)
-  // (not for GEMM+GEGLU: with one workgroup per CU nothing runs under the GELU epilogue of a 256x256
-  // tile -- batch 8 step 59.1 ms with those launches on it, 57.1 with them on 256x128)
-  if (phased_ok && !whole64 && Ktot >= 640 && 2 * blocks(256, 256) >= 3 * kNumCU) return 70;
+  // GEMM+GEGLU too, since its epilogue on this tile runs in registers (value and gate of an output sit
+  // in the same lane; GELU by table): (8192, 10240, 1280) 117 vs 150 us on 256x128, (32768, 5120, 640)
+  // 164 vs 202, (4096, 10240, 1280) 68 vs 79.  (With the staged arithmetic epilogue of round 2 the
+  // 256x128 tile won: two workgroups per CU hid part of it.)
+  if (phased_ok && Ktot >= 640 && 2 * blocks(256, 256) >= 3 * kNumCU) return 70;
   if (blocks(256, 128) >= 2 * kNumCU)
     return (Ktot >= 4096 && blocks(256, 256) >= kNumCU) ? 20 : 13;
   // exact-fit 16x16x64-MFMA tiles (tools/bench_gemm.py, batch 1): 128x80 when that is exactly one

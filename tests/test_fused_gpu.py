@@ -220,6 +220,49 @@ def test_qlinear_geglu_equals_gemm_then_geglu_quantize(C, oracle, case):
     assert torch.equal(got, q2)
 
 
+@pytest.mark.parametrize("cfg", [70, 25, 13])
+def test_qlinear_geglu_into_an_8_byte_aligned_output(C, oracle, cfg):
+    """The entry point asks for 8-byte alignment of the INT8 output only; the register epilogue of the
+    256x256 tile stores 16 bytes at a time when it can and 2 x 8 otherwise.  Same bits either way."""
+    M, D, K = 300, 320, 256
+    a, w = dd.int8(61, (M, K)), dd.int8(62, (2 * D, K))
+    scale, bias0 = dd.f32(63, (2 * D,), 2e-4, 9e-4), dd.f32(64, (2 * D,), -300, 300)
+    s_inv, zp = float(np.float32(1) / np.float32(0.02)), -60.0
+    perm = C.geglu_row_order(D, DEV)
+    args = (t(a), t(w)[perm].contiguous(), t(scale)[perm].contiguous(), t(bias0)[perm].contiguous(), None,
+            scal(s_inv), scal(zp))
+    want = C.qlinear_geglu(*args, _cfg=cfg)
+    buf = torch.full((M * D + 24,), 77, dtype=torch.int8, device=DEV)
+    out = buf[8:8 + M * D].view(M, D)
+    assert out.data_ptr() % 16 == 8
+    got = C.qlinear_geglu(*args, _cfg=cfg, _out=out)
+    assert got.data_ptr() == out.data_ptr() and torch.equal(got, want)
+    assert (buf[:8] == 77).all() and (buf[8 + M * D:] == 77).all()      # nothing written outside
+    h = oracle.qlinear(a, w, bias0, scale, None, C.FLAGS & 1)
+    assert np.array_equal(want.cpu().numpy(), oracle.geglu_quantize(h, s_inv, zp, C.FLAGS & 1)[0])
+
+
+@pytest.mark.parametrize("cfg", [70, 25, 13, 0])
+def test_qlinear_geglu_with_overflowing_and_nan_columns(C, oracle, cfg):
+    """Gates and values beyond the GELU table's range, +-inf (fp16 overflow of the GEMM output) and NaN
+    (a NaN bias0): the table epilogues select g / -0 / NaN on the bits there -- same INT8 tensor as
+    the oracle's chain, in the same launch as ordinary columns."""
+    M, D, K = 300, 320, 256
+    a, w = dd.int8(71, (M, K)), dd.int8(72, (2 * D, K))
+    scale, bias0 = dd.f32(73, (2 * D,), 2e-4, 9e-4), dd.f32(74, (2 * D,), -300, 300)
+    scale[D + 3], scale[D + 40], scale[7], scale[D + 100] = 10.0, 1e-2, 10.0, 4e-3   # gate inf / large, value inf
+    bias0[D + 11], bias0[19] = np.nan, np.nan                                         # NaN gate, NaN value
+    s_inv, zp = float(np.float32(1) / np.float32(0.02)), -60.0
+    with np.errstate(all="ignore"):
+        h = oracle.qlinear(a, w, bias0, scale, None, C.FLAGS & 1)
+        q_ref, _ = oracle.geglu_quantize(h, s_inv, zp, C.FLAGS & 1)
+    assert np.isinf(h[:, D + 3]).any() and np.isnan(h[:, D + 11]).all() and (np.abs(h[:, D + 40]) > 8).any()
+    perm = C.geglu_row_order(D, DEV)
+    got = C.qlinear_geglu(t(a), t(w)[perm].contiguous(), t(scale)[perm].contiguous(),
+                          t(bias0)[perm].contiguous(), None, scal(s_inv), scal(zp), _cfg=cfg)
+    assert np.array_equal(got.cpu().numpy(), q_ref)
+
+
 def test_qlinear_geglu_rejects_tiles_without_whole_value_gate_groups(C):
     """BN % 64 != 0 tiles (the 16x16x64-MFMA exact-fit tiles) cannot hold whole (value, gate) groups
     of 32: forcing one is an error, not a wrong result."""

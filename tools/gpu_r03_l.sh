@@ -1,11 +1,34 @@
 #!/bin/bash
+# Round-3 experiment L: GEMM+GEGLU in registers on the four-phase 256x256 tile -- parity, time, stamps.
 out=gpurun_out/r03_l
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
-( time timeout 1200 python -m pytest tests/test_fused_gpu.py tests/test_ops_gpu.py tests/test_modules_gpu.py -q -x ) > $out/pytest.log 2>&1
-tail -6 $out/pytest.log
-S=$PWD/build/stamp/libmixdq_stamp.so
-for args in "1024 10240 1280 --geglu" "8192 10240 1280 --geglu --cfg 18"; do
-  echo "== $args"; MIXDQ_HIP_LIB=$S timeout 300 python tools/stamp_report.py $args 2>&1 | grep -v amdgpu.ids | tail -2
+timeout 900 python -m pytest tests/test_fused_gpu.py tests/test_large_gpu.py -q -m gpu -k "geglu" -x 2>&1 | tail -8 > $out/pytest.txt
+MIXDQ_EPILOGUE_VARIANT=B timeout 900 python -m pytest tests/test_fused_gpu.py -q -m gpu -k "geglu" -x 2>&1 | tail -4 >> $out/pytest.txt
+python - > $out/geglu_cfgs.txt 2>&1 <<'PY'
+import sys, torch
+sys.path.insert(0, '.')
+import mixdq_amd._C as C
+from tools.bench_floor import timed
+g = torch.Generator(device="cpu").manual_seed(0)
+one, z = torch.ones((), device="cuda"), torch.zeros((), device="cuda")
+for (M, N, K), cfgs in (((8192, 10240, 1280), (0, 13, 70, 71)), ((16384, 10240, 1280), (0, 13, 70)), ((32768, 5120, 640), (0, 13, 70)),
+                        ((65536, 5120, 640), (0, 13, 70)), ((4096, 10240, 1280), (0, 13, 70, 25)), ((2048, 10240, 1280), (0, 13, 70, 25)), ((1024, 10240, 1280), (0, 25)), ((4096, 5120, 640), (0, 25))):
+    a = torch.randint(-128, 128, (M, K), generator=g, dtype=torch.int8).cuda()
+    w = torch.randint(-128, 128, (N, K), generator=g, dtype=torch.int8).cuda()
+    sc = torch.rand(N, generator=g).cuda() * 1e-4
+    row = {}
+    for cfg in cfgs:
+        try:
+            row[cfg] = round(timed(lambda: C.qlinear_geglu(a, w, sc, sc, None, one, z, _cfg=cfg), 50), 2)
+        except RuntimeError as e:
+            row[cfg] = str(e)[:30]
+    plain = round(timed(lambda: C.qlinear_w8_a8_ohalf(a, w, sc, z, z, sc, sc, sc, None), 50), 2)
+    print((M, N, K), "geglu:", row, "| plain auto:", plain, "| auto id", C.igemm_select_id(M, N, K, geglu=True), flush=True)
+PY
+export MIXDQ_HIP_LIB=$PWD/build/stamp/libmixdq_stamp.so
+for spec in "8192 10240 1280 --geglu --cfg 70" "1024 10240 1280 --geglu --cfg 25"; do
+  echo "== $spec" >> $out/stamps.txt
+  timeout 300 python tools/stamp_report.py $spec 2>&1 | grep -v amdgpu.ids >> $out/stamps.txt
 done
-for bs in 1 8; do timeout 600 python tools/bench_geglu.py $bs 2>&1 | grep -v amdgpu.ids; done
+cat $out/pytest.txt $out/geglu_cfgs.txt $out/stamps.txt

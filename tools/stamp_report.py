@@ -5,7 +5,8 @@
 
 Slots: 0 entry | 1 prologue DMA issued | 2 first K-tile landed | 3 main loop done (this wave) | 4 past
 the barrier behind the main loop | 5 accumulators -> fp16 tile in LDS (this wave) | 6 past the barrier
-behind it | 7 stores / GEGLU done.  The shader clocks of different XCDs are not synchronised, so every
+behind it | 7 stores / GEGLU done | 10, 11 (register GEGLU of the 256x256 tile): INT8 tile written, past
+the barrier behind it.  The shader clocks of different XCDs are not synchronised, so every
 time is taken relative to the workgroup's own earliest entry stamp; printed per slot: the median over
 workgroups of the FIRST and of the LAST wave to reach it, in us (shader clock / 100 MHz real-time)."""
 import argparse
@@ -86,7 +87,7 @@ def main():
         ok = dt_rt > 0
         ghz = float(np.median(dt_clk[ok] / dt_rt[ok])) * 0.1 if ok.any() else 2.0
         parts = []
-        for slot in (1, 2, 3, 4, 5, 6, 7):
+        for slot in (1, 2, 3, 4, 5, 6, 10, 11, 7):
             v = s[:, :, slot]
             have = used & (v != 0)
             if not have.any():
