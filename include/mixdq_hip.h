@@ -31,8 +31,9 @@ extern "C" {
 
 /* 1: round 1.  2: status codes 5..9 returned where 1 returned MIXDQ_ERR_UNSUPPORTED; structs and
  * entry points added since (grouped / GEGLU / attention launches, FP16 layers, producer fusions).
- * Bumped whenever an existing entry point changes its signature or its error behaviour. */
-#define MIXDQ_ABI_VERSION 2
+ * 3: mixdq_qlinear_w8a8_geglu takes its weight rows in value|gate groups of 16 (was 32) and N % 32.
+ * Bumped whenever an existing entry point changes its signature, operand layout or error behaviour. */
+#define MIXDQ_ABI_VERSION 3
 
 typedef void* mixdq_stream_t; /* hipStream_t */
 
@@ -46,7 +47,7 @@ enum mixdq_status {
   /* codes 5.. have no reference counterpart: limits of entry points the reference does not have */
   MIXDQ_ERR_W4_SHAPE = 5,        /* MIXDQ_FLAG_W4: K % 32 != 0 (conv: C % 32) or an operand pointer
                                     not 16-byte aligned                                           */
-  MIXDQ_ERR_GEGLU_SHAPE = 6,     /* mixdq_qlinear_w8a8_geglu: N % 64, K % 16 or pointer alignment */
+  MIXDQ_ERR_GEGLU_SHAPE = 6,     /* mixdq_qlinear_w8a8_geglu: N % 32, K % 16 or pointer alignment */
   MIXDQ_ERR_PADDING = 7,         /* conv: padding >= kernel size (a window with no in-image tap)  */
   MIXDQ_ERR_ROWMAP_RESIDUAL = 8, /* output row map and residual in one call                       */
   MIXDQ_ERR_SHAPE = 9            /* shape outside a fused kernel's range (head_dim != 64, GroupNorm
@@ -287,12 +288,13 @@ int mixdq_qlinear_w8a8_grouped(const int8_t* A, const mixdq_gemm_group* groups_d
                                int group_offset, int flags, mixdq_stream_t stream);
 
 /* ff.net.0.proj + GEGLU + quantize in one launch: the GEMM of mixdq_qlinear_w8a8 whose N = 2D
- * output columns arrive as value/gate groups of 32 ([v 0..31 | g 0..31 | v 32..63 | g 32..63 ...]:
- * the caller stores W, bias0, scale and bias with rows in that order), reduced in the epilogue to
+ * output columns arrive as value|gate groups of 16 ([v 0..15 | g 0..15 | v 16..31 | g 16..31 ...]:
+ * the caller stores W, bias0, scale and bias with rows in that order -- then every 32-column MFMA
+ * tile holds the value and the gate of 16 outputs, in the same lanes), reduced in the epilogue to
  * out[m, d] = sat8(rint(y * scale_inv + zero_point)), y = f16(f16(v) * f16(gelu(f16(g)))) -- every
  * rounding point of GEMM -> fp16 -> mixdq_geglu_quantize is kept, so the int8 [M, D] result is
  * bit-identical to that two-launch chain (diffusers GEGLU: hidden, gate = proj(x).chunk(2);
- * hidden * gelu(gate)).  N % 64 == 0, K % 16 == 0 (MIXDQ_ERR_GEGLU_SHAPE otherwise). */
+ * hidden * gelu(gate)).  N % 32 == 0, K % 16 == 0 (MIXDQ_ERR_GEGLU_SHAPE otherwise). */
 int mixdq_qlinear_w8a8_geglu(const int8_t* A, const int8_t* W_interleaved, const float* bias0,
                              const float* scale, const void* bias_f16_or_null, int8_t* out_i8,
                              int64_t M, int N, int K, const float* out_scale_inv,

@@ -390,9 +390,9 @@ def gelu_table(device="cuda") -> torch.Tensor:
 
 
 def geglu_row_order(D: int, device=None) -> torch.Tensor:
-    """Row order of mixdq_qlinear_w8a8_geglu's weight: value/gate groups of 32.  perm[i] = the row
+    """Row order of mixdq_qlinear_w8a8_geglu's weight: value|gate groups of 16.  perm[i] = the row
     of the ordinary [2D, K] GEGLU projection (values 0..D-1, gates D..2D-1) stored at row i."""
-    g = torch.arange(D // 32, device=device)[:, None] * 32 + torch.arange(32, device=device)[None, :]
+    g = torch.arange(D // 16, device=device)[:, None] * 16 + torch.arange(16, device=device)[None, :]
     return torch.stack([g, g + D], dim=1).reshape(-1)
 
 

@@ -159,16 +159,18 @@ inline int ensure_gelu_table(hipStream_t stream) {
   return MIXDQ_OK;
 }
 
-// Two GEGLU outputs at a time from packed fp16 pairs (value xw, gate gw) with the table in LDS:
-// the bytes q0 | q1 << 8 of quantize(f16(x * f16(gelu(g)))).  The epilogue is VALU-bound (one
-// workgroup per CU: nothing runs beside it), so the element chain is kept short:
-//   * NEAR (every |g| < 8, decided per wave for a run of elements): the table entry IS f16(gelu(g));
+// Two GEGLU outputs at a time from packed fp16 pairs (value xw, gate gw): the bytes q0 | q1 << 8 of
+// quantize(f16(x * f16(gelu(g)))).  The epilogue is VALU-bound (with one workgroup per CU nothing runs
+// beside it), so the element chain is kept short:
+//   * HOW = 0, table in LDS, every |g| < 8 (decided per wave for a run of elements): the entry IS
+//     f16(gelu(g));
+//   * HOW = 1, table in LDS, some |g| >= 8 / inf / NaN in the run: g itself, or 0 * g for negative
+//     gates (-0; NaN for -inf / NaN) -- the specification's values there -- selected on the bits,
+//     branch-free (a NaN's payload does not matter: the product is NaN and quantizes to 0);
+//   * HOW = 2, no table (tiles that share their CU): the arithmetic of include/mixdq_math.h;
 //   * the product of two fp16 values is exact in FP32 (22 significant bits), so "FP32 multiply, round
 //     to fp16" is v_pk_mul_f16 -- one instruction for the pair (fp16 denormals are on);
 //   * the clamped integers are packed by v_perm_b32 (low byte of each), no masking.
-// Otherwise (some |g| >= 8 in the run, inf, NaN): g itself, or 0 * g for negative gates (-0; NaN for
-// -inf / NaN) -- the specification's values there -- selected on the bits (a NaN's payload does not
-// matter: the product is NaN and quantizes to 0).
 typedef unsigned short v2u16 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ bool geglu_any_far(uint32_t g0, uint32_t g1, uint32_t g2, uint32_t g3) {
   auto mags = [](uint32_t w) { return __builtin_bit_cast(v2u16, w & 0x7fff7fffu); };
@@ -176,21 +178,28 @@ __device__ __forceinline__ bool geglu_any_far(uint32_t g0, uint32_t g1, uint32_t
                                             __builtin_elementwise_max(mags(g2), mags(g3)));
   return max((uint32_t)m[0], (uint32_t)m[1]) >= (uint32_t)kGeluTabMag;   // eight gates, any |g| >= 8
 }
-template <bool NEAR, bool UNFUSED>
+template <int HOW, bool UNFUSED>
 __device__ __forceinline__ uint32_t geglu_pair(uint32_t xw, uint32_t gw, const char* Tb, float s_inv,
                                                float zpq) {
-  const uint32_t m0 = gw & 0x7fffu, n0 = (gw >> 15) & 1u, m1 = (gw >> 16) & 0x7fffu, n1 = gw >> 31;
-  const uint32_t i0 = n0 * kGeluTabMag + (NEAR ? m0 : min(m0, (uint32_t)kGeluTabMag - 1));
-  const uint32_t i1 = n1 * kGeluTabMag + (NEAR ? m1 : min(m1, (uint32_t)kGeluTabMag - 1));
-  uint32_t t0 = *reinterpret_cast<const uint16_t*>(Tb + 2 * i0);
-  uint32_t t1 = *reinterpret_cast<const uint16_t*>(Tb + 2 * i1);
-  if constexpr (!NEAR) {   // on the bits, branch-free: g | -0 | NaN (0 * -inf, 0 * NaN)
-    const uint32_t f0 = n0 ? (m0 >= 0x7c00u ? 0xfe00u : 0x8000u) : m0;
-    const uint32_t f1 = n1 ? (m1 >= 0x7c00u ? 0xfe00u : 0x8000u) : m1;
-    t0 = m0 >= (uint32_t)kGeluTabMag ? f0 : t0;
-    t1 = m1 >= (uint32_t)kGeluTabMag ? f1 : t1;
+  v2h ge;
+  if constexpr (HOW == 2) {
+    const v2h gh = __builtin_bit_cast(v2h, gw);
+    const v2f g2 = geluf2(v2f{(float)gh[0], (float)gh[1]});
+    ge = v2h{(_Float16)f32_to_f16_rn(g2[0]), (_Float16)f32_to_f16_rn(g2[1])};
+  } else {
+    const uint32_t m0 = gw & 0x7fffu, n0 = (gw >> 15) & 1u, m1 = (gw >> 16) & 0x7fffu, n1 = gw >> 31;
+    const uint32_t i0 = n0 * kGeluTabMag + (HOW == 0 ? m0 : min(m0, (uint32_t)kGeluTabMag - 1));
+    const uint32_t i1 = n1 * kGeluTabMag + (HOW == 0 ? m1 : min(m1, (uint32_t)kGeluTabMag - 1));
+    uint32_t t0 = *reinterpret_cast<const uint16_t*>(Tb + 2 * i0);
+    uint32_t t1 = *reinterpret_cast<const uint16_t*>(Tb + 2 * i1);
+    if constexpr (HOW == 1) {
+      const uint32_t f0 = n0 ? (m0 >= 0x7c00u ? 0xfe00u : 0x8000u) : m0;
+      const uint32_t f1 = n1 ? (m1 >= 0x7c00u ? 0xfe00u : 0x8000u) : m1;
+      t0 = m0 >= (uint32_t)kGeluTabMag ? f0 : t0;
+      t1 = m1 >= (uint32_t)kGeluTabMag ? f1 : t1;
+    }
+    ge = __builtin_bit_cast(v2h, t0 | (t1 << 16));
   }
-  const v2h ge = __builtin_bit_cast(v2h, t0 | (t1 << 16));
   v2h y = __builtin_bit_cast(v2h, xw) * ge;
   asm("" : "+v"(y));
   const int q0 = quantize_one<UNFUSED>((float)y[0], s_inv, zpq);
@@ -198,26 +207,26 @@ __device__ __forceinline__ uint32_t geglu_pair(uint32_t xw, uint32_t gw, const c
   return __builtin_amdgcn_perm((uint32_t)q1, (uint32_t)q0, 0x0c0c0400u);
 }
 // four outputs: the bytes of one dword
-template <bool NEAR, bool UNFUSED>
+template <int HOW, bool UNFUSED>
 __device__ __forceinline__ uint32_t geglu_quad(uint2 xq, uint2 gq, const char* Tb, float s_inv, float zpq) {
-  const uint32_t lo = geglu_pair<NEAR, UNFUSED>(xq.x, gq.x, Tb, s_inv, zpq);
-  const uint32_t hi = geglu_pair<NEAR, UNFUSED>(xq.y, gq.y, Tb, s_inv, zpq);
+  const uint32_t lo = geglu_pair<HOW, UNFUSED>(xq.x, gq.x, Tb, s_inv, zpq);
+  const uint32_t hi = geglu_pair<HOW, UNFUSED>(xq.y, gq.y, Tb, s_inv, zpq);
   return __builtin_amdgcn_perm(hi, lo, 0x05040100u);
 }
 
+// The GEGLU epilogue's LDS: the INT8 output tile (rows of BN / 2 bytes + 16) and, for the tiles that have
+// their CU to themselves anyway (stages > 80 KB), the GELU table behind it -- both inside the K-tile
+// stage buffers, which are free by then.
+constexpr int geglu_tile_bytes(int BM, int BN) { return (BM * (BN / 2 + 16) + 1023) / 1024 * 1024; }
 template <int BM, int BN, int BK, int STAGES>
-constexpr bool igemm_gelu_table_fits() {   // one workgroup per CU anyway, and room behind the fp16 tile
-  return BN % 64 == 0 && STAGES * (BM + BN) * BK > 80 * 1024 &&
-         BM * (BN * 2 + 16) + kGeluTabBytes + BN * 12 <= 160 * 1024;
+constexpr bool igemm_gelu_table_fits() {
+  return BN % 32 == 0 && STAGES * (BM + BN) * BK > 80 * 1024 &&
+         geglu_tile_bytes(BM, BN) + kGeluTabBytes <= STAGES * (BM + BN) * BK;
 }
 
 template <int BM, int BN, int BK, int STAGES>
-constexpr int igemm_main_bytes() {   // K-tile stages, overlaid by the epilogue's fp16 tile (+ GELU table)
-  int m = (STAGES * (BM + BN) * BK > BM * (BN * 2 + 16)) ? STAGES * (BM + BN) * BK
-                                                         : BM * (BN * 2 + 16);
-  if (igemm_gelu_table_fits<BM, BN, BK, STAGES>() && m < BM * (BN * 2 + 16) + kGeluTabBytes)
-    m = BM * (BN * 2 + 16) + kGeluTabBytes;
-  return m;
+constexpr int igemm_main_bytes() {   // K-tile stages, overlaid by the epilogue's fp16 tile
+  return (STAGES * (BM + BN) * BK > BM * (BN * 2 + 16)) ? STAGES * (BM + BN) * BK : BM * (BN * 2 + 16);
 }
 template <int BM, int BN, int BK, int STAGES>
 constexpr int igemm_smem_bytes() {   // + the per-channel epilogue vectors: bias0, scale, bias
@@ -936,19 +945,6 @@ void igemm_kernel(const IgemmParams p_in) {
   // ---- epilogue: registers -> f16 tile in LDS -> whole-row 16-byte stores --------------------
   __syncthreads();   // every wave is done reading the stage buffers
   MIXDQ_STAMP_AT(4);
-  constexpr bool GELU_TAB = igemm_gelu_table_fits<BM, BN, BK, STAGES>() && !CONV && !F16 && !ATT &&
-                            !GROUPED && KSPLIT == 1;
-  if constexpr (GELU_TAB) {
-    if (p.Dq != nullptr) {   // GELU table -> LDS behind the fp16 tile, under the accumulator pass
-      constexpr int PIECES = kGeluTabBytes / 1024;
-      const char* src = reinterpret_cast<const char*>(g_gelu_tab);
-#pragma unroll
-      for (int j = 0; j < (PIECES + NWAVES - 1) / NWAVES; ++j) {
-        const int q = wid + NWAVES * j;
-        if (q < PIECES) glds16(src + q * 1024 + lane * 16, smem + BM * CS_STRIDE + q * 1024);
-      }
-    }
-  }
   if constexpr (KSPLIT > 1) {
     // groups 1.. park their partial accumulators (behind the fp16 tile's area), group 0 adds them
     constexpr int WREGS = TN * TM * ACC;          // accumulator registers of one wave
@@ -990,102 +986,142 @@ void igemm_kernel(const IgemmParams p_in) {
   // into one flat_load per register quad followed by vmcnt(0) -- twenty serial memory round trips,
   // 4.4 of the 26 us of the (1024, 10240, 1280) launch and ~1 us of every small GEMM; tools/
   // stamp_report.py.)
-  // ---- GEMM+GEGLU on the 256x256 four-phase tile, in registers.  A wave's 128x64 patch is one whole
-  //      value|gate group of 64 columns, and in the 16x16 accumulator layout the lane that holds value
-  //      columns c..c+3 (MFMA tile tn) holds gate columns c+32..c+35 (tile tn+2) of the same row: the
-  //      fp16 tile never goes through LDS.  What LDS holds instead: the GELU table (72 KB, DMA'd under
-  //      the accumulator -> fp16 pass) and the INT8 output tile (whole 128-byte rows for the stores).
-  //      Same rounding points as the staged form: GEMM -> fp16, gelu -> fp16, product -> fp16, quantize.
-  //      ((8192, 10240, 1280): 142 us with the staged arithmetic form on this tile, 152 on 256x128.)
-  if constexpr (PHASED) {
+  // ---- GEMM + GEGLU + quantize, in registers.  The weight rows arrive as value|gate groups of 16
+  //      ([v 0..15 | g 0..15 | v 16..31 | ...], include/mixdq_hip.h), so every 32-column MFMA tile (or
+  //      pair of 16-column tiles) holds whole groups, and in the accumulator layout the lane that holds
+  //      value columns c..c+3 of a row holds gate columns c+16..c+19 of it too: the fp16 tile never
+  //      goes through LDS.  What LDS holds instead: the INT8 output tile (whole rows for the stores)
+  //      and -- on the tiles that have their CU to themselves -- the GELU table (72 KB, DMA'd under the
+  //      accumulator -> fp16 pass).  Every rounding point of the unfused chain (GEMM -> fp16, gelu ->
+  //      fp16, product -> fp16, quantize) is kept: the INT8 tensor is the one mixdq_geglu_quantize
+  //      produces from this GEMM's fp16 output.  ((8192, 10240, 1280) on the 256x256 tile: 117 us;
+  //      142 with the fp16 tile staged through LDS and GELU computed, as round 2 did.)
+  if constexpr (BN % 32 == 0 && !CONV && !F16 && !ATT && !GROUPED) {
     if (p.Dq != nullptr) {
       constexpr int QS = BN / 2 + 16;             // INT8 tile row stride (bytes)
-      static_assert(WTN == 64 && MT == 16 && TN == 4 && ACC == 4, "one value|gate group per wave column");
-      static_assert((BM * QS) % 1024 == 0 && BM * QS + kGeluTabBytes <= STAGES * STAGE,
-                    "INT8 tile + GELU table fit the stage buffers");
-      char* Tb = smem + BM * QS;
-      {
+      constexpr bool TAB = igemm_gelu_table_fits<BM, BN, BK, STAGES>();
+      constexpr int OQ = MT == 32 ? 2 * TN : TN / 2;   // output quads (4 consecutive channels) per row
+      static_assert(WTN % 32 == 0 && (MT == 32 || TN % 2 == 0), "whole value|gate groups per wave");
+      static_assert(BM * QS <= igemm_main_bytes<BM, BN, BK, STAGES>(), "INT8 tile fits");
+      const char* Tb = smem + geglu_tile_bytes(BM, BN);
+      if constexpr (TAB) {
         constexpr int PIECES = kGeluTabBytes / 1024;
         const char* src = reinterpret_cast<const char*>(g_gelu_tab);
 #pragma unroll
         for (int j = 0; j < (PIECES + NWAVES - 1) / NWAVES; ++j) {
           const int q = wid + NWAVES * j;
-          if (q < PIECES) glds16(src + q * 1024 + lane * 16, Tb + q * 1024);
+          if (q < PIECES) glds16(src + q * 1024 + lane * 16, smem + geglu_tile_bytes(BM, BN) + q * 1024);
         }
       }
       const float s_inv = *p.g_sinv, zpq = *p.g_zp;
-      uint2 hq[TM][TN];                           // the wave's patch as packed fp16 quads
-      auto to_regs = [&](auto mode_c) {
-        constexpr int MODE = decltype(mode_c)::value;
+      // output quad oq of MFMA row-tile tm: tile-local value column (the gate is 16 further) and the
+      // accumulator quads that hold them
+      auto vcol = [&](int oq) {
+        return MT == 32 ? wn * WTN + (oq >> 1) * 32 + 8 * (oq & 1) + 4 * lkq : wn * WTN + oq * 32 + 4 * lkq;
+      };
+      uint2 hv[TM][OQ], hg[TM][OQ];               // the wave's patch as packed fp16 quads
+      auto to_regs = [&](auto mode_c, int tm) {   // MFMA row-tile tm of the patch
+        constexpr int MODE = decltype(mode_c)::value;   // as to_tile below
+        {
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
+          for (int oq = 0; oq < OQ; ++oq) {
 #pragma unroll
-          for (int tn = 0; tn < TN; ++tn) {
-            const int nl = wn * WTN + tn * MT + 4 * lkq;
-            const v4f b0 = *reinterpret_cast<const v4f*>(P_B0 + nl);
-            const v4f sc = *reinterpret_cast<const v4f*>(P_SC + nl);
-            v4f bs = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (MODE != 0)
-              bs = __builtin_convertvector(*reinterpret_cast<const v4h*>(P_BS + nl), v4f);
-            uint32_t packed[2];
+            for (int half = 0; half < 2; ++half) {      // value quad, gate quad
+              const int nl = vcol(oq) + 16 * half;
+              const int tn = MT == 32 ? (oq >> 1) : 2 * oq + half;
+              const int e0 = MT == 32 ? 4 * ((oq & 1) + 2 * half) : 0;
+              v4f b0 = *reinterpret_cast<const v4f*>(P_B0 + nl);
+              v4f sc = *reinterpret_cast<const v4f*>(P_SC + nl);
+              if constexpr (W4) { b0 = b0 * 16.0f; sc = sc * 0.0625f; }   // exact: the MFMA ran on 16*q
+              v4f bs = {0.f, 0.f, 0.f, 0.f};
+              if constexpr (MODE != 0)
+                bs = __builtin_convertvector(*reinterpret_cast<const v4h*>(P_BS + nl), v4f);
+              uint32_t packed[2];
 #pragma unroll
-            for (int e2 = 0; e2 < 2; ++e2) {
-              v2f x = {(float)acc[tn][tm][2 * e2], (float)acc[tn][tm][2 * e2 + 1]};
-              const v2f b0e = {b0[2 * e2], b0[2 * e2 + 1]};
-              const v2f sce = {sc[2 * e2], sc[2 * e2 + 1]};
-              const v2f bse = {bs[2 * e2], bs[2 * e2 + 1]};
-              v2f r;
-              x = x - b0e;
-              if constexpr (MODE == 0) r = x * sce;
-              else if constexpr (MODE == 2) r = x * sce + bse;
-              else r = __builtin_elementwise_fma(x, sce, bse);
-              asm("" : "+v"(r));
-              const v2h h = __builtin_convertvector(r, v2h);
-              packed[e2] = *reinterpret_cast<const uint32_t*>(&h);
+              for (int e2 = 0; e2 < 2; ++e2) {
+                v2f x = {(float)acc[tn][tm][e0 + 2 * e2], (float)acc[tn][tm][e0 + 2 * e2 + 1]};
+                const v2f b0e = {b0[2 * e2], b0[2 * e2 + 1]};
+                const v2f sce = {sc[2 * e2], sc[2 * e2 + 1]};
+                const v2f bse = {bs[2 * e2], bs[2 * e2 + 1]};
+                v2f r;
+                x = x - b0e;
+                if constexpr (MODE == 0) r = x * sce;
+                else if constexpr (MODE == 2) r = x * sce + bse;
+                else r = __builtin_elementwise_fma(x, sce, bse);
+                asm("" : "+v"(r));
+                const v2h h = __builtin_convertvector(r, v2h);
+                packed[e2] = *reinterpret_cast<const uint32_t*>(&h);
+              }
+              if (half == 0) hv[tm][oq] = make_uint2(packed[0], packed[1]);
+              else hg[tm][oq] = make_uint2(packed[0], packed[1]);
             }
-            hq[tm][tn] = make_uint2(packed[0], packed[1]);
+            if (oq % 2 == 1) __builtin_amdgcn_sched_barrier(0);
           }
-          __builtin_amdgcn_sched_barrier(0);
         }
       };
-      if (!has_bias) to_regs(std::integral_constant<int, 0>{});
-      else if (!unfused) to_regs(std::integral_constant<int, 1>{});
-      else to_regs(std::integral_constant<int, 2>{});
-      MIXDQ_STAMP_AT(5);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();                            // the table has landed, for every wave
-      MIXDQ_STAMP_AT(6);
+      const bool mine = KSPLIT == 1 || kg == 0;   // k-split: group 0 holds the sums
+      const int mode = !has_bias ? 0 : !unfused ? 1 : 2;
+      auto to_regs_tm = [&](int tm) {
+        if (mode == 0) to_regs(std::integral_constant<int, 0>{}, tm);
+        else if (mode == 1) to_regs(std::integral_constant<int, 1>{}, tm);
+        else to_regs(std::integral_constant<int, 2>{}, tm);
+      };
+      if constexpr (TAB) {                        // the whole patch first: the table is still in flight
+        if (mine) {
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm) {
-        const int ml = wm * WTM + tm * MT + lrow;
-        const bool far = geglu_any_far(hq[tm][2].x, hq[tm][2].y, hq[tm][3].x, hq[tm][3].y);
-        uint32_t pk[2];
-        auto quads = [&](auto near_c, auto unf_c) {
-          constexpr bool NEAR = decltype(near_c)::value, UNF = decltype(unf_c)::value;
-#pragma unroll
-          for (int tn = 0; tn < 2; ++tn)
-            pk[tn] = geglu_quad<NEAR, UNF>(hq[tm][tn], hq[tm][tn + 2], Tb, s_inv, zpq);
-        };
-        if (__builtin_amdgcn_ballot_w64(far) == 0) {       // wave-uniform: the usual case
-          if (unfused) quads(std::true_type{}, std::true_type{}); else quads(std::true_type{}, std::false_type{});
-        } else {
-          if (unfused) quads(std::false_type{}, std::true_type{}); else quads(std::false_type{}, std::false_type{});
+          for (int tm = 0; tm < TM; ++tm) to_regs_tm(tm);
         }
+        MIXDQ_STAMP_AT(5);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                          // the table has landed, for every wave
+      }
+      MIXDQ_STAMP_AT(6);
+      if (mine) {
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn)
-          *reinterpret_cast<uint32_t*>(smem + ml * QS + wn * 32 + tn * 16 + 4 * lkq) = pk[tn];
+        for (int tm = 0; tm < TM; ++tm) {
+          if constexpr (!TAB) to_regs_tm(tm);     // no table to wait for: row-tile by row-tile
+          const int ml = wm * WTM + tm * MT + lrow;
+          uint32_t pk[OQ];
+          auto quads = [&](auto how_c, auto unf_c) {
+            constexpr int HOW = decltype(how_c)::value;
+            constexpr bool UNF = decltype(unf_c)::value;
+#pragma unroll
+            for (int oq = 0; oq < OQ; ++oq) pk[oq] = geglu_quad<HOW, UNF>(hv[tm][oq], hg[tm][oq], Tb, s_inv, zpq);
+          };
+          if constexpr (TAB) {
+            bool far = false;
+#pragma unroll
+            for (int oq = 0; oq < OQ; oq += 2)
+              far |= geglu_any_far(hg[tm][oq].x, hg[tm][oq].y, hg[tm][oq + 1 < OQ ? oq + 1 : oq].x,
+                                   hg[tm][oq + 1 < OQ ? oq + 1 : oq].y);
+            if (__builtin_amdgcn_ballot_w64(far) == 0) {       // wave-uniform: the usual case
+              if (unfused) quads(std::integral_constant<int, 0>{}, std::true_type{});
+              else quads(std::integral_constant<int, 0>{}, std::false_type{});
+            } else {
+              if (unfused) quads(std::integral_constant<int, 1>{}, std::true_type{});
+              else quads(std::integral_constant<int, 1>{}, std::false_type{});
+            }
+          } else {
+            if (unfused) quads(std::integral_constant<int, 2>{}, std::true_type{});
+            else quads(std::integral_constant<int, 2>{}, std::false_type{});
+          }
+#pragma unroll
+          for (int oq = 0; oq < OQ; ++oq) {
+            const int v = vcol(oq);                           // group start / 2 + offset in the group
+            *reinterpret_cast<uint32_t*>(smem + ml * QS + ((v & ~31) >> 1) + (v & 15)) = pk[oq];
+          }
+        }
       }
       MIXDQ_STAMP_AT(10);
       __syncthreads();
       MIXDQ_STAMP_AT(11);
       const int Dh = p.N >> 1;
       const bool al16 = ((uintptr_t)p.Dq & 15) == 0;
-#pragma unroll
-      for (int it = 0; it < BM * 8 / NTHREADS; ++it) {
-        const int idx = tid + it * NTHREADS;
-        const int row = idx >> 3, cc = idx & 7;      // 16 outputs per chunk, two chunks per group
+      constexpr int CH = BN / 32;                 // 16-output chunks per tile row = its groups
+      for (int idx = tid; idx < BM * CH; idx += NTHREADS) {
+        const int row = idx / CH, cc = idx - row * CH;
         const int64_t m = m0 + row;
-        if (m >= p.M || n0 + 64 * (cc >> 1) >= p.N) continue;
+        if (m >= p.M || n0 + 32 * cc >= p.N) continue;        // N % 32 == 0: groups are whole
         const uint4 v = *reinterpret_cast<const uint4*>(smem + row * QS + cc * 16);
         int8_t* dst = p.Dq + m * Dh + (n0 >> 1) + cc * 16;
         if (al16) {
@@ -1177,7 +1213,6 @@ void igemm_kernel(const IgemmParams p_in) {
     else to_tile(std::integral_constant<int, 2>{});
   }
   MIXDQ_STAMP_AT(5);
-  if constexpr (GELU_TAB) { if (p.Dq != nullptr) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
   __syncthreads();
   MIXDQ_STAMP_AT(6);
   if constexpr (ATT) {
@@ -1325,56 +1360,6 @@ void igemm_kernel(const IgemmParams p_in) {
         *reinterpret_cast<uint2*>(reinterpret_cast<int8_t*>(p.att_out) + off) = make_uint2(pk[0], pk[1]);
       }
     }
-    return;
-  }
-  if constexpr (BN % 64 == 0) if (p.Dq != nullptr) {
-    // GEGLU + quantize on the staged fp16 tile: every rounding point of the unfused chain
-    // (GEMM -> fp16, gelu -> fp16, product -> fp16, quantize) is kept, so the int8 tensor is the
-    // one mixdq_geglu_quantize produces from this GEMM's fp16 output.
-    constexpr int VCH = BN / 16;               // 8-column value chunks per tile row
-    const float s_inv = *p.g_sinv, zpq = *p.g_zp;
-    const int Dh = p.N >> 1;
-    for (int idx = tid; idx < BM * VCH; idx += NTHREADS) {
-      const int row = idx / VCH, vc = idx - row * VCH;
-      const int grp = vc >> 2, j8 = (vc & 3) * 8;
-      const int64_t m = m0 + row;
-      if (m >= p.M || n0 + 64 * grp >= p.N) continue;   // N % 64 == 0: groups are whole
-      const int oc = (n0 >> 1) + 32 * grp + j8;
-      const uint4 xv = *reinterpret_cast<const uint4*>(Cs + row * CS_STRIDE + (64 * grp + j8) * 2);
-      const uint4 gv =
-          *reinterpret_cast<const uint4*>(Cs + row * CS_STRIDE + (64 * grp + 32 + j8) * 2);
-      const __half* xh = reinterpret_cast<const __half*>(&xv);
-      const __half* gh = reinterpret_cast<const __half*>(&gv);
-      uint32_t pk[2] = {0u, 0u};
-      if constexpr (GELU_TAB) {              // f16(gelu(g)) from the table in LDS (geglu_pair)
-        const char* Tb = smem + BM * CS_STRIDE;
-        const bool far = geglu_any_far(gv.x, gv.y, gv.z, gv.w);
-        auto quads = [&](auto near_c, auto unf_c) {
-          constexpr bool NEAR = decltype(near_c)::value, UNF = decltype(unf_c)::value;
-          pk[0] = geglu_quad<NEAR, UNF>(make_uint2(xv.x, xv.y), make_uint2(gv.x, gv.y), Tb, s_inv, zpq);
-          pk[1] = geglu_quad<NEAR, UNF>(make_uint2(xv.z, xv.w), make_uint2(gv.z, gv.w), Tb, s_inv, zpq);
-        };
-        if (__builtin_amdgcn_ballot_w64(far) == 0) {       // wave-uniform: the usual case
-          if (unfused) quads(std::true_type{}, std::true_type{}); else quads(std::true_type{}, std::false_type{});
-        } else {
-          if (unfused) quads(std::false_type{}, std::true_type{}); else quads(std::false_type{}, std::false_type{});
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; j += 2) {     // two gate values at a time
-          const v2f g2 = geluf2(v2f{__half2float(gh[j]), __half2float(gh[j + 1])});
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const float ge = __half2float(f32_to_f16_rn(g2[e]));
-            const float y = __half2float(f32_to_f16_rn(__fmul_rn(__half2float(xh[j + e]), ge)));
-            const int q = unfused ? quantize_one<true>(y, s_inv, zpq) : quantize_one<false>(y, s_inv, zpq);
-            pk[(j + e) >> 2] |= (uint32_t)(q & 0xff) << (8 * ((j + e) & 3));
-          }
-        }
-      }
-      *reinterpret_cast<uint2*>(p.Dq + m * Dh + oc) = make_uint2(pk[0], pk[1]);
-    }
-    MIXDQ_STAMP_AT(7);
     return;
   }
   constexpr int CPRO = BN / 8;   // 16-byte chunks per output row of the tile
@@ -1569,7 +1554,7 @@ template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool CONV, bool FA
 int launch_kernel(IgemmParams& p, hipStream_t stream) {
   constexpr int SMEM = igemm_smem_bytes<BM, BN, BK, STAGES>();
   static_assert(SMEM <= 160 * 1024, "LDS is 160 KiB per CU");
-  if (p.Dq != nullptr && BN % 64 != 0) return MIXDQ_ERR_GEGLU_SHAPE;   // whole value/gate groups per tile
+  if (p.Dq != nullptr && BN % 32 != 0) return MIXDQ_ERR_GEGLU_SHAPE;   // whole value|gate groups per tile
   if constexpr (SMEM > 64 * 1024) {   // opt in to > 64 KiB of dynamic LDS, once per instantiation
     static const hipError_t attr = hipFuncSetAttribute(
         reinterpret_cast<const void*>(
@@ -1666,17 +1651,18 @@ inline const std::vector<TuneEntry>& tune_overrides() {
 
 // An override applies to the INT8 launches of that shape only (the FP16 layers count K in bytes and
 // have their own list), and only if the launch's constraints admit the tile: GEMM+GEGLU needs
-// BN % 64 == 0 -- an entry meant for a plain Linear of the same shape is ignored there.
+// BN % 32 == 0 -- an entry meant for a plain Linear of the same shape is ignored there.
 inline int tuned_cfg(int64_t M, int N, int Ktot, bool whole64) {
   for (const TuneEntry& t : tune_overrides()) {
     if (t.M != M || t.N != N || t.K != Ktot) continue;
     for (const TileCfg& c : kTileCfgs)
-      if (c.id == t.cfg && (!whole64 || c.bn % 64 == 0)) return t.cfg;
+      if (c.id == t.cfg && (!whole64 || c.bn % 32 == 0)) return t.cfg;
   }
   return 0;
 }
 
-// whole64: the launch needs BN % 64 == 0 (GEMM+GEGLU: whole value/gate groups per tile)
+// whole64: a GEMM+GEGLU launch (needs BN % 32 == 0: whole value|gate groups per tile; the name is
+// round 2's, when the groups were 64 columns)
 // phased_ok: a Linear launch on the fast staging path (K % 128 == 0, 32-bit operand offsets)
 // tune: consult MIXDQ_IGEMM_TUNE (off for the FP16 layers' rule, which reuses this one on bytes)
 inline int select_cfg(int64_t M, int N, int Ktot, bool whole64 = false, bool phased_ok = false,
@@ -1955,7 +1941,7 @@ extern "C" int mixdq_qlinear_w8a8_geglu(const int8_t* A, const int8_t* W, const 
   if (!A || !W || !bias0 || !scale || !out_i8 || !out_scale_inv || !out_zero_point)
     return MIXDQ_ERR_INVALID_ARG;
   // whole value/gate groups per tile, the LDS-DMA kernels only, 8-byte output stores
-  if (N % 64 != 0 || K % 16 != 0 || ((uintptr_t)out_i8 & 7)) return MIXDQ_ERR_GEGLU_SHAPE;
+  if (N % 32 != 0 || K % 16 != 0 || ((uintptr_t)out_i8 & 7)) return MIXDQ_ERR_GEGLU_SHAPE;
   if (((uintptr_t)A | (uintptr_t)W | (uintptr_t)scale | (uintptr_t)bias0) & 15)
     return MIXDQ_ERR_GEGLU_SHAPE;
   if ((uintptr_t)bias_f16_or_null & 7) return MIXDQ_ERR_GEGLU_SHAPE;
@@ -2215,7 +2201,7 @@ extern "C" const char* mixdq_status_string(int status) {
       return "unsupported configuration (packed 4-bit weights need K % 32 == 0 -- conv: C % 32 == 0 "
              "-- and 16-byte aligned operands)";
     case MIXDQ_ERR_GEGLU_SHAPE:
-      return "unsupported configuration (GEMM+GEGLU needs N % 64 == 0, K % 16 == 0, 16-byte aligned "
+      return "unsupported configuration (GEMM+GEGLU needs N % 32 == 0, K % 16 == 0, 16-byte aligned "
              "operands and an 8-byte aligned output)";
     case MIXDQ_ERR_PADDING:
       return "unsupported configuration (padding must be smaller than the kernel size)";
@@ -2270,7 +2256,7 @@ extern "C" int mixdq_igemm_select_id_w4(int64_t M, int N, int k_align, int k_tot
 }
 
 extern "C" int mixdq_igemm_select_id_geglu(int64_t M, int N, int k_total, int w4) {
-  if (M <= 0 || N <= 0 || N % 64 != 0 || k_total % (w4 ? 32 : 16) != 0) return -1;
+  if (M <= 0 || N <= 0 || N % 32 != 0 || k_total % (w4 ? 32 : 16) != 0) return -1;
   return w4 ? select_cfg_w4(M, N, k_total, true)
             : select_cfg(M, N, k_total, true, linear_fast(M, N, k_total, k_total));
 }

@@ -526,7 +526,7 @@ class FeedForward(nn.Module):
         return self.net[2](self.net[0](x))
 
     def set_interleaved(self, on: bool):
-        """Store ff.net.0.proj's rows as value/gate groups of 32 (on) or in the ordinary
+        """Store ff.net.0.proj's rows as value|gate groups of 16 (on) or in the ordinary
         [values | gates] order (off).  Interleaved, one GEMM launch produces net.2's INT8 operand
         (GEMM + GEGLU + quantize); only W8A8 pairs qualify."""
         from mixdq_amd import _C

@@ -36,14 +36,14 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared_symbols():
         assert hasattr(lib, name), f"{name} declared in include/ but not exported"
     lib.mixdq_abi_version.restype = ctypes.c_int
-    assert lib.mixdq_abi_version() == 2
+    assert lib.mixdq_abi_version() == 3
     lib.mixdq_status_string.restype = ctypes.c_char_p
     assert lib.mixdq_status_string(0) == b"ok"
     assert b"alignment not to 4" in lib.mixdq_status_string(2)
     # one message per cause of "unsupported" (dilation is the only one the reference has)
     msgs = [lib.mixdq_status_string(c) for c in (3, 5, 6, 7, 8, 9)]
     assert b"dilation must be 1" in msgs[0] and len(set(msgs)) == 6
-    assert b"K % 32" in msgs[1] and b"N % 64" in msgs[2] and b"padding" in msgs[3]
+    assert b"K % 32" in msgs[1] and b"N % 32" in msgs[2] and b"padding" in msgs[3]
     lib.mixdq_qconv2d_workspace_bytes.restype = ctypes.c_size_t
     assert lib.mixdq_qconv2d_workspace_bytes(1280, 3, 3, 1) == 81 * 1280 * 4
     assert lib.mixdq_qconv2d_workspace_bytes(1280, 1, 1, 0) == 0
@@ -87,12 +87,11 @@ def test_tile_choice_is_a_host_function_of_the_shape():
     assert sel(32768, 1920, 640, 640) == 70
     # ... not for convolutions (k_align = C != k_total: the gather needs the general staging) ...
     assert sel(32768, 640, 640, 5760) != 70 and sel(8192, 10240, 1280, 11520) != 70
-    # ... nor a K that is not whole 128-byte tiles, nor GEMM + GEGLU (one workgroup per CU: the GELU
-    # epilogue of a 256x256 tile runs uncovered)
+    # ... nor a K that is not whole 128-byte tiles; GEMM + GEGLU does (its epilogue runs in registers)
     assert sel(8192, 10240, 1296, 1296) != 70
-    assert lib.mixdq_igemm_select_id_geglu(8192, 10240, 1280, 0) == 13
+    assert lib.mixdq_igemm_select_id_geglu(8192, 10240, 1280, 0) == 70
     assert lib.mixdq_igemm_select_id_geglu(1024, 10240, 1280, 0) == 25
-    assert lib.mixdq_igemm_select_id_geglu(1024, 10240 + 32, 1280, 0) == -1      # N % 64 != 0
+    assert lib.mixdq_igemm_select_id_geglu(1024, 10240 + 16, 1280, 0) == -1      # N % 32 != 0
     # packed W4: 32x32x32 tiles (every wave unpacks what it multiplies)
     assert lib.mixdq_igemm_select_id_w4(1024, 1280, 1280, 1280) == 41
     assert lib.mixdq_igemm_select_id_w4(1024, 1280, 1281, 1281) == -1             # K % 32 != 0

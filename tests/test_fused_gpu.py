@@ -190,6 +190,10 @@ GEGLU_GEMM_CASES = [  # M, D, K, forced tile config (0 = automatic), bias
     (300, 320, 256, 25, True), (300, 320, 192, 46, True), (130, 160, 128, 46, False),
     # the four-phase 256x256 loop: M tail, several column tiles, a K tail (one-phase fallback)
     (300, 256, 256, 70, True), (513, 384, 384, 70, False), (257, 256, 192, 70, True),
+    # every remaining tile family: 64x64x64, the k-split 64x64, 128x128 8-wave, 128x256, 256x256,
+    # the deeper 128x320 pipelines, the four-phase loop on 64-byte K-tiles; D = 16 (one group)
+    (96, 64, 64, 1, True), (130, 64, 256, 37, True), (200, 128, 128, 35, False), (300, 128, 128, 15, True),
+    (257, 256, 128, 14, True), (300, 320, 320, 47, True), (300, 256, 256, 71, True), (40, 16, 64, 0, True),
 ]
 
 
@@ -264,19 +268,19 @@ def test_qlinear_geglu_with_overflowing_and_nan_columns(C, oracle, cfg):
 
 
 def test_qlinear_geglu_rejects_tiles_without_whole_value_gate_groups(C):
-    """BN % 64 != 0 tiles (the 16x16x64-MFMA exact-fit tiles) cannot hold whole (value, gate) groups
-    of 32: forcing one is an error, not a wrong result."""
+    """BN % 32 != 0 tiles (the 16x16x64-MFMA exact-fit tiles) cannot hold whole value|gate groups
+    (16 + 16 columns): forcing one is an error, not a wrong result."""
     a = torch.zeros(64, 128, dtype=torch.int8, device=DEV)
     w = torch.zeros(320, 128, dtype=torch.int8, device=DEV)
     v = torch.ones(320, device=DEV)
-    with pytest.raises(RuntimeError, match="N % 64"):
+    with pytest.raises(RuntimeError, match="N % 32"):
         C.qlinear_geglu(a, w, v, v, None, scal(1.0), scal(0.0), _cfg=42)
 
 
 def test_qlinear_geglu_argument_checks(C):
     a = torch.zeros(8, 64, dtype=torch.int8, device=DEV)
-    w = torch.zeros(96, 64, dtype=torch.int8, device=DEV)      # N = 96: not whole 64-groups
-    v = torch.zeros(96, dtype=torch.float32, device=DEV)
+    w = torch.zeros(80, 64, dtype=torch.int8, device=DEV)      # N = 80: not whole groups of 32
+    v = torch.zeros(80, dtype=torch.float32, device=DEV)
     with pytest.raises(RuntimeError):
         C.qlinear_geglu(a, w, v, v, None, scal(1), scal(0))
 
