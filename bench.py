@@ -537,13 +537,13 @@ def main():
         tot_ops = sum(v["ops"] for v in roof_stats.values())
         tot_ms = sum(v["ms"] for v in roof_stats.values())
         # HBM-side bytes per launch and MFMA-busy fraction of THIS instantiation, from the rocprofv3
-        # --pmc passes of tools/pmc_probe.py (separate FETCH_SIZE / WRITE_SIZE / SQ runs; FETCH_SIZE
+        # --pmc passes of tools/pmc_r03.sh (separate FETCH_SIZE / WRITE_SIZE / SQ runs; FETCH_SIZE
         # x2 on gfx950) -- keyed by the kernel's own name, null when it was not collected
         traffic = mfma_util = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc) and args.px == 1024 and B == 1:
-            with open(pmc) as f:
-                entry = json.load(f).get(dom.split("#")[0], {})
+        if os.path.exists(pmc) and args.px == 1024 and not args.tiny:
+            with open(pmc) as f:      # sections by batch size of the probed launches (bs1, bs8)
+                entry = json.load(f).get(f"bs{B}", {}).get(dom.split("#")[0], {})
             traffic, mfma_util = entry.get("hbm_bytes_per_launch"), entry.get("mfma_util")
         out["roofline"] = {
             "bound": "mfma", "kernel": dom, "achieved": achieved, "peak": INT8_MFMA_PEAK_TOPS,

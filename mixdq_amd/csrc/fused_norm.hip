@@ -12,6 +12,7 @@
 // FP16, then the a1 quantizer on that FP16 value.  All reductions have a FIXED order, and the
 // transcendental steps are the shared specification include/mixdq_math.h, so the CPU oracle
 // (oracle/mixdq_oracle.c) reproduces every kernel bit-for-bit.  HBM-bound.
+#include <cstdlib>
 #include "common.h"
 #include "../../include/mixdq_math.h"
 
@@ -530,7 +531,9 @@ extern "C" int mixdq_layernorm_quantize(const void* x, const void* gamma, const 
     return MIXDQ_ERR_ALIGNMENT;
   hipStream_t stream = (hipStream_t)stream_;
   const bool unfused = flags & MIXDQ_FLAG_UNFUSED, want_h = out_f16_or_null != nullptr;
-  const int rows = M >= 8192 ? 2 : 1;                 // rows per wave (see the kernel)
+  static const int rows_forced = [] { const char* e = getenv("MIXDQ_LN_ROWS"); return e ? atoi(e) : 0; }();
+  const int rows = rows_forced == 1 || rows_forced == 2 ? rows_forced   // (tuning runs)
+                                                        : (M >= 8192 ? 2 : 1);   // rows per wave (see the kernel)
   const int grid = (int)((M + 4 * rows - 1) / (4 * rows));
 #define LN_LAUNCH(U, NQ, H)                                                                          \
   do {                                                                                               \
