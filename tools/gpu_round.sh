@@ -10,7 +10,7 @@ timeout 1200 python bench.py > $out/bench_bs1.json 2> $out/bench_bs1.err
 timeout 1200 python bench.py --batch 8 --steps 10 --cpu-seconds 1 --no-cpu-baseline > $out/bench_bs8.json 2> $out/bench_bs8.err
 timeout 900 python bench.py --baseline-config 4 --forwards-per-image 20 --steps 20 --warmup 2 --no-fp16 --no-cpu-baseline > $out/bench_bs16_cfg4_20steps.json 2> $out/bench_cfg4.err
 timeout 900 python bench.py --baseline-config 2 --no-fp16 --no-cpu-baseline > $out/bench_w4a8_mixed_bs1.json 2> $out/bench_cfg2.err
-timeout 900 python bench.py --baseline-config 3 --gpus 1 --steps 4 --warmup 1 --no-fp16 --no-cpu-baseline --no-roofline > $out/bench_bs64_cfg3_1gpu.json 2> $out/bench_cfg3.err
+timeout 1500 python bench.py --baseline-config 3 --gpus 1 --steps 4 --warmup 1 --no-fp16 --no-cpu-baseline --no-roofline > $out/bench_bs64_cfg3_1gpu.json 2> $out/bench_cfg3.err
 MIXDQ_SHARE_DEVICE=1 MIXDQ_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 2 --tiny --no-fp16 --no-cpu-baseline --no-roofline > $out/bench_gpus2_tiny_shared_device.json 2> $out/bench_gpus2.err
 for bs in 1 8; do
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof$bs -o bench -- python3 bench.py --no-fp16 --no-cpu-baseline --no-roofline --steps 20 --batch $bs > $out/bench_prof_bs$bs.json 2> $out/bench_prof_bs$bs.err
