@@ -1,5 +1,6 @@
 #!/bin/bash
-out=gpurun_out/r03_n
+# One lease: the whole GPU suite, then the batch-8 / batch-1 / batch-16 bench lines (no FP16 legs).
+out=gpurun_out/check
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 ( time timeout 1500 python -m pytest tests -q -m gpu -x 2>&1 | tail -6 ) > $out/pytest.txt 2>&1

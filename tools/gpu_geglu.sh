@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round-3 experiment O: value|gate groups of 16 -- GEMM+GEGLU in registers on every tile.
-out=gpurun_out/r03_o
+# GEMM+GEGLU+quantize launches: parity (both epilogue variants), time per tile configuration with typical and wide gates, stamps.
+out=gpurun_out/geglu
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 timeout 900 python -m pytest tests/test_fused_gpu.py tests/test_large_gpu.py -q -m gpu -k "geglu" -x 2>&1 | tail -8 > $out/pytest.txt

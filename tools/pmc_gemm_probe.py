@@ -25,7 +25,7 @@ if kind in ("lin", "geglu"):
     a = torch.randint(-128, 128, (M, K), generator=g, dtype=torch.int8).to("cuda")
     w = torch.randint(-128, 128, (N, K), generator=g, dtype=torch.int8).to("cuda")
     # GEGLU: outputs of a few units (|gate| < 8 almost everywhere, as calibrated activations are; the
-    # epilogue's beyond-the-table path is timed by tools/gpu_r03_o.sh); plain: range does not matter
+    # epilogue's beyond-the-table path is timed by tools/gpu_geglu.sh); plain: range does not matter
     sc = (torch.rand(N, generator=g) * (1e-5 if kind == "geglu" else 1e-4)).to("cuda")
     for _ in range(REPS):
         if kind == "geglu":
