@@ -86,8 +86,8 @@ struct IgemmParams {
   int64_t res_div;       //   D = f16(f32(f16(epilogue)) + f32(res[(m / res_div) * N + n]))
   int tiles_m, tiles_n;
   int unfused;
-  // GEGLU epilogue (Dq != null): the N = 2D output columns are value/gate groups of 32
-  // ([v 0..31 | g 0..31 | v 32..63 | ...], weight rows pre-interleaved by the host); the tile is
+  // GEGLU epilogue (Dq != null): the N = 2D output columns are value|gate groups of 16
+  // ([v 0..15 | g 0..15 | v 16..31 | ...], weight rows pre-interleaved by the host); the tile is
   // reduced to int8 q(f16(f16(v) * f16(gelu(f16(g))))) [M, D] -- ff.net.2's operand -- instead of D.
   int8_t* Dq;
   const float* g_sinv;
@@ -127,7 +127,8 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
 // taken by every wave) is 5.4-8.6 us of the 26 us (1024, 10240, 1280) launch, the largest of the
 // step (tools/stamp_report.py) -- VALU-bound, and packed FP32 buys nothing on CDNA4 (v_pk_fma_f32
 // issues at half the rate of v_fma_f32).  The tiles that have a CU to themselves anyway (LDS > 80 KB)
-// and whose fp16 tile leaves room look the value up instead: f16(gelu(g)) for every |g| < 8 (36 864
+// look the value up instead (the table sits in the K-tile stage buffers, free by then, behind the
+// INT8 output tile): f16(gelu(g)) for every |g| < 8 (36 864
 // entries, 72 KB; beyond: g, or -0 / NaN as the specification gives), built ONCE per device by the
 // specification itself (gelu_table_init_kernel), copied into LDS behind the main loop while the
 // accumulators are converted, read with one ds_read_u16 per element.  Bit-identical by construction.
