@@ -1722,8 +1722,18 @@ inline int select_cfg_w4(int64_t M, int N, int Ktot, bool whole64 = false) {
   auto blocks = [&](int tm, int tn) {
     return ((M + tm - 1) / tm) * (int64_t)((N + tn - 1) / tn);
   };
-  if (blocks(256, 128) >= 2 * kNumCU)
-    return (Ktot >= 4096 && blocks(256, 256) >= kNumCU) ? 20 : 18;
+  // GEMM+GEGLU (its epilogue runs in registers on every tile, with the GELU table where the tile owns
+  // its CU): the 128x320 tile at exactly one or two workgroups per CU, as for W8 ((1024, 10240, 1280):
+  // 20.9 vs 25.9 us on 128x128, (4096, 5120, 640): 26.4 vs 30.0); 256x256 for the large launches
+  // ((8192, 10240, 1280): 135.5 vs 152 us on 256x128x128; tools/gpu_w4geglu.sh, tools/bench_gemm.py --w4)
+  const int64_t b320 = blocks(128, 320);
+  if (whole64 && N % 320 == 0 && Ktot % 128 == 0 && (b320 == kNumCU || b320 == 2 * kNumCU)) return 25;
+  if (blocks(256, 128) >= 2 * kNumCU) {
+    if (whole64) return blocks(256, 256) >= kNumCU ? 20 : 18;
+    // plain launches: 256x128x64 (two workgroups per CU) -- (8192, 3840, 1280) 55.1 vs 63.1 us on
+    // 256x128x128, (32768, 1920, 640) 65.9 vs 80.6, (8192, 10240, 1280) 140 vs 153
+    return (Ktot >= 4096 && blocks(256, 256) >= kNumCU) ? 20 : 13;
+  }
   const int64_t b80 = blocks(128, 80);
   if (!whole64 && N % 80 == 0 && Ktot >= 2048 && (b80 == kNumCU || b80 == 2 * kNumCU)) return 44;
   if (blocks(128, 128) >= kNumCU) return 3;
