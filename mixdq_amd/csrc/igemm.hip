@@ -1687,6 +1687,10 @@ inline int select_cfg(int64_t M, int N, int Ktot, bool whole64 = false, bool pha
   // in the same lane; GELU by table): (8192, 10240, 1280) 117 vs 150 us on 256x128, (32768, 5120, 640)
   // 164 vs 202, (4096, 10240, 1280) 68 vs 79.  (With the staged arithmetic epilogue of round 2 the
   // 256x128 tile won: two workgroups per CU hid part of it.)
+  // (short K AND few columns -- the 640-channel to_q / to_out / ff layers at batch >= 8 -- is all
+  // prologue and epilogue: three co-resident workgroups of 128x128 pipeline them; (32768, 640, 640):
+  // 23.9 us against 28.8 on 256x256, 26.6 on 256x128, 26.3 on 128x320)
+  if (!whole64 && Ktot <= 640 && N <= 640 && blocks(128, 128) >= 4 * kNumCU) return 35;
   if (phased_ok && Ktot >= 640 && 2 * blocks(256, 256) >= 3 * kNumCU) return 70;
   if (blocks(256, 128) >= 2 * kNumCU)
     return (Ktot >= 4096 && blocks(256, 256) >= kNumCU) ? 20 : 13;
