@@ -104,7 +104,11 @@ def main():
         ref = run(1)
         row = dict(shape=label, count=cnt, gops=ops / 1e9, us={})
         for cfg in cfgs:
-            out = run(cfg)
+            try:
+                out = run(cfg)
+            except RuntimeError as e:           # a tile that does not take this problem (halo: 3x3 only)
+                row["us"][cfg] = f"n/a ({str(e)[-40:]})"
+                continue
             ok = torch.equal(out, ref)
             us = timeit(lambda: run(cfg))
             row["us"][cfg] = round(us, 2)
