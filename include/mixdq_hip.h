@@ -362,8 +362,8 @@ int mixdq_igemm_select_id_geglu(int64_t M, int N, int k_total, int w4);
 int mixdq_conv_halo_select(int N, int H, int W, int C, int K, int R, int S, int stride, int pad);
 
 /* Introspection (tests): the table the GEMM + GEGLU epilogue of the large tiles looks GELU up in --
- * 2 x 0x4800 uint16: f16 bits of gelu(g) for the FP16 gate g with bits (sign << 15) | magnitude,
- * magnitude < 0x4800 (|g| < 8), positive half first -- copied to `out_device` (73 728 bytes). */
+ * 2 x 0x4c00 uint16: f16 bits of gelu(g) for the FP16 gate g with bits (sign << 15) | magnitude,
+ * magnitude < 0x4c00 (|g| < 16), positive half first -- copied to `out_device` (77 824 bytes). */
 int mixdq_gelu_table(uint16_t* out_device, mixdq_stream_t stream);
 
 #ifdef __cplusplus

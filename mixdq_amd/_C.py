@@ -378,12 +378,15 @@ _lib.mixdq_qlinear_w8a8_geglu.argtypes = [_vp] * 6 + [_i64, _i32, _i32, _vp, _vp
 _lib.mixdq_qlinear_w8a8_geglu.restype = _i32
 
 
+GELU_TABLE_MAG = 0x4c00   # csrc/igemm.hip kGeluTabMag: the table covers |gate| < 16
+
+
 def gelu_table(device="cuda") -> torch.Tensor:
     """The table the GEMM + GEGLU epilogue of the large tiles looks GELU up in (mixdq_gelu_table):
-    int16 [2, 0x4800] -- row 0: gates +0 .. +8, row 1: -0 .. -8 -- of f16 bit patterns."""
+    int16 [2, 0x4c00] -- row 0: gates +0 .. +16, row 1: -0 .. -16 -- of f16 bit patterns."""
     _lib.mixdq_gelu_table.argtypes = [_vp, _vp]
     _lib.mixdq_gelu_table.restype = _i32
-    out = torch.empty((2, 0x4800), dtype=torch.int16, device=device)
+    out = torch.empty((2, GELU_TABLE_MAG), dtype=torch.int16, device=device)
     with torch.cuda.device(out.device):
         _status(_lib.mixdq_gelu_table(out.data_ptr(), _stream()), "gelu_table")
     return out

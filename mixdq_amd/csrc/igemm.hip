@@ -128,11 +128,14 @@ __device__ __forceinline__ void glds16(const void* gsrc, char* lds_wave_base) {
 // step (tools/stamp_report.py) -- VALU-bound, and packed FP32 buys nothing on CDNA4 (v_pk_fma_f32
 // issues at half the rate of v_fma_f32).  The tiles that have a CU to themselves anyway (LDS > 80 KB)
 // look the value up instead (the table sits in the K-tile stage buffers, free by then, behind the
-// INT8 output tile): f16(gelu(g)) for every |g| < 8 (36 864
-// entries, 72 KB; beyond: g, or -0 / NaN as the specification gives), built ONCE per device by the
+// INT8 output tile): f16(gelu(g)) for every |g| < 16 (38 912
+// entries, 76 KB; beyond: g, or -0 / NaN as the specification gives), built ONCE per device by the
 // specification itself (gelu_table_init_kernel), copied into LDS behind the main loop while the
 // accumulators are converted, read with one ds_read_u16 per element.  Bit-identical by construction.
-constexpr int kGeluTabMag = 0x4800;                         // |g| < 8.0
+#ifndef MIXDQ_GELU_TAB_MAG
+#define MIXDQ_GELU_TAB_MAG 0x4c00   // (0x4800, |g| < 8: batch-1 step 11.62 ms against 11.55 with this, same box)
+#endif
+constexpr int kGeluTabMag = MIXDQ_GELU_TAB_MAG;             // |g| < 16.0
 constexpr int kGeluTabBytes = 2 * kGeluTabMag * 2;          // two signs x 2 bytes
 __device__ uint16_t g_gelu_tab[2 * kGeluTabMag];
 
@@ -163,9 +166,9 @@ inline int ensure_gelu_table(hipStream_t stream) {
 // Two GEGLU outputs at a time from packed fp16 pairs (value xw, gate gw): the bytes q0 | q1 << 8 of
 // quantize(f16(x * f16(gelu(g)))).  The epilogue is VALU-bound (with one workgroup per CU nothing runs
 // beside it), so the element chain is kept short:
-//   * HOW = 0, table in LDS, every |g| < 8 (decided per wave for a run of elements): the entry IS
+//   * HOW = 0, table in LDS, every |g| < 16 (decided per wave for a run of elements): the entry IS
 //     f16(gelu(g));
-//   * HOW = 1, table in LDS, some |g| >= 8 / inf / NaN in the run: g itself, or 0 * g for negative
+//   * HOW = 1, table in LDS, some |g| >= 16 / inf / NaN in the run: g itself, or 0 * g for negative
 //     gates (-0; NaN for -inf / NaN) -- the specification's values there -- selected on the bits,
 //     branch-free (a NaN's payload does not matter: the product is NaN and quantizes to 0);
 //   * HOW = 2, no table (tiles that share their CU): the arithmetic of include/mixdq_math.h;
@@ -177,7 +180,7 @@ __device__ __forceinline__ bool geglu_any_far(uint32_t g0, uint32_t g1, uint32_t
   auto mags = [](uint32_t w) { return __builtin_bit_cast(v2u16, w & 0x7fff7fffu); };
   const v2u16 m = __builtin_elementwise_max(__builtin_elementwise_max(mags(g0), mags(g1)),
                                             __builtin_elementwise_max(mags(g2), mags(g3)));
-  return max((uint32_t)m[0], (uint32_t)m[1]) >= (uint32_t)kGeluTabMag;   // eight gates, any |g| >= 8
+  return max((uint32_t)m[0], (uint32_t)m[1]) >= (uint32_t)kGeluTabMag;   // eight gates, any |g| >= 16
 }
 template <int HOW, bool UNFUSED>
 __device__ __forceinline__ uint32_t geglu_pair(uint32_t xw, uint32_t gw, const char* Tb, float s_inv,
@@ -992,7 +995,7 @@ void igemm_kernel(const IgemmParams p_in) {
   //      pair of 16-column tiles) holds whole groups, and in the accumulator layout the lane that holds
   //      value columns c..c+3 of a row holds gate columns c+16..c+19 of it too: the fp16 tile never
   //      goes through LDS.  What LDS holds instead: the INT8 output tile (whole rows for the stores)
-  //      and -- on the tiles that have their CU to themselves -- the GELU table (72 KB, DMA'd under the
+  //      and -- on the tiles that have their CU to themselves -- the GELU table (76 KB, DMA'd under the
   //      accumulator -> fp16 pass).  Every rounding point of the unfused chain (GEMM -> fp16, gelu ->
   //      fp16, product -> fp16, quantize) is kept: the INT8 tensor is the one mixdq_geglu_quantize
   //      produces from this GEMM's fp16 output.  ((8192, 10240, 1280) on the 256x256 tile: 117 us;

@@ -165,18 +165,19 @@ def test_packed_gelu_equals_the_scalar_specification_on_every_fp16_gate(C, oracl
 
 def test_gelu_table_of_the_large_tile_epilogue_is_the_specification(C, oracle):
     """The GEMM + GEGLU epilogue of the one-workgroup-per-CU tiles looks f16(gelu(g)) up in an LDS
-    table for |g| < 8 and uses `g` (g >= 8) or `0 * g` (g <= -8: -0; -inf -> NaN) beyond: both
+    table for |g| < 16 and uses `g` (g >= 16) or `0 * g` (g <= -16: -0; -inf -> NaN) beyond: both
     halves against the host evaluation of include/mixdq_math.h, for all 65536 gates."""
     L = oracle.lib()
-    tab = C.gelu_table(DEV).cpu().numpy().view(np.uint16)              # [2, 0x4800]
+    tab = C.gelu_table(DEV).cpu().numpy().view(np.uint16)              # [2, 0x4c00]
+    MAG = C.GELU_TABLE_MAG
     bits = np.arange(65536, dtype=np.uint32).astype(np.uint16)
     g = bits.view(np.float16)
     with np.errstate(all="ignore"):
         want = np.array([np.float32(L.mixdq_oracle_geluf(float(a))) for a in g.astype(np.float32)],
                         np.float32).astype(np.float16)
         mag, neg = bits & 0x7fff, bits >> 15
-        near = mag < 0x4800
-        got = np.where(near, tab[neg, np.minimum(mag, 0x47ff)].view(np.float16),
+        near = mag < MAG
+        got = np.where(near, tab[neg, np.minimum(mag, MAG - 1)].view(np.float16),
                        np.where(neg == 1, (np.float32(0) * g.astype(np.float32)).astype(np.float16), g))
     both_nan = np.isnan(got) & np.isnan(want)
     assert np.array_equal(np.isnan(got), np.isnan(want))
@@ -260,7 +261,7 @@ def test_qlinear_geglu_with_overflowing_and_nan_columns(C, oracle, cfg):
     with np.errstate(all="ignore"):
         h = oracle.qlinear(a, w, bias0, scale, None, C.FLAGS & 1)
         q_ref, _ = oracle.geglu_quantize(h, s_inv, zp, C.FLAGS & 1)
-    assert np.isinf(h[:, D + 3]).any() and np.isnan(h[:, D + 11]).all() and (np.abs(h[:, D + 40]) > 8).any()
+    assert np.isinf(h[:, D + 3]).any() and np.isnan(h[:, D + 11]).all() and (np.abs(h[:, D + 40]) > 16).any()
     perm = C.geglu_row_order(D, DEV)
     got = C.qlinear_geglu(t(a), t(w)[perm].contiguous(), t(scale)[perm].contiguous(),
                           t(bias0)[perm].contiguous(), None, scal(s_inv), scal(zp), _cfg=cfg)
