@@ -551,3 +551,20 @@ def test_quantizer_groups_memo_follows_identity_and_version():
     b.act_scales_inv = torch.tensor([4.0])                          # replaced tensor
     assert U._quantizer_groups(h, "k", [a, b, c]) == [0, 1, 0]
     assert U._quantizer_groups(h, "k", []) == []
+
+
+def test_geglu_row_order_is_value_gate_groups_of_16():
+    """include/mixdq_hip.h, mixdq_qlinear_w8a8_geglu: stored row i = row perm[i] of the ordinary
+    [values 0..D-1 ; gates D..2D-1] projection, in groups [v 0..15 | g 0..15 | v 16..31 | g 16..31 ...] --
+    every 32 stored rows hold the value and the gate of 16 outputs (what lets one lane of an MFMA tile hold
+    both halves of an output)."""
+    from mixdq_amd._C import geglu_row_order
+    D = 80
+    perm = geglu_row_order(D).tolist()
+    assert sorted(perm) == list(range(2 * D))
+    for grp in range(D // 16):
+        blk = perm[32 * grp:32 * grp + 32]
+        assert blk[:16] == list(range(16 * grp, 16 * grp + 16))
+        assert blk[16:] == list(range(D + 16 * grp, D + 16 * grp + 16))
+    inv = torch.argsort(torch.tensor(perm))
+    assert torch.equal(torch.tensor(perm)[inv], torch.arange(2 * D))
