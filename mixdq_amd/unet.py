@@ -320,9 +320,18 @@ SDXL_CONFIG = dict(
 def sinusoidal_embedding(t: torch.Tensor, dim: int) -> torch.Tensor:
     """diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0)."""
     half = dim // 2
-    exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=t.device) / half
-    emb = t.float()[:, None] * torch.exp(exponent)[None, :]
+    key = (half, t.device)
+    freqs = _SIN_FREQS.get(key)
+    if freqs is None:      # a constant of (dim, device): four launches per call when recomputed
+        exponent = -math.log(10000.0) * torch.arange(half, dtype=torch.float32, device=t.device) / half
+        freqs = torch.exp(exponent)
+        if not (t.is_cuda and torch.cuda.is_current_stream_capturing()):
+            _SIN_FREQS[key] = freqs        # (never cache a tensor that only a graph replay fills)
+    emb = t.float()[:, None] * freqs[None, :]
     return torch.cat([torch.cos(emb), torch.sin(emb)], dim=-1)
+
+
+_SIN_FREQS = {}
 
 
 class TimestepEmbedding(nn.Module):
