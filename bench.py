@@ -44,6 +44,7 @@ import torch.nn as nn  # noqa: E402
 # dense INT8 MFMA: 2x the BF16 rate per clock (MI355X_MICROARCH.md, Matrix cores table: "I8 ... 2x BF16
 # per clock") x its ~2.5 PF dense BF16 figure (Chip-level parameters)
 INT8_MFMA_PEAK_TOPS = 5000.0
+F16_MFMA_PEAK_TFLOPS = 2500.0     # dense FP16 / BF16 MFMA (same table): the attention core's roof
 HBM_PEAK_GBS = 8000.0
 
 
@@ -67,7 +68,12 @@ def parse_args():
     ap.add_argument("--no-fp16", action="store_true", help="skip the FP16 comparison")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-batch8", action="store_true", help="skip the batch-8 object of the default line")
+    ap.add_argument("--no-dropin", action="store_true",
+                    help="skip the module-swap-only (unfused) leg of the default line")
+    ap.add_argument("--cpu-seconds", type=float, default=60.0,
+                    help="budget of the cpu_baseline leg (layer time): the whole 794-layer inventory on the "
+                         "GPU box's host (7-26 s), a MAC-extrapolated sample on a slow one")
     ap.add_argument("--sweep-reps", type=int, default=5)
     ap.add_argument("--tiny", action="store_true",
                     help="small UNet config (tests of the harness itself; not a benchmark)")
@@ -176,6 +182,12 @@ def roofline_sweep(run_eager, device, reps):
         torch.cuda.synchronize(device)
     groups = {}
     for kind, (M, N, K, k_align), w4, replay in rec:
+        if kind == "attention":          # FP16 attention core: M = B * heads * Tq, N = Tkv, K = head_dim
+            g_ = groups.setdefault(f"attn_fwd_kernel<Tkv={N}>", dict(fns=[], ops=0.0, bytes=0.0, f16=True))
+            g_["fns"].append(replay)
+            g_["ops"] += 4.0 * M * N * K                       # Q K^T and P V
+            g_["bytes"] += 2.0 * (2 * M * K) + 0.0             # q read + o written (k / v are re-read per q block)
+            continue
         if kind == "linear_grouped":     # N = the members' total; mixdq_qlinear_w8a8_grouped's rule
             cid = 37 if M <= 64 else 35
         elif kind == "linear_attn":      # to_q + cross-attention: always the 64x128 8-wave tile
@@ -214,9 +226,77 @@ def roofline_sweep(run_eager, device, reps):
             e1.record()
             torch.cuda.synchronize(device)
             stats[kname] = dict(ms=e0.elapsed_time(e1), ops=g_["ops"] * reps,
-                                bytes=g_["bytes"] * reps, launches=len(g_["fns"]) * reps)
+                                bytes=g_["bytes"] * reps, launches=len(g_["fns"]) * reps,
+                                f16=bool(g_.get("f16")))
             del graph
     return stats
+
+
+def roofline_object(roof_stats, B, reps, px, tiny):
+    """The `roofline` object of the JSON line from roofline_sweep's per-kernel totals.  The dominant
+    kernel is chosen among the INT8 GEMM / conv instantiations (the metric's roof is the INT8 MFMA
+    peak); the FP16 attention core is listed beside them under `per_kernel` against ITS roof."""
+    i8 = {k: v for k, v in roof_stats.items() if not v.get("f16")}
+    dom = max(i8, key=lambda k: i8[k]["ms"])
+    s = i8[dom]
+    achieved = s["ops"] / (s["ms"] * 1e-3) / 1e12
+    tot_ops = sum(v["ops"] for v in i8.values())
+    tot_ms = sum(v["ms"] for v in i8.values())
+    # HBM-side bytes per launch and MFMA-busy fraction of THIS instantiation, from the rocprofv3
+    # --pmc passes (tools/pmc_r04.sh: separate FETCH_SIZE / WRITE_SIZE / SQ runs; FETCH_SIZE x2 on
+    # gfx950) -- keyed by the kernel's own name, null when it was not collected
+    traffic = mfma_util = None
+    pmc_all = {}
+    pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc) and px == 1024 and not tiny:
+        with open(pmc) as f:      # sections by batch size of the probed launches (bs1, bs8)
+            pmc_all = json.load(f).get(f"bs{B}", {})
+        entry = pmc_all.get(dom.split("#")[0], {})
+        traffic, mfma_util = entry.get("hbm_bytes_per_launch"), entry.get("mfma_util")
+    per_kernel = {}
+    for k, v in sorted(roof_stats.items()):
+        peak = F16_MFMA_PEAK_TFLOPS if v.get("f16") else INT8_MFMA_PEAK_TOPS
+        tops = v["ops"] / (v["ms"] * 1e-3) / 1e12
+        per_kernel[k] = {"ms_per_step": v["ms"] / reps, "launches": v["launches"] // reps,
+                         "avg_launch_us": 1e3 * v["ms"] / v["launches"], "tops": tops,
+                         "frac": tops / peak, "peak": peak}
+        e = pmc_all.get(k.split("#")[0])
+        if e:
+            per_kernel[k].update({kk: e[kk] for kk in ("mfma_util", "hbm_bytes_per_launch", "valu_util")
+                                  if kk in e})
+    return {
+        "bound": "mfma", "kernel": dom, "achieved": achieved, "peak": INT8_MFMA_PEAK_TOPS,
+        "unit": "TFLOP/s", "frac": achieved / INT8_MFMA_PEAK_TOPS, "traffic": traffic,
+        "mfma_util": mfma_util,
+        "launches_per_step": s["launches"] // reps,
+        "avg_launch_us": 1e3 * s["ms"] / s["launches"],
+        "ops_per_launch": s["ops"] / s["launches"],
+        "algorithmic_bytes_per_launch": s["bytes"] / s["launches"],
+        "hbm_frac_of_8TBs": s["bytes"] / (s["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
+        "all_igemm": {"tops": tot_ops / (tot_ms * 1e-3) / 1e12,
+                      "ms_per_step": tot_ms / reps,
+                      "launches_per_step": sum(v["launches"] for v in i8.values()) // reps,
+                      "int8_ops_per_step": tot_ops / reps},
+        "per_kernel": per_kernel,
+    }
+
+
+def count_kernels(fn, device):
+    """GPU kernels one call of fn() launches (torch.profiler / roctracer), or None if unavailable."""
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        with torch.no_grad():
+            fn()
+            torch.cuda.synchronize(device)
+            with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                fn()
+                torch.cuda.synchronize(device)
+        n = sum(1 for e in prof.events()
+                if str(getattr(e, "device_type", "")).endswith("CUDA") and "Memcpy" not in e.name
+                and "Memset" not in e.name)
+        return n or None
+    except Exception:
+        return None
 
 
 def cpu_fake_quant_baseline(seconds_budget):
@@ -262,39 +342,107 @@ def cpu_fake_quant_baseline(seconds_budget):
         n_done += 1
         M, N, K = layer_work(mod, shp)
         macs_done += float(M) * N * K
-        if t_total > seconds_budget or time.perf_counter() - t_begin > 4 * seconds_budget:
+        if t_total > seconds_budget or time.perf_counter() - t_begin > 3 * seconds_budget:
             break
-    # scaled by multiply-accumulates, not by layer count (the sample is spread uniformly over the
-    # model, but layers differ by 1000x in work); a fast host times the whole inventory: factor 1
-    est_forward_s = t_total * (macs_all / max(macs_done, 1.0))
+    # The budget (default 60 s of layer time) is sized so that the GPU box's host (128 threads: 7-26 s
+    # per forward) runs the WHOLE inventory: measured_mac_frac = 1, nothing extrapolated.  A slower
+    # host stops at the budget; what it did not reach is extrapolated by multiply-accumulates (the
+    # sample is spread uniformly over the model, but layers differ by 1000x in work), and the line
+    # says how much of the number was measured.
+    frac = macs_done / macs_all
+    est_forward_s = t_total / max(frac, 1e-9)
+    whole = n_done == len(layers)
     return dict(value=1.0 / est_forward_s, unit="images/s", cores=torch.get_num_threads(),
                 kind="port", seconds_per_forward_est=est_forward_s,
+                measured_s=t_total, measured_layers=n_done, measured_mac_frac=frac,
+                extrapolated_s=est_forward_s - t_total, whole_inventory=whole,
                 sample=f"qdiff fake-quant (Path A) W8A8 512px bs1 FP32 on CPU: {n_done} of "
-                       f"{len(layers)} layers (uniformly spread over the model, "
-                       f"{100 * macs_done / macs_all:.1f}% of the MACs) in {t_total:.1f} s, "
-                       f"scaled by MACs; host os.cpu_count()={os.cpu_count()}")
+                       f"{len(layers)} layers ({100 * frac:.1f}% of the MACs) in {t_total:.1f} s"
+                       + ("" if whole else ", the rest extrapolated by MACs")
+                       + f"; host os.cpu_count()={os.cpu_count()}")
 
 
 def spawn_ranks(n: int) -> int:
     """`--gpus N` without a launcher: start the N ranks as fresh child processes (one per GPU,
     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment) BEFORE this process has made
     any GPU call -- it never does -- relay rank 0's JSON line, and return non-zero if any rank
-    failed.  (Never re-exec a process that has touched the GPU.)"""
+    failed.  (Never re-exec a process that has touched the GPU.)
+
+    The ranks run in a process group of their own: when one of them dies, or this process is told
+    to stop (SIGTERM / SIGINT, e.g. `timeout 600 python bench.py --gpus 2`), the rest are ended too
+    instead of sitting in a rendezvous until torch's timeout while holding the GPUs.  Of rank 0's
+    stdout only the last line that parses as JSON goes to stdout; everything else goes to stderr."""
+    import signal
     import socket
     import subprocess
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
-                                      env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr))
-    out0, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0.decode())
+    procs, pgid = [], None
+
+    def end_all(sig=signal.SIGTERM):
+        if pgid is not None:
+            try:
+                os.killpg(pgid, sig)
+            except ProcessLookupError:
+                pass
+
+    def on_signal(signum, _frame):
+        end_all()
+        raise SystemExit(128 + signum)
+
+    old = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGTERM, signal.SIGINT)}
+    out0 = b""
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            pr = subprocess.Popen(
+                [sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                stdout=subprocess.PIPE if r == 0 else sys.stderr,
+                preexec_fn=(lambda g=(pgid or 0): os.setpgid(0, g)))   # rank 0 founds the group
+            if r == 0:
+                pgid = pr.pid
+            procs.append(pr)
+        import threading
+        buf = []
+        reader = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+        reader.start()
+        codes = [None] * n
+        while any(c is None for c in codes):
+            for r, pr in enumerate(procs):
+                if codes[r] is None:
+                    codes[r] = pr.poll()
+            if any(c not in (None, 0) for c in codes):
+                end_all()                      # a rank failed: the others would wait for it forever
+                for r, pr in enumerate(procs):
+                    if codes[r] is None:
+                        try:
+                            codes[r] = pr.wait(timeout=30)
+                        except subprocess.TimeoutExpired:
+                            end_all(signal.SIGKILL)
+                            codes[r] = pr.wait()
+                break
+            time.sleep(0.2)
+        reader.join(timeout=10)
+        out0 = buf[0] if buf else b""
+    finally:
+        if any(pr.poll() is None for pr in procs):
+            end_all()
+        for sg, h in old.items():
+            signal.signal(sg, h)
+    lines = out0.decode(errors="replace").splitlines()
+    last_json = None
+    for i in range(len(lines) - 1, -1, -1):
+        try:
+            json.loads(lines[i])
+            last_json = i
+            break
+        except ValueError:
+            continue
+    for i, ln in enumerate(lines):
+        print(ln, file=sys.stdout if i == last_json else sys.stderr)
     sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]
     if bad:
@@ -481,6 +629,51 @@ def main():
     roof_stats = None
     if not args.no_roofline and rank == 0:
         roof_stats = roofline_sweep(lambda: eager_forward(**inputs), device, args.sweep_reps)
+
+    # ---- batch 8 beside the headline (north_star: "bs=1/8 on 1 GPU"; also the per-GPU shard of
+    #      configs[3] on 8 GPUs): the same network and graph machinery on a batch-8 input, timed AFTER
+    #      the main region, with its own dominant kernel's roofline.  Default N = 1 run only.
+    batch8 = None
+    default_line = (world == 1 and B == 1 and not strong and not args.tiny and args.px == 1024
+                    and not args.no_graph)
+    if default_line and not args.no_batch8:
+        inputs8 = example_inputs(8, L, device, seed=1042)
+        with torch.no_grad():
+            eager_forward(**inputs8)                   # persistent K/V buffers of this shape
+        torch.cuda.synchronize(device)
+        k8 = max(5, args.steps // 2)
+        dt8 = time_steps(lambda: unet(**inputs8)[0], k8, 2, device)
+        batch8 = {"ms_per_step": 1e3 * dt8 / k8, "images_per_s": 8 * k8 / dt8, "steps": k8,
+                  "workload": f"sdxl_turbo_unet_{'w4a8_mixed' if args.w4_kernel else 'w8a8'}_{args.px}px_bs8_1step"}
+        if not args.no_roofline:
+            r8 = roofline_object(roofline_sweep(lambda: eager_forward(**inputs8), device,
+                                                max(2, args.sweep_reps // 2)),
+                                 8, max(2, args.sweep_reps // 2), args.px, args.tiny)
+            batch8["roofline"] = {k: r8[k] for k in ("kernel", "achieved", "peak", "frac", "traffic",
+                                                     "mfma_util", "launches_per_step", "avg_launch_us",
+                                                     "algorithmic_bytes_per_launch", "all_igemm")}
+            batch8["roofline"]["per_kernel"] = r8["per_kernel"]
+        del inputs8
+
+    # ---- what the module swap ALONE gives (mixdq_extension._C replaced under
+    #      an unchanged graph): the same quantized network with this repo's producer fusions off --
+    #      one quantize launch per layer, torch GroupNorm / LayerNorm / GELU / SDPA glue -- in a hipGraph.
+    dropin = None
+    if default_line and not args.no_dropin and not args.no_fuse:
+        unet.forward = eager_forward
+        unet.set_fused(False)
+        with torch.no_grad():
+            eager_forward(**inputs)
+        torch.cuda.synchronize(device)
+        n_unfused = count_kernels(lambda: eager_forward(**inputs), device)
+        hip_graph_opt(unet)
+        kd = max(5, args.steps // 2)
+        dtd = time_steps(run_once, kd, 2, device)
+        unet.forward = eager_forward
+        unet.set_fused(True)
+        n_fused = count_kernels(lambda: eager_forward(**inputs), device)
+        dropin = {"dropin_unfused_ms_per_step": 1e3 * dtd / kd, "dropin_unfused_kernels_per_step": n_unfused,
+                  "kernels_per_step": n_fused}
     if args.profile_ranges and rank == 0:
         unet.forward = eager_forward
         layers_roctx_annotate(unet)
@@ -531,39 +724,11 @@ def main():
             out["memory"]["saving_vs_fp16"] = {
                 k: memory["fp16"][k] / q[k] for k in ("static_mb", "dynamic_mb", "peak_mb") if q[k]}
     if roof_stats:
-        dom = max(roof_stats, key=lambda k: roof_stats[k]["ms"])
-        s = roof_stats[dom]
-        achieved = s["ops"] / (s["ms"] * 1e-3) / 1e12
-        tot_ops = sum(v["ops"] for v in roof_stats.values())
-        tot_ms = sum(v["ms"] for v in roof_stats.values())
-        # HBM-side bytes per launch and MFMA-busy fraction of THIS instantiation, from the rocprofv3
-        # --pmc passes of tools/pmc_r03.sh (separate FETCH_SIZE / WRITE_SIZE / SQ runs; FETCH_SIZE
-        # x2 on gfx950) -- keyed by the kernel's own name, null when it was not collected
-        traffic = mfma_util = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc) and args.px == 1024 and not args.tiny:
-            with open(pmc) as f:      # sections by batch size of the probed launches (bs1, bs8)
-                entry = json.load(f).get(f"bs{B}", {}).get(dom.split("#")[0], {})
-            traffic, mfma_util = entry.get("hbm_bytes_per_launch"), entry.get("mfma_util")
-        out["roofline"] = {
-            "bound": "mfma", "kernel": dom, "achieved": achieved, "peak": INT8_MFMA_PEAK_TOPS,
-            "unit": "TFLOP/s", "frac": achieved / INT8_MFMA_PEAK_TOPS, "traffic": traffic,
-            "mfma_util": mfma_util,
-            "launches_per_step": s["launches"] // args.sweep_reps,
-            "avg_launch_us": 1e3 * s["ms"] / s["launches"],
-            "ops_per_launch": s["ops"] / s["launches"],
-            "algorithmic_bytes_per_launch": s["bytes"] / s["launches"],
-            "hbm_frac_of_8TBs": s["bytes"] / (s["ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "all_igemm": {"tops": tot_ops / (tot_ms * 1e-3) / 1e12,
-                          "ms_per_step": tot_ms / args.sweep_reps,
-                          "launches_per_step": sum(v["launches"] for v in roof_stats.values())
-                          // args.sweep_reps,
-                          "int8_ops_per_step": tot_ops / args.sweep_reps},
-            "per_kernel": {k: {"ms_per_step": v["ms"] / args.sweep_reps,
-                               "launches": v["launches"] // args.sweep_reps,
-                               "tops": v["ops"] / (v["ms"] * 1e-3) / 1e12}
-                           for k, v in sorted(roof_stats.items())},
-        }
+        out["roofline"] = roofline_object(roof_stats, B, args.sweep_reps, args.px, args.tiny)
+    if batch8:
+        out["batch8"] = batch8
+    if dropin:
+        out.update(dropin)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_fake_quant_baseline(args.cpu_seconds)
     print(json.dumps(out))

@@ -352,7 +352,8 @@ int mixdq_igemm_select_id(int64_t M, int N, int k_align, int k_total);
 /* The same for a packed-W4 weight operand (MIXDQ_FLAG_W4); -1 = invalid (k_align % 32 != 0). */
 int mixdq_igemm_select_id_w4(int64_t M, int N, int k_align, int k_total);
 /* The same for the GEMM + GEGLU + quantize launch (mixdq_qlinear_w8a8_geglu), whose tiles hold whole
- * 64-column value / gate groups and which does not take the 256x256 four-phase loop. */
+ * 32-column value | gate groups (BN % 32 == 0); from 1.5 workgroups of 256x256 per CU on it runs on the
+ * four-phase 256x256 tile (id 70) like a plain Linear. */
 int mixdq_igemm_select_id_geglu(int64_t M, int N, int k_total, int w4);
 
 /* Tile id of the LDS-resident-halo kernel (csrc/iconv.hip) that mixdq_qconv2d_w8a8[_table] runs this

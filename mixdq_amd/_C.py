@@ -56,6 +56,13 @@ _lib.mixdq_igemm_select.argtypes = [_i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp]
 _lib.mixdq_igemm_select.restype = _i32
 
 ABI_VERSION = _lib.mixdq_abi_version()
+# This binding is written against ONE data-layout contract (include/mixdq_hip.h MIXDQ_ABI_VERSION: e.g. ABI 3
+# stores GEMM+GEGLU weight rows as value|gate groups of 16 where ABI 2 had 32): a library of another
+# version (MIXDQ_HIP_LIB A/B runs) would compute silently different tensors -- refuse it here.
+EXPECTED_ABI = 3
+if ABI_VERSION != EXPECTED_ABI:
+    raise ImportError(f"{LIB_PATH} reports ABI version {ABI_VERSION}; mixdq_amd._C is written for "
+                      f"ABI {EXPECTED_ABI} (rebuild with `python -m mixdq_amd.build --force`)")
 
 
 _lib.mixdq_igemm_select_id.argtypes = [_i64, _i32, _i32, _i32]
@@ -99,7 +106,7 @@ IGEMM_CONFIGS = {1: (64, 64, 64, 2), 3: (128, 128, 64, 2), 4: (64, 64, 128, 3),
                  42: (64, 80, 128, 3), 43: (64, 240, 128, 3), 44: (128, 80, 128, 3),
                  45: (64, 80, 128, 4), 46: (128, 320, 64, 4), 56: (64, 80, 128, 6),
                  # 256x256x128 on the four-phase loop (2 x 4 waves of 128x64, 16x16x64 MFMAs)
-                 70: (256, 256, 128, 2), 71: (256, 256, 64, 4)}
+                 70: (256, 256, 128, 2)}
 
 FLAG_W4 = 2   # MIXDQ_FLAG_W4: the weight tensor holds packed signed 4-bit values
 FLAG_UPSAMPLE2X = 4   # MIXDQ_FLAG_UPSAMPLE2X: the conv input is read through a nearest 2x upsampling
@@ -850,6 +857,10 @@ def attention_f16(q, k, v, heads, scale_inv=None, zero_point=None, softmax_scale
     _check(k.shape == v.shape and k.shape[0] == B and k.shape[2] == C, "q/k/v shapes disagree")
     _check(C == heads * 64, "head_dim must be 64")
     quant = scale_inv is not None
+    # (measurement only) recorded as ("attention", (B * heads * Tq, Tkv, 64, 64)): 4 * M * N * K FLOPs
+    _record("attention", B * heads * Tq, k.shape[1], 64, 64, False, attention_f16,
+            (q, k, v, heads), dict(scale_inv=scale_inv, zero_point=zero_point,
+                                   softmax_scale=softmax_scale, _cfg=_cfg))
     out = torch.empty((B, Tq, C), dtype=torch.int8 if quant else torch.float16, device=q.device)
     sc = float(softmax_scale) if softmax_scale is not None else 0.125
     with torch.cuda.device(q.device):

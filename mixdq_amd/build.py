@@ -20,7 +20,14 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 # Per-file extras.  attention.hip: keep the MFMA accumulators in VGPRs — the softmax works on them
 # between the two products, and the default AGPR form costs ~190 v_accvgpr moves per K/V tile.
-EXTRA = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+# igemm.hip: the dispatcher preloads the first 14 dwords of the kernel arguments into scalar registers
+# (csrc/igemm.hip MIXDQ_KP: the operands the prologue DMAs depend on are leading scalar arguments), so the
+# first memory request of a launch does not wait for a scalar-cache round trip: (1024, 1280, 1280) in a
+# dependent chain 5.95 -> 5.79 us, batch-1 step 11.60 -> 11.41 ms (same box, tools/kp_build.sh A/B).
+# Not on the other files: a kernel that gains nothing from it pays for the preload at every wave
+# launch (quantize on 8 elements: 1.58 -> 1.71 us).
+EXTRA = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+         "igemm.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=14"]}
 OBJ = os.path.join(PKG, "_obj")
 
 

@@ -25,6 +25,20 @@ inline int launch_status() {
   return hipGetLastError() == hipSuccess ? MIXDQ_OK : MIXDQ_ERR_LAUNCH;
 }
 
+// Opt a kernel in to more than 64 KiB of dynamic LDS.  The attribute is a property of the kernel ON A
+// DEVICE: it is applied once per (instantiation, device) -- `seen` is the instantiation's own static
+// table -- so that a process that drives several devices through the C-ABI gets it on each of them.
+inline int lds_opt_in(const void* kernel, int bytes, bool (&seen)[64]) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MIXDQ_ERR_LAUNCH;
+  if (!seen[dev]) {
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
+      return MIXDQ_ERR_LAUNCH;
+    seen[dev] = true;
+  }
+  return MIXDQ_OK;
+}
+
 // ---- arithmetic specification ------------------------------------------
 // Quantize one value: q = clamp(rint(x * s_inv + zp)).  rint = round-half-to-even (v_rndne_f32),
 // the float->int conversion saturates and maps NaN to 0 (v_cvt_i32_f32), as cvt.rni does on the

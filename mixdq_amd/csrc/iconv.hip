@@ -388,10 +388,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloConvArgs
 template <int TH, int TW, int BN, int CK>
 int launch_halo(const HaloConvArgs& a, hipStream_t stream) {
   using G = HaloGeom<TH, TW, BN, CK>;
-  static const hipError_t attr = hipFuncSetAttribute(
-      reinterpret_cast<const void*>(&conv3x3_halo_kernel<TH, TW, BN, CK>),
-      hipFuncAttributeMaxDynamicSharedMemorySize, G::SMEM);
-  if (attr != hipSuccess) return MIXDQ_ERR_LAUNCH;
+  static bool seen[64] = {};
+  if (const int st = lds_opt_in(reinterpret_cast<const void*>(&conv3x3_halo_kernel<TH, TW, BN, CK>),
+                                G::SMEM, seen))
+    return st;
   const int64_t grid = (int64_t)a.NI * (a.H / TH) * (a.W / TW) * ((a.K + BN - 1) / BN);
   if (grid <= 0 || grid > 0x7fffffff) return MIXDQ_ERR_INVALID_ARG;
   conv3x3_halo_kernel<TH, TW, BN, CK><<<dim3((unsigned)grid), 512, G::SMEM, stream>>>(a);

@@ -85,6 +85,7 @@ struct IgemmParams {
   const __half* res;     // optional residual added AFTER the fp16 rounding of the epilogue:
   int64_t res_div;       //   D = f16(f32(f16(epilogue)) + f32(res[(m / res_div) * N + n]))
   int tiles_m, tiles_n;
+  int gm;                // m-tiles per super-row of the tile map (8; MIXDQ_IGEMM_GM overrides it for A/B runs)
   int unfused;
   // GEGLU epilogue (Dq != null): the N = 2D output columns are value|gate groups of 16
   // ([v 0..15 | g 0..15 | v 16..31 | ...], weight rows pre-interleaved by the host); the tile is
@@ -149,15 +150,23 @@ __global__ __launch_bounds__(256) void gelu_table_init_kernel() {
   g_gelu_tab[i] = __half_as_ushort(f32_to_f16_rn(mixdq_geluf(g)));
 }
 
-// the table is built by the first launch that needs it, on that launch's stream (stream-ordered in
-// front of the consumer; idempotent, so a repeat from a second stream or inside a graph is harmless)
+// The table is built once per device by the first launch that needs it.  `done[dev]` is only set once
+// the table IS in memory for every stream: outside a capture the init kernel runs on the caller's
+// stream and is waited for (one host synchronisation per device and process, at first use).  Inside a
+// stream capture nothing may synchronise and the kernel is only RECORDED, so the init is recorded in
+// front of the consumer in that graph (idempotent: every replay rewrites the same bits) and `done`
+// stays false -- an eager launch or a later capture before the first replay builds the table itself.
 inline int ensure_gelu_table(hipStream_t stream) {
   static bool done[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MIXDQ_ERR_LAUNCH;
-  if (!done[dev]) {
-    gelu_table_init_kernel<<<(2 * kGeluTabMag + 255) / 256, 256, 0, stream>>>();
-    if (hipGetLastError() != hipSuccess) return MIXDQ_ERR_LAUNCH;
+  if (done[dev]) return MIXDQ_OK;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cap) != hipSuccess) return MIXDQ_ERR_LAUNCH;
+  gelu_table_init_kernel<<<(2 * kGeluTabMag + 255) / 256, 256, 0, stream>>>();
+  if (hipGetLastError() != hipSuccess) return MIXDQ_ERR_LAUNCH;
+  if (cap == hipStreamCaptureStatusNone) {
+    if (hipStreamSynchronize(stream) != hipSuccess) return MIXDQ_ERR_LAUNCH;
     done[dev] = true;
   }
   return MIXDQ_OK;
@@ -262,6 +271,33 @@ __device__ __forceinline__ uint32_t add_f16x2(uint32_t a, uint32_t b) {
   return *reinterpret_cast<const uint32_t*>(&h);
 }
 
+// Kernel-argument preload (gfx950: the dispatcher can place the first 14 dwords of the argument block in
+// scalar registers before the first wave starts; hipcc -mllvm -amdgpu-kernarg-preload-count=14 marks the
+// leading SCALAR arguments -- a by-value struct is never preloaded).  The operands the first memory
+// request of a launch depends on are therefore passed a second time, as leading scalars: the per-lane
+// staging offsets and the prologue DMAs need nothing else, and the rest of the block (one scalar-cache
+// round trip, ~0.5 us cold) arrives under them.
+#ifndef MIXDQ_KP
+#define MIXDQ_KP 1
+#endif
+#if MIXDQ_KP
+#define MIXDQ_IGEMM_HEAD_PARAMS                                                                      \
+  const int8_t* __restrict__ hA, const int8_t* __restrict__ hWt, int64_t hM, int hN, int hKtot,       \
+      int htm_gm, int htn, const float* __restrict__ hb0, const float* __restrict__ hsc,
+// (the super-row height of the tile map rides in the top byte of the preloaded tiles_m word)
+#define MIXDQ_IGEMM_HEAD_TAKE(p)                                                                     \
+  do { (p).A = hA; (p).Wt = hWt; (p).M = hM; (p).N = hN; (p).Ktot = hKtot;                            \
+       (p).tiles_m = htm_gm & 0xffffff; (p).gm = (int)((unsigned)htm_gm >> 24);                        \
+       (p).tiles_n = htn; (p).bias0 = hb0; (p).scale = hsc; } while (0)
+#define MIXDQ_IGEMM_HEAD_ARGS(p)                                                                     \
+  (p).A, (p).Wt, (p).M, (p).N, (p).Ktot, (int)((unsigned)(p).tiles_m | ((unsigned)(p).gm << 24)),     \
+      (p).tiles_n, (p).bias0, (p).scale,
+#else
+#define MIXDQ_IGEMM_HEAD_PARAMS
+#define MIXDQ_IGEMM_HEAD_TAKE(p) do {} while (0)
+#define MIXDQ_IGEMM_HEAD_ARGS(p)
+#endif
+
 // FAST (Linear only): K % BK == 0 and every operand offset fits 32 bits.  Then the staging needs
 // no per-K-tile vector arithmetic at all: each lane keeps one constant 32-bit byte offset per
 // DMA piece and the K-tile advance is a scalar add on the uniform base pointer (saddr form of
@@ -299,8 +335,8 @@ __global__ __launch_bounds__(
     64 * WM * WN * KSPLIT,
     (ATT ? 2 : igemm_waves_per_simd<BM, BN, BK, STAGES, WM * WN * KSPLIT,
                                     (BM / WM / MT) * (BN / WN / MT) * (MT == 32 ? 16 : 4)>()))
-void igemm_kernel(const IgemmParams p_in) {
-  static_assert(!PHASED || (BM == 256 && BN == 256 && ((BK == 128 && STAGES == 2) || (BK == 64 && STAGES == 4)) &&
+void igemm_kernel(MIXDQ_IGEMM_HEAD_PARAMS const IgemmParams p_in) {
+  static_assert(!PHASED || (BM == 256 && BN == 256 && BK == 128 && STAGES == 2 &&
                             WM == 2 && WN == 4 && KSPLIT == 1 && MT == 16 && FAST && !CONV && !W4 &&
                             !F16 && !ATT),
                 "the phased loops are written for the 256x256 tile, 2 x 4 waves of 128x64");
@@ -308,19 +344,31 @@ void igemm_kernel(const IgemmParams p_in) {
   static_assert(!ATT || (BM == 64 && BN == 128 && NWAVES_OF(WM, WN, KSPLIT) == 8 && MT == 32 && !CONV &&
                          !F16), "the attention epilogue is written for the 64x128 8-wave tile");
   static_assert(!(CONV && FAST), "the fast staging path is for Linear");
-  // every argument requested at once (common.h): 1.2-2.6 us from wave start to the first DMA before
-  MIXDQ_ARGS_NOW(p_in.A, p_in.Wt, p_in.bias0, p_in.scale, p_in.bias, p_in.table, p_in.zp, p_in.D,
-                 p_in.M, p_in.N, p_in.Ktot, p_in.tiles_m, p_in.tiles_n, p_in.groups, p_in.Dq, p_in.res);
-  MIXDQ_ARGS_NOW(p_in.H, p_in.W, p_in.C, p_in.R, p_in.S, p_in.P, p_in.Q, p_in.stride, p_in.pad,
-                 p_in.grp_rows, p_in.grp_stride, p_in.grp_off, p_in.res_div, p_in.unfused,
-                 p_in.g_sinv, p_in.g_zp);
-  if constexpr (ATT) {
-    MIXDQ_ARGS_NOW(p_in.att_k, p_in.att_v, p_in.att_k_bs, p_in.att_v_bs, p_in.att_k_rs, p_in.att_v_rs,
-                   p_in.att_tkv, p_in.att_tq, p_in.att_scale_log2, p_in.att_out, p_in.att_sinv,
-                   p_in.att_zp);
-  }
+  // every argument requested at once (common.h): 1.2-2.6 us from wave start to the first DMA before.
+  // LATE_ARGS (Linear fast path with preloaded head arguments): the tile map, the per-lane staging offsets
+  // and the prologue DMAs need the preloaded scalars only, so the rest of the argument block is asked
+  // for (and waited for) BEHIND the prologue DMAs -- its scalar-cache round trip runs under them.
+  constexpr bool LATE_ARGS = MIXDQ_KP && FAST && !ATT && !GROUPED;
+  auto args_now = [&]() {
+#if MIXDQ_KP
+    MIXDQ_ARGS_NOW(p_in.bias, p_in.table, p_in.zp, p_in.D, p_in.groups, p_in.Dq, p_in.res);
+#else
+    MIXDQ_ARGS_NOW(p_in.A, p_in.Wt, p_in.bias0, p_in.scale, p_in.bias, p_in.table, p_in.zp, p_in.D,
+                   p_in.M, p_in.N, p_in.Ktot, p_in.tiles_m, p_in.tiles_n, p_in.groups, p_in.Dq, p_in.res);
+#endif
+    MIXDQ_ARGS_NOW(p_in.H, p_in.W, p_in.C, p_in.R, p_in.S, p_in.P, p_in.Q, p_in.stride, p_in.pad,
+                   p_in.grp_rows, p_in.grp_stride, p_in.grp_off, p_in.res_div, p_in.unfused,
+                   p_in.g_sinv, p_in.g_zp);
+    if constexpr (ATT) {
+      MIXDQ_ARGS_NOW(p_in.att_k, p_in.att_v, p_in.att_k_bs, p_in.att_v_bs, p_in.att_k_rs, p_in.att_v_rs,
+                     p_in.att_tkv, p_in.att_tq, p_in.att_scale_log2, p_in.att_out, p_in.att_sinv,
+                     p_in.att_zp);
+    }
+  };
+  if constexpr (!LATE_ARGS) args_now();
   IgemmParams p = p_in;
-  int nwg = p_in.tiles_m * p_in.tiles_n;   // == gridDim.x (which would be one more dependent load)
+  MIXDQ_IGEMM_HEAD_TAKE(p);
+  int nwg = p.tiles_m * p.tiles_n;   // == gridDim.x (which would be one more dependent load)
   if constexpr (GROUPED) {          // one member of a grouped launch (wave-uniform scalar loads)
     const mixdq_gemm_group g = p_in.groups[blockIdx.y];
     p.Wt = g.W; p.bias0 = g.bias0; p.scale = g.scale; p.bias = (const __half*)g.bias_f16_or_null;
@@ -370,7 +418,7 @@ void igemm_kernel(const IgemmParams p_in) {
   const int bid = blockIdx.x;
   const int xcd = bid % kNumXCD, q8 = nwg / kNumXCD, r8 = nwg % kNumXCD;
   const int wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / kNumXCD;
-  constexpr int GM = 8;
+  const int GM = p.gm;
   const int per_group = GM * p.tiles_n;
   const int group = wg / per_group;
   const int first_m = group * GM;
@@ -380,49 +428,57 @@ void igemm_kernel(const IgemmParams p_in) {
   const int64_t m0 = (int64_t)tile_m * BM;
   const int n0 = tile_n * BN;
 
-  // ---- residual operand of the epilogue, requested NOW on the small tiles: it comes cold (another
+  // ---- residual operand of the epilogue, requested up front on the small tiles: it comes cold (another
   //      kernel just wrote it), and read inside the store loop its ~1 us of latency sat at the very
-  //      end of every to_out / ff.net.2 / conv2 launch of the batch-1 chain.  These loads are older
-  //      than every DMA piece, so the counted waits of the main loop cover them.
+  //      end of every to_out / ff.net.2 / conv2 launch of the batch-1 chain.  Requested in front of the
+  //      prologue DMAs (or, LATE_ARGS, right behind them: then the first counted wait also waits for
+  //      these few loads, which were issued next to the stage it waits for) and used behind the main
+  //      loop's final vmcnt(0).
   constexpr int RES_ITERS = (BM * (BN / 8) + 64 * WM * WN * KSPLIT - 1) / (64 * WM * WN * KSPLIT);
   constexpr bool RES_PRE = !ATT && !GROUPED && RES_ITERS <= 2;
   uint4 res_pre[RES_PRE ? RES_ITERS : 1];
-  const bool res_pre_on = RES_PRE && p.res != nullptr && (p.N & 7) == 0;
-  if constexpr (RES_PRE) {
-    if (res_pre_on) {     // wave-uniform; addresses clamped into the tensor instead of predicated, so
-#pragma unroll            // that no select sits between the load and its use after the main loop
-      for (int it = 0; it < RES_ITERS; ++it) {
-        const int idx = min(tid + it * (64 * WM * WN * KSPLIT), BM * (BN / 8) - 1);
-        const int row = idx / (BN / 8), cc = idx - row * (BN / 8);
-        const int64_t m = min(m0 + row, p.M - 1);
-        const int n = n0 + cc * 8 < p.N ? n0 + cc * 8 : 0;
-        res_pre[it] = *reinterpret_cast<const uint4*>(
-            p.res + (p.res_div == 1 ? m : m / p.res_div) * p.N + n);
-      }
-    }
-  }
-  // ---- this thread's slice of the per-channel epilogue vectors (threads < BN / 4), requested now
+  bool res_pre_on = false;
+  // ---- this thread's slice of the per-channel epilogue vectors (threads < BN / 4), requested up front
   //      too and parked in registers: they go to LDS behind the main loop.  (Stored to LDS right
   //      here, as round 2 did, the store's vmcnt(0) made the first waves wait for EVERY prologue
   //      stage -- five K-tiles on the six-stage tile -- before the first K-tile could be computed.)
   //      P_B0: bias0[n] (table mode: the full-window class row), P_SC: scale[n], P_BS: bias[n].
-  const bool has_bias = p.bias != nullptr;
-  const bool use_table = p.table != nullptr;
-  const int full_cls = (((p.R - 1)) * p.S) * p.S + (p.S - 1);   // rlo=0, rhi=R-1, slo=0, shi=S-1
+  bool has_bias = false, use_table = false;
+  int full_cls = 0;
   v4f pre_b0, pre_sc;
   uint2 pre_bs;
   const bool pre_on = tid < BN / 4;
   const bool pre_in = n0 + tid * 4 < p.N;
-  if (pre_on) {
-    const int n = pre_in ? n0 + tid * 4 : 0;
-    if constexpr (!F16) {
-      const float* b0src = p.bias0;
-      if constexpr (CONV) if (use_table) b0src = p.table + (int64_t)full_cls * p.N;
-      pre_b0 = *reinterpret_cast<const v4f*>(b0src + n);
-      pre_sc = *reinterpret_cast<const v4f*>(p.scale + n);
+  auto early_loads = [&]() {
+    res_pre_on = RES_PRE && p.res != nullptr && (p.N & 7) == 0;
+    if constexpr (RES_PRE) {
+      if (res_pre_on) {   // wave-uniform; addresses clamped into the tensor instead of predicated, so
+#pragma unroll            // that no select sits between the load and its use after the main loop
+        for (int it = 0; it < RES_ITERS; ++it) {
+          const int idx = min(tid + it * (64 * WM * WN * KSPLIT), BM * (BN / 8) - 1);
+          const int row = idx / (BN / 8), cc = idx - row * (BN / 8);
+          const int64_t m = min(m0 + row, p.M - 1);
+          const int n = n0 + cc * 8 < p.N ? n0 + cc * 8 : 0;
+          res_pre[it] = *reinterpret_cast<const uint4*>(
+              p.res + (p.res_div == 1 ? m : m / p.res_div) * p.N + n);
+        }
+      }
     }
-    if (has_bias) pre_bs = *reinterpret_cast<const uint2*>(p.bias + n);
-  }
+    has_bias = p.bias != nullptr;
+    use_table = p.table != nullptr;
+    full_cls = (((p.R - 1)) * p.S) * p.S + (p.S - 1);   // rlo=0, rhi=R-1, slo=0, shi=S-1
+    if (pre_on) {
+      const int n = pre_in ? n0 + tid * 4 : 0;
+      if constexpr (!F16) {
+        const float* b0src = p.bias0;
+        if constexpr (CONV) if (use_table) b0src = p.table + (int64_t)full_cls * p.N;
+        pre_b0 = *reinterpret_cast<const v4f*>(b0src + n);
+        pre_sc = *reinterpret_cast<const v4f*>(p.scale + n);
+      }
+      if (has_bias) pre_bs = *reinterpret_cast<const uint2*>(p.bias + n);
+    }
+  };
+  if constexpr (!LATE_ARGS) early_loads();
 
   const char* zero = reinterpret_cast<const char*>(&g_zero16);
   const int Ktot = p.Ktot;
@@ -693,91 +749,35 @@ void igemm_kernel(const IgemmParams p_in) {
         glds16(p.Wt + kk_u + ph_b[h][j], S + A_STAGE + ((q >> 2) * 64 + h * 32 + (q & 3) * 8) * BK);
     }
   };
-  // ---- PHASED, BK = 64: the same tile over 64-byte K-tiles in a ring of FOUR buffers ----------
-  // The loop above keeps 32-48 KB of DMA in flight per CU and moves ~31 GB/s per CU: with ~1 us of
-  // loaded L2 latency the bytes in flight are the limit, and what can be in flight is what LDS can
-  // land.  Here a K-tile is 32 KB (one 16x16x64 k-step): one buffer is read while up to five 16-KB
-  // units (activation tile, weight tile, alternating; 2.5 K-tiles) fly into the other three.  Two
-  // phases per K-tile (the wave's row halves), 16 MFMAs each; unit P + 5 is staged in phase P.
-  unsigned ph4_a[2], ph4_b[2];          // per-lane source offsets of a unit's two pieces
-  if constexpr (PHASED && BK == 64) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int r = (wid * 2 + j) * 16 + (lane >> 2);                // piece = 16 rows x 64 B
-      const int64_t m = m0 + r;
-      const int n = n0 + r;
-      ph4_a[j] = (uint32_t)(m < p.M ? m : p.M - 1) * (uint32_t)Ktot + (((lane & 3) ^ swz<BK>(r)) << 4);
-      ph4_b[j] = (uint32_t)min(n, p.N - 1) * (uint32_t)Ktot + (((lane & 3) ^ swz<BK>(r)) << 4);
+  // LATE_ARGS: the rest of the argument block is waited for behind the FIRST prologue stage (the
+  // address unit is busy with that stage's requests for ~0.5 us anyway), and the epilogue operands are
+  // requested there: older than every later stage, so the first counted wait covers them with the
+  // stage they were issued next to.
+  auto late_args = [&]() {
+    if constexpr (LATE_ARGS) {
+      args_now();
+      early_loads();
     }
-  }
-  auto stage_unit4 = [&](int u) {       // unit u: the activation (even) or weight (odd) tile of K-tile u / 2
-    const int kt = u >> 1;
-    const int kk_u = __builtin_amdgcn_readfirstlane(kt * BK < Ktot ? kt * BK : 0);
-    char* S = smem + (kt & 3) * STAGE + ((u & 1) ? A_STAGE : 0);
-    const int8_t* src = ((u & 1) ? p.Wt : p.A) + kk_u;
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-      glds16(src + ((u & 1) ? ph4_b[j] : ph4_a[j]), S + (wid * 2 + j) * 1024);
   };
   if constexpr (!PHASED) {
+    stage(0, 0);
+    late_args();
 #pragma unroll
-    for (int s = 0; s < PRE; ++s) stage(s, s * BK);
-  } else if constexpr (BK == 128) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) stage_unit(0, 0, u);
+    for (int s = 1; s < PRE; ++s) stage(s, s * BK);
   } else {
-#pragma unroll
-    for (int u = 0; u < 5; ++u) stage_unit4(u);
+    stage_unit(0, 0, 0);
+    stage_unit(0, 0, 1);
+    late_args();
+    stage_unit(0, 0, 2);
+    stage_unit(0, 0, 3);
   }
-
   MIXDQ_STAMP_AT(1);
   constexpr int PARAM_OFF = igemm_main_bytes<BM, BN, BK, STAGES>();
   float* P_B0 = reinterpret_cast<float*>(smem + PARAM_OFF);
   float* P_SC = P_B0 + BN;
   __half* P_BS = reinterpret_cast<__half*>(P_SC + BN);
 
-  if constexpr (PHASED && BK == 64) {
-    const int a_lane = (wm * WTM + lrow) * BK + ((lkq ^ swz<BK>(lrow)) << 4);
-    const int b_lane = A_STAGE + (wn * WTN + lrow) * BK + ((lkq ^ swz<BK>(lrow)) << 4);
-    v4i af[4], bf[4];
-    auto half = [&](int mh) {
-      asm volatile("s_barrier\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_setprio(1);
-#if MIXDQ_ABLATE == 1
-#pragma unroll
-      for (int t = 0; t < 4; ++t) { asm volatile("" ::"v"(bf[t])); asm volatile("" ::"v"(af[t])); }
-#else
-#pragma unroll
-      for (int tn = 0; tn < 4; ++tn)
-#pragma unroll
-        for (int tm = 0; tm < 4; ++tm) acc[tn][mh * 4 + tm] = mfma(bf[tn], af[tm], acc[tn][mh * 4 + tm]);
-#endif
-      __builtin_amdgcn_s_setprio(0);
-      asm volatile("s_barrier" ::: "memory");
-    };
-    // K-tile 0 has landed (units 2..4 may fly) and is visible to every wave
-    asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
-    if (wid >= 4) asm volatile("s_barrier" ::: "memory");   // the second wave group: one barrier behind
-    for (int kt = 0; kt < nk; ++kt) {
-      const char* S0 = smem + (kt & 3) * STAGE;
-#pragma unroll
-      for (int t = 0; t < 4; ++t) bf[t] = *reinterpret_cast<const v4i*>(S0 + b_lane + t * 16 * BK);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) af[t] = *reinterpret_cast<const v4i*>(S0 + a_lane + t * 16 * BK);
-      if (MIXDQ_ABLATE != 3) stage_unit4(2 * kt + 5);
-      half(0);
-#pragma unroll
-      for (int t = 0; t < 4; ++t) af[t] = *reinterpret_cast<const v4i*>(S0 + a_lane + (4 + t) * 16 * BK);
-      if (MIXDQ_ABLATE != 3) stage_unit4(2 * kt + 6);
-      // K-tile kt + 1 (units 2 kt + 2, 2 kt + 3): waited for one phase before its first read, so
-      // that both wave groups' pieces are behind a barrier every reader has passed
-      if (MIXDQ_ABLATE != 5) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-      half(1);
-    }
-    if (wid < 4) asm volatile("s_barrier" ::: "memory");    // the groups meet again
-  }
-  if constexpr (PHASED && BK == 128) {
+  if constexpr (PHASED) {
     // fragment read offsets: the swizzle term depends on the lane's row within its 16-row tile
     // only, so every other tile of the wave is the same address plus an immediate
     const int a_lane = (wm * WTM + lrow) * BK, b_lane = A_STAGE + (wn * WTN + lrow) * BK;
@@ -1553,27 +1553,40 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const __half* __restrict_
   }
 }
 
+// m-tiles per super-row of the blockIdx -> tile map: 8 (super-rows of 1, 2, 4, 16 measured equal or worse
+// on the UNet's shapes; MIXDQ_IGEMM_GM=<1..64> overrides it for A/B runs)
+inline int tile_map_gm() {
+  static const int gm = [] {
+    const char* e = getenv("MIXDQ_IGEMM_GM");
+    const int v = e ? atoi(e) : 8;
+    return v >= 1 && v <= 64 ? v : 8;
+  }();
+  return gm;
+}
+
 template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool CONV, bool FAST, bool W4, int KSPLIT,
           int MT, bool F16 = false, bool PHASED = false, bool GROUPED = false>
 int launch_kernel(IgemmParams& p, hipStream_t stream) {
   constexpr int SMEM = igemm_smem_bytes<BM, BN, BK, STAGES>();
   static_assert(SMEM <= 160 * 1024, "LDS is 160 KiB per CU");
   if (p.Dq != nullptr && BN % 32 != 0) return MIXDQ_ERR_GEGLU_SHAPE;   // whole value|gate groups per tile
-  if constexpr (SMEM > 64 * 1024) {   // opt in to > 64 KiB of dynamic LDS, once per instantiation
-    static const hipError_t attr = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(
-            &igemm_kernel<BM, BN, BK, STAGES, WM, WN, CONV, FAST, W4, KSPLIT, MT, F16, false, PHASED, GROUPED>),
-        hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-    if (attr != hipSuccess) return MIXDQ_ERR_LAUNCH;
+  if constexpr (SMEM > 64 * 1024) {   // opt in to > 64 KiB of dynamic LDS, once per instantiation and device
+    static bool seen[64] = {};
+    if (const int st = lds_opt_in(
+            reinterpret_cast<const void*>(
+                &igemm_kernel<BM, BN, BK, STAGES, WM, WN, CONV, FAST, W4, KSPLIT, MT, F16, false, PHASED, GROUPED>),
+            SMEM, seen))
+      return st;
   }
   p.tiles_m = (int)((p.M + BM - 1) / BM);
   p.tiles_n = (p.N + BN - 1) / BN;
+  p.gm = tile_map_gm();
   const int64_t grid = (int64_t)p.tiles_m * p.tiles_n;
-  if (grid <= 0 || grid > 0x7fffffff) return MIXDQ_ERR_INVALID_ARG;
+  if (grid <= 0 || grid > 0x7fffffff || p.tiles_m >= (1 << 24)) return MIXDQ_ERR_INVALID_ARG;
   const int ny = GROUPED ? p.ngroups_launch : 1;
   if (GROUPED != (p.groups != nullptr)) return MIXDQ_ERR_INVALID_ARG;
   igemm_kernel<BM, BN, BK, STAGES, WM, WN, CONV, FAST, W4, KSPLIT, MT, F16, false, PHASED, GROUPED>
-      <<<dim3((unsigned)grid, (unsigned)ny), 64 * WM * WN * KSPLIT, SMEM, stream>>>(p);
+      <<<dim3((unsigned)grid, (unsigned)ny), 64 * WM * WN * KSPLIT, SMEM, stream>>>(MIXDQ_IGEMM_HEAD_ARGS(p) p);
   return launch_status();
 }
 
@@ -1621,8 +1634,7 @@ int launch_tile(IgemmParams& p, hipStream_t stream) {
   X(46, 128, 320, 64, 4, 4, 2, 1, 32, false)     \
   X(47, 128, 320, 64, 5, 4, 2, 1, 32, false)     \
   X(56, 64, 80, 128, 6, 4, 1, 2, 16, false)  \
-  X(70, 256, 256, 128, 2, 2, 4, 1, 16, true)   \
-  X(71, 256, 256, 64, 4, 2, 4, 1, 16, true)
+  X(70, 256, 256, 128, 2, 2, 4, 1, 16, true)
 
 struct TileCfg { int id, bm, bn, bk, stages, wm, wn, ksplit, mt; };
 constexpr TileCfg kTileCfgs[] = {
@@ -1792,17 +1804,18 @@ int launch_att(IgemmParams& p, hipStream_t stream) {
   constexpr int BM = 64, BN = 128, BK = 128, ST = 3;
   constexpr int SMEM = ((igemm_smem_bytes<BM, BN, BK, ST>() + 1023) / 1024) * 1024 + 4 * kStageBytes;
   static_assert(SMEM <= 160 * 1024, "LDS is 160 KiB per CU");
-  static const hipError_t attr = hipFuncSetAttribute(
-      reinterpret_cast<const void*>(
-          &igemm_kernel<BM, BN, BK, ST, 2, 4, false, true, W4, 1, 32, false, true>),
-      hipFuncAttributeMaxDynamicSharedMemorySize, SMEM);
-  if (attr != hipSuccess) return MIXDQ_ERR_LAUNCH;
+  static bool seen[64] = {};
+  if (const int st = lds_opt_in(
+          reinterpret_cast<const void*>(&igemm_kernel<BM, BN, BK, ST, 2, 4, false, true, W4, 1, 32, false, true>),
+          SMEM, seen))
+    return st;
   p.tiles_m = (int)((p.M + BM - 1) / BM);
   p.tiles_n = (p.N + BN - 1) / BN;
+  p.gm = tile_map_gm();
   const int64_t grid = (int64_t)p.tiles_m * p.tiles_n;
-  if (grid <= 0 || grid > 0x7fffffff) return MIXDQ_ERR_INVALID_ARG;
+  if (grid <= 0 || grid > 0x7fffffff || p.tiles_m >= (1 << 24)) return MIXDQ_ERR_INVALID_ARG;
   igemm_kernel<BM, BN, BK, ST, 2, 4, false, true, W4, 1, 32, false, true>
-      <<<dim3((unsigned)grid), 512, SMEM, stream>>>(p);
+      <<<dim3((unsigned)grid), 512, SMEM, stream>>>(MIXDQ_IGEMM_HEAD_ARGS(p) p);
   return launch_status();
 }
 

@@ -171,3 +171,119 @@ def test_producers_full_batch_sampled_rows_vs_oracle(C, oracle, B):
     assert (err <= 2e-3 + 4e-3 * np.abs(ref)).all(), err.max()
     one = C.attention_f16(d[B - 1:, :, :128], d[B - 1:, :, 128:256], d[B - 1:, :, 256:], 2)
     assert torch.equal(att[B - 1:], one)
+
+
+# ---- per-GPU batch 32 / 64: the N = 2 and N = 1 shards of BASELINE.json configs[3] (global batch 64) ----
+# Inputs are generated on the GPU (hundreds of MB per tensor); only the sampled rows travel to the host.
+
+def _rand_i8(shape, seed):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    return torch.randint(-128, 128, shape, generator=g, dtype=torch.int8, device=DEV)
+
+
+@pytest.mark.parametrize("B", [32, 64])
+def test_shard_size_geglu_sampled_rows_vs_oracle(C, oracle, B):
+    """ff.net.0.proj + GEGLU + quantize at (B x 1024, 10240, 1280) on the four-phase 256x256 tile."""
+    M, D, K = B * 1024, 5120, 1280
+    a = _rand_i8((M, K), 900 + B)
+    w = dd.int8(52, (2 * D, K))
+    scale, bias0 = dd.f32(53, (2 * D,), 2e-5, 9e-5), dd.f32(54, (2 * D,), -3000, 3000)
+    s_inv, zp = float(np.float32(1) / np.float32(0.02)), -60.0
+    perm = C.geglu_row_order(D, DEV)
+    got = C.qlinear_geglu(a, t(w)[perm].contiguous(), t(scale)[perm].contiguous(),
+                          t(bias0)[perm].contiguous(), None, scal(s_inv), scal(zp))
+    assert C.igemm_select_id(M, 2 * D, K, geglu=True) == 70
+    rows = sample_rows(M, 96, 7 * B)
+    idx = torch.from_numpy(rows).to(DEV)
+    h = oracle.qlinear(a[idx].cpu().numpy(), w, bias0, scale, None, C.FLAGS & 1)
+    q_ref, _ = oracle.geglu_quantize(h, s_inv, zp, C.FLAGS & 1)
+    assert np.array_equal(got[idx].cpu().numpy(), q_ref)
+    # batch equivariance: three images alone (their own tile rule: M = 1024 runs on 128x320)
+    for i in (0, B // 2, B - 1):
+        one = C.qlinear_geglu(a[i * 1024:(i + 1) * 1024], t(w)[perm].contiguous(),
+                              t(scale)[perm].contiguous(), t(bias0)[perm].contiguous(), None,
+                              scal(s_inv), scal(zp))
+        assert torch.equal(got[i * 1024:(i + 1) * 1024], one), f"image {i}"
+
+
+@pytest.mark.parametrize("B", [32, 64])
+def test_shard_size_linear_640_sampled_rows_vs_oracle(C, oracle, B):
+    """(B x 4096, 640, 640) with a residual epilogue: the 640-channel to_q / to_out layers (M = 262144
+    rows at batch 64)."""
+    M, N, K = B * 4096, 640, 640
+    a = _rand_i8((M, K), 300 + B)
+    w = dd.int8(2, (N, K))
+    b0, sc, bs = dd.f32(3, (N,), -4000, 4000), dd.f32(4, (N,), 1e-4, 1e-3), dd.f16(5, (N,), -1, 1)
+    g = torch.Generator(device=DEV).manual_seed(5 + B)
+    res = (torch.randn(M, N, generator=g, device=DEV) * 0.5).half()
+    out = C.qlinear_w8_a8_ohalf(a, t(w), t(sc), scal(1), scal(0), t(b0), t(sc), t(b0), t(bs),
+                                _residual=res)
+    assert C.igemm_select_id(M, N, K) == 35
+    rows = sample_rows(M, 160, M + N)
+    idx = torch.from_numpy(rows).to(DEV)
+    want = oracle.add_f16(oracle.qlinear(a[idx].cpu().numpy(), w, b0, sc, bs, C.FLAGS & 1),
+                          res[idx].cpu().numpy())
+    assert np.array_equal(bits(out[idx].cpu().numpy()), bits(want))
+    for i in (0, B // 2, B - 1):
+        sl = slice(i * 4096, (i + 1) * 4096)
+        one = C.qlinear_w8_a8_ohalf(a[sl], t(w), t(sc), scal(1), scal(0), t(b0), t(sc), t(b0), t(bs),
+                                    _residual=res[sl].contiguous())
+        assert torch.equal(out[sl], one), f"image {i}"
+
+
+@pytest.mark.parametrize("B", [32, 64])
+@pytest.mark.parametrize("ks,Cin,Cout", [(3, 320, 320), (1, 640, 320)],
+                         ids=["3x3_halo_128px_c320", "1x1_shortcut_128px_640to320"])
+def test_shard_size_conv_equals_per_image_and_oracle(C, oracle, B, ks, Cin, Cout):
+    """Level-0 convs at B x 128 x 128 pixels (1 048 576 output pixels at batch 64): the halo-resident 3x3
+    kernel and the 1x1 shortcut (second half of a split: bias0 form + residual epilogue)."""
+    HW, pad = 128, ks // 2
+    x = _rand_i8((B, HW, HW, Cin), 31 * B + ks)                  # NHWC memory
+    wt = dd.int8(61, (Cout, ks, ks, Cin))
+    sc = dd.f32(62, (Cout,), 1e-5, 1e-4)
+    bias = dd.f16(63, (Cout,), -1, 1)
+    zp = -37.0
+    wsum = wt.astype(np.float32).sum(axis=3, dtype=np.float32)
+    b0 = (wsum.reshape(Cout, -1).sum(axis=1, dtype=np.float32) * np.float32(zp)).astype(np.float32)
+    g = torch.Generator(device=DEV).manual_seed(11 + B)
+    res = None
+    if ks == 1:                                                  # the other half's output, added in the epilogue
+        res = (torch.randn(B, HW, HW, Cout, generator=g, device=DEV) * 0.5).half().permute(0, 3, 1, 2)
+
+    def run(xi, ri):
+        return C.qconv2d_w8_a8_ohalf(
+            xi.permute(0, 3, 1, 2), t(wt).permute(0, 3, 1, 2), t(sc), scal(1), scal(zp), t(sc),
+            t(wsum.reshape(Cout, 1, ks, ks)) if pad else None, None if pad else t(b0), t(bias), 1, pad,
+            _residual=ri)
+
+    full = run(x, res)
+    if ks == 3:
+        assert C.conv_halo_select(B, HW, HW, Cin, Cout, 3, 3, 1, 1) == 92
+    for i in (0, B // 2, B - 1):                                 # batch equivariance, bit for bit
+        assert torch.equal(full[i:i + 1], run(x[i:i + 1], None if res is None else res[i:i + 1])), f"image {i}"
+    rows = 4                                                     # a top band of the LAST image vs the oracle
+    band = x[B - 1:B, :rows + pad].cpu().numpy()
+    want = oracle.qconv2d(band, wt, sc, wsum if pad else None, zp, None if pad else b0, bias, 1, pad,
+                          C.FLAGS & 1)
+    got = full[B - 1].permute(1, 2, 0)[:rows].contiguous().cpu().numpy()
+    want = want[0, :rows]
+    if res is not None:
+        want = oracle.add_f16(want.reshape(-1, Cout),
+                              res[B - 1].permute(1, 2, 0)[:rows].reshape(-1, Cout).cpu().numpy()
+                              ).reshape(want.shape)
+    assert np.array_equal(bits(got), bits(want)), "band vs oracle"
+
+
+def test_qlinear_operand_over_4_gib_leaves_the_32bit_offset_path(C, oracle):
+    """M x K >= 2^32 bytes: the fast staging path keeps one 32-bit byte offset per lane and is gated on
+    the operand fitting it (csrc/igemm.hip launch_tile); above that the launch must take the general
+    path with 64-bit row pointers -- nothing at the UNet's sizes reaches the gate."""
+    M, N, K = 2_200_000, 64, 2048                                # 4.5 GB of int8 activations
+    a = _rand_i8((M, K), 4242)
+    w = dd.int8(2, (N, K))
+    b0, sc = dd.f32(3, (N,), -4000, 4000), dd.f32(4, (N,), 1e-4, 1e-3)
+    out = C.qlinear_w8_a8_ohalf(a, t(w), t(sc), scal(1), scal(0), t(b0), t(sc), t(b0), None)
+    rows = np.unique(np.concatenate([sample_rows(M, 64, 1), [2_097_151, 2_097_152, 2_097_153]]))
+    idx = torch.from_numpy(rows).to(DEV)                         # rows either side of the 2^32-byte line
+    want = oracle.qlinear(a[idx].cpu().numpy(), w, b0, sc, None, C.FLAGS & 1)
+    assert np.array_equal(bits(out[idx].cpu().numpy()), bits(want))

@@ -1,0 +1,133 @@
+"""BASELINE.json configs[0] tied to the HIP path on identical inputs.
+
+The 794-layer SDXL UNet at 512 px, batch 1, `uniform_8` + `act_8.00` with the BOS carve-out runs twice on
+the SAME seeded weights, inputs and calibrated quantizer state:
+
+  * on the GPU: the module-swapped network on the HIP kernels, fused graph (the benchmarked path) and
+    unfused (the drop-in);
+  * on the host, FP32: the same graph with `oracle/fakequant.quant_layer_forward` -- the restatement of
+    the reference's qdiff `QuantLayer.forward` (quant_layer.py:63-103, base_quantizer.py:119-129),
+    pinned bit-for-bit by tests/golden/fakequant.npz -- in place of every accelerated layer.  This is
+    what the `cpu_baseline` leg of bench.py times.
+
+Path A divides by the step and rounds activations to the integer grid in FP32, the kernels multiply by
+the reciprocal and round every layer output to FP16, so the two agree at quantization-noise level, not
+bit for bit (the reference's own tolerance between its two paths is rtol = atol = 1e-2 per layer,
+op/qlinear.py:101).  Every bound is relative to a noise level measured here: the distance of the Path A
+network from the FP32 network.  A wiring mistake at real shapes (a wrong scale, zero point, BOS row,
+split half, row map) is an O(1) error and fails.  Collected last (tests/conftest.py): ~2 minutes of host
+time on the GPU box's cores."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+class _Cfg:
+    def __init__(self, w, a):
+        self.w_config, self.a_config = w, a
+
+
+def _host_path_a_(unet_c, ckpt, accelerated, split_of):
+    """Swap the forward of every accelerated layer of the FP32 host network for Path A (8-bit)."""
+    from mixdq_amd.calib import _is_bos_layer
+    from mixdq_amd.unet import quantizable_layers
+    from oracle.fakequant import quant_layer_forward
+    i8 = 2                                            # index of 8 bit in the [2, 4, 8] lists
+
+    def q(name, suffix=""):
+        wq, aq = ckpt[f"{name}.weight_quantizer{suffix}"], ckpt[f"{name}.act_quantizer{suffix}"]
+        return (wq["delta_list"][i8].float(), aq["delta_list"][i8].float(),
+                aq["zero_point_list"][i8].float())
+
+    for name, mod in quantizable_layers(unet_c).items():
+        if not accelerated[name]:
+            continue                                  # the reference's FP fallback (nn/Linear.py:155-156)
+        w_d, a_d, a_zp = q(name)
+        split = split_of[name]
+        extra = {}
+        if split:
+            w_d0, a_d0, a_zp0 = q(name, "_0")
+            extra = dict(split=split, w_delta_0=w_d0, a_delta_0=a_d0, a_zp_0=a_zp0)
+        kw = None
+        if isinstance(mod, nn.Conv2d):
+            kw = dict(stride=mod.stride, padding=mod.padding, dilation=mod.dilation, groups=1)
+        bos = _is_bos_layer(name)
+
+        def fwd(x, mod=mod, w_d=w_d, a_d=a_d, a_zp=a_zp, kw=kw, extra=extra, bos=bos):
+            y = quant_layer_forward(x, mod.weight, mod.bias, w_d, a_d, a_zp, 8, 8, kw, **extra)
+            if bos and x.dim() == 3 and x.shape[1] > 1:      # token 0: the FP carve-out (nn/Linear.py:178-194)
+                y[:, 0, :] = F.linear(x[:, 0, :], mod.weight, mod.bias)
+            return y
+        mod.forward = fwd
+
+
+def test_full_unet_512px_hip_path_matches_host_path_a_within_quantization_noise(C):
+    from mixdq_amd import cfgs
+    from mixdq_amd.calib import calibrate, precompute_bos
+    from mixdq_amd.nn import QuantizedConv2d, QuantizedLinear
+    from mixdq_amd.quantize_sdxl import example_inputs, quantize_unet
+    from mixdq_amd.unet import build_unet, quantizable_layers
+
+    unet = build_unet(DEV)                                         # FP16, seeded
+    inp = example_inputs(1, 64, DEV, seed=42)                      # 512 px
+    host = dict(sample=inp["sample"].float().cpu(), timestep=inp["timestep"].float().cpu(),
+                encoder_hidden_states=inp["encoder_hidden_states"].float().cpu(),
+                added_cond_kwargs={k: v.float().cpu() for k, v in inp["added_cond_kwargs"].items()})
+    unet_c = build_unet("cpu", dtype=torch.float32)
+    unet_c.load_state_dict({k: v.float().cpu() for k, v in unet.state_dict().items()})   # the SAME (fp16-valued) weights
+    with torch.no_grad():
+        ckpt = calibrate(unet_c, [host])                           # host forward 1: min-max statistics
+        ref32 = unet_c(**host)[0]                                  # host forward 2: the FP32 network
+        bos = {k: v.half().to(DEV) for k, v in
+               precompute_bos(unet_c, host["encoder_hidden_states"]).items()}
+        ref16 = unet(**inp)[0].float().cpu()                       # PyTorch's FP16 network on the GPU
+    split_of = {n: (getattr(m, "split", 0) if ("up_blocks" in n and "conv_shortcut" in n) else 0)
+                for n, m in quantizable_layers(unet_c).items()}
+
+    quantize_unet(unet, _Cfg(cfgs.load("weight/uniform_8"), cfgs.load("act/act_8.00")), ckpt, bos=True,
+                  bos_dict=bos)
+    mods = dict(unet.named_modules())
+    accelerated = {n: bool(getattr(mods[n], "valid_for_acceleration", False)) for n in split_of}
+    assert sum(accelerated.values()) == 785                        # 794 - 9 act-protected
+    assert all(isinstance(mods[n], (QuantizedLinear, QuantizedConv2d)) for n in split_of)
+    with torch.no_grad():
+        unfused = unet(**inp)[0].float().cpu()
+        unet.set_fused(True)
+        fused = unet(**inp)[0].float().cpu()
+    del unet
+    torch.cuda.empty_cache()
+
+    _host_path_a_(unet_c, ckpt, accelerated, split_of)
+    with torch.no_grad():
+        path_a = unet_c(**host)[0]                                 # host forward 3: Path A (fake-quant)
+
+    def dist(a, b):
+        d = (a - b).abs()
+        return d.mean().item(), d.max().item()
+
+    spread = ref32.std().item()
+    n_mean, n_max = dist(path_a, ref32)                            # Path A's own quantization noise
+    f_mean, f_max = dist(ref16, ref32)                             # what FP16 arithmetic alone costs
+    report = {}
+    for tag, out in (("fused", fused), ("unfused", unfused)):
+        assert torch.isfinite(out).all()
+        d_mean, d_max = dist(out, path_a)                          # HIP path vs Path A
+        e_mean, e_max = dist(out, ref32)                           # HIP path vs the FP32 network
+        report[tag] = dict(d_mean=d_mean, d_max=d_max, e_mean=e_mean, e_max=e_max)
+    msg = f"spread {spread:.4f} noise {n_mean:.5f}/{n_max:.4f} fp16 {f_mean:.5f}/{f_max:.4f} {report}"
+    print(msg)
+    assert n_mean < 0.1 * spread, msg                              # the quantized network still tracks the FP32 one
+    for tag, r in report.items():
+        # the two implementations of the SAME quantized network agree to within its quantization noise
+        assert r["d_mean"] <= 1.0 * n_mean + 1e-4, (tag, msg)
+        assert r["d_max"] <= 3.0 * n_max + 1e-3, (tag, msg)
+        # ... and the HIP path is no further from the FP32 network than Path A is
+        assert r["e_mean"] <= 1.25 * n_mean + 1e-4, (tag, msg)
+        assert r["e_max"] <= 2.0 * n_max + 1e-3, (tag, msg)
+        # against what FP16 arithmetic alone costs: W8A8 noise on this
+        # random-weight network is a bounded multiple of it (measured on MI355X: see DESIGN.md section 4)
+        assert r["e_mean"] <= 60.0 * f_mean + 1e-4, (tag, msg)

@@ -1,17 +1,35 @@
 #!/bin/bash
 # Build the HIP library of another commit for same-box A/B runs: build/ab_<name>/libmixdq_hip.so
 #   bash tools/ab_build.sh <commit> <name>;  MIXDQ_HIP_LIB=$PWD/build/ab_<name>/libmixdq_hip.so python bench.py ...
+# The file lists (sources, headers, per-file flags) are taken from THAT commit's mixdq_amd/build.py.
+# (mixdq_amd._C refuses a library of another ABI version: A/B across an ABI change needs that commit's
+# Python too.)
 set -e
 cd "$(dirname "$0")/.."
 c=$1; n=$2; d=build/ab_$n
-mkdir -p $d/mixdq_amd/csrc $d/include
-for f in quantize.hip igemm.hip fused_norm.hip attention.hip common.h attn_core.h; do git show $c:mixdq_amd/csrc/$f > $d/mixdq_amd/csrc/$f; done
-for f in mixdq_hip.h mixdq_math.h; do git show $c:include/$f > $d/include/$f; done
-F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function"
-pids=""
-for f in quantize igemm fused_norm; do /opt/rocm/bin/hipcc $F -c -o $d/$f.o $d/mixdq_amd/csrc/$f.hip & pids="$pids $!"; done
-/opt/rocm/bin/hipcc $F -mllvm -amdgpu-mfma-vgpr-form=1 -c -o $d/attention.o $d/mixdq_amd/csrc/attention.hip & pids="$pids $!"
-for p in $pids; do wait $p; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $d/libmixdq_hip.so $d/quantize.o $d/igemm.o $d/fused_norm.o $d/attention.o
-rm -rf $d/mixdq_amd $d/include $d/*.o
+rm -rf $d/src; mkdir -p $d/src/mixdq_amd/csrc $d/src/include
+git show $c:mixdq_amd/build.py > $d/src/build_py.py
+python3 - "$c" "$d" <<'PY'
+import importlib.util, os, subprocess, sys
+c, d = sys.argv[1:3]
+spec = importlib.util.spec_from_file_location("build_py", os.path.join(d, "src", "build_py.py"))
+b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+csrc = os.path.join(d, "src", "mixdq_amd", "csrc")
+for f in list(b.SOURCES) + list(b.HEADERS):
+    rel = os.path.normpath(os.path.join("mixdq_amd/csrc", f))
+    out = os.path.normpath(os.path.join(csrc, f))
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    open(out, "wb").write(subprocess.check_output(["git", "show", f"{c}:{rel}"]))
+procs, objs = [], []
+for src in b.SOURCES:
+    obj = os.path.join(d, src.replace(".hip", ".o")); objs.append(obj)
+    flags = [f for f in b.FLAGS if f != "-Wall"] + list(getattr(b, "EXTRA", {}).get(src, []))
+    procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc"] + flags + ["-c", "-o", obj, os.path.join(csrc, src)]))
+assert all(p.wait() == 0 for p in procs), "compile failed"
+subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o",
+                       os.path.join(d, "libmixdq_hip.so")] + objs)
+for o in objs:
+    os.remove(o)
+PY
+rm -rf $d/src
 echo $d/libmixdq_hip.so

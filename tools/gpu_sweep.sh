@@ -4,7 +4,7 @@ out=gpurun_out/sweep
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
 timeout 900 python tools/bench_gemm.py --bs 1 2>&1 | grep -v amdgpu > $out/w8_bs1.txt
-timeout 900 python tools/bench_gemm.py --bs 8 --cfgs 3,13,14,15,18,20,25,35,41,44,46,70,71 2>&1 | grep -v amdgpu > $out/w8_bs8.txt
+timeout 900 python tools/bench_gemm.py --bs 8 --cfgs 3,13,14,15,18,20,25,35,41,44,46,70 2>&1 | grep -v amdgpu > $out/w8_bs8.txt
 timeout 900 python tools/bench_gemm.py --bs 2 --cfgs 3,4,13,18,25,35,37,41,42,43,44,45,56,46,70 2>&1 | grep -v amdgpu > $out/w8_bs2.txt
 python - <<PY
 import json

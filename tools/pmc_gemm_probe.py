@@ -3,6 +3,7 @@
     rocprofv3 --pmc <counters> --output-format csv -d out -- python3 tools/pmc_gemm_probe.py lin   M N K [cfg]
                                                               ... python3 tools/pmc_gemm_probe.py geglu M N K [cfg]
                                                               ... python3 tools/pmc_gemm_probe.py conv  IMG HW CIN COUT [cfg]
+                                                              ... python3 tools/pmc_gemm_probe.py attn  B T C   (self-attention, heads = C / 64)
 Inputs are made on the CPU and copied; no PyTorch GPU kernel is launched (rocprofv3 --pmc segfaults
 inside some torch reduction launches on this image)."""
 import os
@@ -32,6 +33,12 @@ if kind in ("lin", "geglu"):
             C.qlinear_geglu(a, w, sc, sc, None, one, zero, _cfg=cfg)
         else:
             C.qlinear_w8_a8_ohalf(a, w, sc, zero, zero, sc, sc, sc, None, _cfg=cfg)
+elif kind == "attn":
+    B, T, Cc = a1, a2, a3
+    qkv = (torch.randn(B, T, 3 * Cc, generator=g) * 1.0).half().to("cuda")     # the fused q|k|v projection's layout
+    s_inv = torch.full((), 20.0).to("cuda")
+    for _ in range(REPS):
+        C.attention_f16(qkv[..., :Cc], qkv[..., Cc:2 * Cc], qkv[..., 2 * Cc:], Cc // 64, s_inv, zero)
 else:
     NI, HW, CIN = a1, a2, a3
     COUT, cfg = rest[0], (rest[1] if len(rest) > 1 else 0)

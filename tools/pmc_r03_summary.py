@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""gpurun_out/r03_pmc/raw/* (tools/pmc_r03.sh) -> summary.json: per probed launch the HBM-side bytes
+"""<out>/raw/* (tools/pmc_r04.sh, round 3: tools/pmc_r03.sh) -> summary.json: per probed launch the HBM-side bytes
 (FETCH_SIZE x 2 + WRITE_SIZE, KiB -> bytes: MI355X_MICROARCH.md, HBM section), the algorithmic bytes, and
 from the SQ pass mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES) and the wave-cycle split."""
 import collections
@@ -14,7 +14,14 @@ res = {}
 for line in open(out + "/shapes.txt"):
     i, kind, *v = line.split()
     v = [int(t) for t in v]
-    if kind == "conv":
+    peak_kind = "int8"
+    if kind == "attn":
+        B, T, Cc = v[:3]
+        M, N, K = B * (Cc // 64) * T, T, 64                 # 4 M N K FLOPs: Q K^T and P V
+        alg = 4 * 2 * B * T * Cc                            # q, k, v read + o written, fp16 / int8 mix: fp16 bound
+        shape = f"attn B{B} T{T} C{Cc}"
+        peak_kind = "f16"
+    elif kind == "conv":
         NI, HW, CIN, COUT = v[:4]
         M, N, K = NI * HW * HW, COUT, 9 * CIN
         alg = NI * HW * HW * CIN + N * K + 2 * M * N
@@ -24,13 +31,13 @@ for line in open(out + "/shapes.txt"):
         alg = M * K + N * K + (M * N // 2 if kind == "geglu" else 2 * M * N)
         shape = f"{kind} M{M} N{N} K{K}"
     entry = {}
-    for p in ("FETCH_SIZE", "WRITE_SIZE", "SQ"):
+    for p in ("FETCH_SIZE", "WRITE_SIZE", "SQ", "SQ2"):
         f = glob.glob(f"{out}/raw/{p}_{i}/**/*counter_collection.csv", recursive=True)
         if not f:
             continue
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f[0])):
-            if "igemm_kernel" not in r["Kernel_Name"] and "conv3x3_halo" not in r["Kernel_Name"]:
+            if not any(t in r["Kernel_Name"] for t in ("igemm_kernel", "conv3x3_halo", "attn_fwd_kernel")):
                 continue
             k = re.sub(r"\(.*$", "", r["Kernel_Name"].replace("mixdq::(anonymous namespace)::", "").replace("void ", ""))
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -53,7 +60,13 @@ for line in open(out + "/shapes.txt"):
                 if c in e:
                     e[c + "_frac_of_wave_cycles"] = e[c] / e["SQ_WAVE_CYCLES"]
         dur = e.get("SQ:_dur_ns", e.get("FETCH_SIZE:_dur_ns", 1))
-        e["int8_tops_profiled"] = 2.0 * M * N * K / (dur * 1e-9) / 1e12
+        if peak_kind == "f16":
+            e["f16_tflops_profiled"] = 4.0 * M * N * K / (dur * 1e-9) / 1e12
+        else:
+            e["int8_tops_profiled"] = 2.0 * M * N * K / (dur * 1e-9) / 1e12
+        # VALU-busy (second SQ pass): vector-ALU instruction cycles of all waves over the CUs' busy cycles x 4 SIMDs
+        if "SQ_ACTIVE_INST_VALU" in e and e.get("SQ_BUSY_CU_CYCLES"):
+            e["valu_util"] = 4.0 * e["SQ_ACTIVE_INST_VALU"] / (4.0 * e["SQ_BUSY_CU_CYCLES"])   # quad-cycles -> cycles
         res[f"{k} @ {shape}"] = e
 json.dump(res, open(out + "/summary.json", "w"), indent=1, sort_keys=True)
 for k, e in sorted(res.items()):
