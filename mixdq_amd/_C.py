@@ -100,6 +100,7 @@ def igemm_select(M: int, N: int, k_align: int, k_total: int = 0):
 IGEMM_CONFIGS = {1: (64, 64, 64, 2), 3: (128, 128, 64, 2), 4: (64, 64, 128, 3),
                  13: (256, 128, 64, 3), 14: (256, 256, 64, 3), 15: (128, 256, 64, 3),
                  18: (256, 128, 128, 2), 20: (256, 256, 128, 2), 25: (128, 320, 128, 2),
+                 27: (128, 320, 128, 2),   # the same tile on 16 waves of 16 x 160 (16x16x64 MFMAs)
                  35: (128, 128, 64, 3), 37: (64, 64, 128, 3), 41: (64, 128, 128, 3),
                  # 16x16x64-MFMA tiles (exactly one workgroup per CU on the UNet's M = 1024 / 4096
                  # layers; 45 / 56: deeper pipelines) and the 4-stage 128x320 tile

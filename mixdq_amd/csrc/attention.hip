@@ -325,9 +325,16 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
   for (int i = 0; i < 8; ++i) ones[i] = (_Float16)1.f;
 
+  // SHORT key sequences (every tile fits the prologue: cross-attention, 77 keys = 2 tiles): only the
+  // real tiles are staged, all of them up front, and the loop below stages nothing -- its counted
+  // waits are then satisfied at once.  (Staged like a long sequence, 3 of the 5 stages a workgroup
+  // issued were dummies re-reading the last key: 48 of 80 DMA pieces.)  Same arithmetic, same order.
+  const bool short_k = ntiles <= PRE;            // wave-uniform
 #pragma unroll
-  for (int s = 0; s < PRE; ++s) stage(s, s);     // tiles past the end re-stage the last key
-  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((PRE - 1) * NI) : "memory");
+  for (int s = 0; s < PRE; ++s)
+    if (!short_k || s < ntiles) stage(s, s);     // long: tiles past the end re-stage the last key
+  if (short_k) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((PRE - 1) * NI) : "memory");
   v16f S[2][2];                                  // scores: S[t & 1] softmaxed now, S[~t & 1] next
   qk(0, 0, S[0]);
   v8h P[2][2][2];                                // P[t & 1]: probabilities of tile t, FP16, B operand
@@ -347,7 +354,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2
       // tile t+1 has landed (PRE-2 younger tiles may still fly); every wave is past tile t-1 --
       // its V fragments are in registers (lgkmcnt) -- whose buffer is restaged next
       asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"((PRE - 2) * NI) : "memory");
-      stage((sb + PRE) % STAGES, t + PRE);
+      if (!short_k) stage((sb + PRE) % STAGES, t + PRE);
       unsigned k_next[4];                          // past the last tile: a re-staged key, unused
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) k_next[ks] = k_a[ks] + ((sb + 1) % STAGES) * kStageBytes;

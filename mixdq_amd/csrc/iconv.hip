@@ -346,11 +346,32 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloConvArgs
     else if (!p.unfused) to_tile(std::integral_constant<int, 1>{});
     else to_tile(std::integral_constant<int, 2>{});
   }
-  __syncthreads();
   // whole 16-byte row segments out; thread -> (pixel, chunk), chunk fastest
   constexpr int CPRO = BN / 8;
   const bool n8 = (p.K & 7) == 0;
-  for (int idx = tid; idx < BM * CPRO; idx += G::NTHREADS) {
+  // the residual operand (conv2: the block input, cold -- another kernel just wrote it): every chunk
+  // this thread needs is requested here, at once, and lands under the barrier and the LDS reads below.
+  // (Read inside the store loop it cost one dependent memory round trip per iteration: the compiler
+  // cannot move a load of `res` across a store to `D`.)
+  constexpr int ST_ITERS = (BM * CPRO + G::NTHREADS - 1) / G::NTHREADS;
+  static_assert(ST_ITERS <= 8, "residual chunks parked in registers");
+  v4i res_late[ST_ITERS];
+  const bool res_late_on = p.res != nullptr && n8;
+  if (res_late_on) {
+#pragma unroll
+    for (int it = 0; it < ST_ITERS; ++it) {
+      const int idx = min(tid + it * G::NTHREADS, BM * CPRO - 1);
+      const int row = idx / CPRO, cc = idx - row * CPRO;
+      const int n = n0 + cc * 8 < p.K ? n0 + cc * 8 : 0;
+      const int64_t pix = ((int64_t)img * p.H + (y0 + row / TW)) * p.W + (x0 + row % TW);
+      res_late[it] = *reinterpret_cast<const v4i*>(p.res + (p.res_div == 1 ? pix : (int64_t)img) * p.K + n);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < ST_ITERS; ++it) {
+    const int idx = tid + it * G::NTHREADS;
+    if (idx >= BM * CPRO) break;
     const int row = idx / CPRO, cc = idx - row * CPRO;
     const int n = n0 + cc * 8;
     if (n >= p.K) continue;
@@ -360,8 +381,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloConvArgs
       const __half* rp = p.res + (p.res_div == 1 ? pix : (int64_t)img) * p.K + n;
       uint32_t rw[4];
       if (n8) {
-        const uint4 r = *reinterpret_cast<const uint4*>(rp);
-        rw[0] = r.x; rw[1] = r.y; rw[2] = r.z; rw[3] = r.w;
+        const v4i r = res_late[it];
+        rw[0] = (uint32_t)r[0]; rw[1] = (uint32_t)r[1]; rw[2] = (uint32_t)r[2]; rw[3] = (uint32_t)r[3];
       } else {
         const uint2 r0 = *reinterpret_cast<const uint2*>(rp);
         rw[0] = r0.x; rw[1] = r0.y; rw[2] = 0; rw[3] = 0;
@@ -377,7 +398,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloConvArgs
     __half* dst = p.D + pix * p.K + n;
     if (n8) {
       const v4i vv = {(int)v.x, (int)v.y, (int)v.z, (int)v.w};
-      asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(vv) : "memory");
+      // global_store_dwordx4 ... nt, through the builtin: the compiler then counts the store in vmcnt and pads
+        // the gfx950 store-data hazard (a store of more than 64 bits reads its data registers up to two wait
+        // states after issue).  As inline asm it did neither: a VALU write of the first data register right
+        // behind the asm was picked up by the store (tests/test_ops_gpu.py halo cases, round 4).
+        __builtin_nontemporal_store(vv, reinterpret_cast<v4i*>(dst));
     } else {
       *reinterpret_cast<uint2*>(dst) = make_uint2(v.x, v.y);
       if (n + 8 <= p.K) *reinterpret_cast<uint2*>(dst + 4) = make_uint2(v.z, v.w);

@@ -262,6 +262,16 @@ constexpr int igemm_waves_per_simd() {
   return w;
 }
 
+// f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{}): a loop whose index is a
+// compile-time constant in every iteration (register arrays indexed by it stay in registers)
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void igemm_unrolled(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    igemm_unrolled<N, I + 1>(f);
+  }
+}
+
 // two packed fp16 + two packed fp16, each lane as torch's half add: f32 add, one rounding
 __device__ __forceinline__ uint32_t add_f16x2(uint32_t a, uint32_t b) {
   const v2h ah = *reinterpret_cast<const v2h*>(&a), bh = *reinterpret_cast<const v2h*>(&b);
@@ -366,6 +376,18 @@ void igemm_kernel(MIXDQ_IGEMM_HEAD_PARAMS const IgemmParams p_in) {
     }
   };
   if constexpr (!LATE_ARGS) args_now();
+#ifndef MIXDQ_KARG_WARM
+#define MIXDQ_KARG_WARM 1
+#endif
+  // LATE_ARGS: the rest of the argument block is read by scalar loads that the compiler issues next to the
+  // wait behind the first prologue stage -- cold, that is a trip to memory.  Four lanes touch its cache lines
+  // with a vector load right here, so that the scalar loads find them in L2.
+  int karg_warm = 0;
+  if constexpr (LATE_ARGS && MIXDQ_KARG_WARM) {
+    const auto ka = (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    if ((threadIdx.x & ~3u) == 0)
+      karg_warm = *(const __attribute__((address_space(4))) int*)(ka + 64 + 64 * (threadIdx.x & 3));
+  }
   IgemmParams p = p_in;
   MIXDQ_IGEMM_HEAD_TAKE(p);
   int nwg = p.tiles_m * p.tiles_n;   // == gridDim.x (which would be one more dependent load)
@@ -380,6 +402,9 @@ void igemm_kernel(MIXDQ_IGEMM_HEAD_PARAMS const IgemmParams p_in) {
   static_assert(!(F16 && W4), "packed weights are an INT8-path format");
   static_assert(MT == 32 || MT == 16, "MFMA shapes: 32x32x32 or 16x16x64");
   constexpr int NWAVES = WM * WN * KSPLIT, NTHREADS = 64 * NWAVES;
+  // registers per lane the launch bound leaves this kernel (512 per SIMD lane over the waves per SIMD)
+  constexpr int REG_CAP = 512 / (ATT ? 2 : igemm_waves_per_simd<BM, BN, BK, STAGES, WM * WN * KSPLIT,
+                                                                 (BM / WM / MT) * (BN / WN / MT) * (MT == 32 ? 16 : 4)>());
   constexpr int WTM = BM / WM, WTN = BN / WN;     // wave tile (WM x WN waves)
   constexpr int TM = WTM / MT, TN = WTN / MT;     // MT x MT MFMA tiles per wave
   constexpr int KSTEP = MT == 32 ? 32 : 64;       // k-values one MFMA consumes
@@ -434,6 +459,11 @@ void igemm_kernel(MIXDQ_IGEMM_HEAD_PARAMS const IgemmParams p_in) {
   //      prologue DMAs (or, LATE_ARGS, right behind them: then the first counted wait also waits for
   //      these few loads, which were issued next to the stage it waits for) and used behind the main
   //      loop's final vmcnt(0).
+  // lane -> (tile row, 16-byte k-chunk of the k-step) of an MFMA fragment: 32x32x32 has the row on lane & 31
+  // and two chunks (lane >> 5), 16x16x64 the row on lane & 15 and four chunks (lane >> 4); in the
+  // accumulator the same lane holds output row `lrow` and 4 consecutive channels per register quad
+  const int lrow = MT == 32 ? (lane & 31) : (lane & 15);
+  const int lkq = MT == 32 ? (lane >> 5) : (lane >> 4);
   constexpr int RES_ITERS = (BM * (BN / 8) + 64 * WM * WN * KSPLIT - 1) / (64 * WM * WN * KSPLIT);
   constexpr bool RES_PRE = !ATT && !GROUPED && RES_ITERS <= 2;
   uint4 res_pre[RES_PRE ? RES_ITERS : 1];
@@ -450,6 +480,9 @@ void igemm_kernel(MIXDQ_IGEMM_HEAD_PARAMS const IgemmParams p_in) {
   const bool pre_on = tid < BN / 4;
   const bool pre_in = n0 + tid * 4 < p.N;
   auto early_loads = [&]() {
+    has_bias = p.bias != nullptr;
+    use_table = p.table != nullptr;
+    full_cls = (((p.R - 1)) * p.S) * p.S + (p.S - 1);   // rlo=0, rhi=R-1, slo=0, shi=S-1
     res_pre_on = RES_PRE && p.res != nullptr && (p.N & 7) == 0;
     if constexpr (RES_PRE) {
       if (res_pre_on) {   // wave-uniform; addresses clamped into the tensor instead of predicated, so
@@ -464,9 +497,6 @@ void igemm_kernel(MIXDQ_IGEMM_HEAD_PARAMS const IgemmParams p_in) {
         }
       }
     }
-    has_bias = p.bias != nullptr;
-    use_table = p.table != nullptr;
-    full_cls = (((p.R - 1)) * p.S) * p.S + (p.S - 1);   // rlo=0, rhi=R-1, slo=0, shi=S-1
     if (pre_on) {
       const int n = pre_in ? n0 + tid * 4 : 0;
       if constexpr (!F16) {
@@ -613,41 +643,6 @@ void igemm_kernel(MIXDQ_IGEMM_HEAD_PARAMS const IgemmParams p_in) {
     }
   };
 
-  // ---- fragment read offsets (loop invariant; the LDS buffer base is a compile-time constant
-  //      after the K loop is unrolled by STAGES, so each ds_read_b128 needs no address arithmetic)
-  // lane -> (tile row, 16-byte k-chunk of the k-step): 32x32x32 has the row on lane & 31 and two
-  // chunks (lane >> 5), 16x16x64 the row on lane & 15 and four chunks (lane >> 4)
-  const int lrow = MT == 32 ? (lane & 31) : (lane & 15);
-  const int lkq = MT == 32 ? (lane >> 5) : (lane >> 4);
-  constexpr int KS = BK / KSTEP / KSPLIT;            // k-steps of a K-tile this wave computes
-  static_assert((BK / KSTEP) % KSPLIT == 0 && KS >= 1, "k-split groups take whole k-steps");
-  int a_rd[TM][KS], b_rd[TN][KS];
-#pragma unroll
-  for (int t = 0; t < TM; ++t) {
-    const int row = wm * WTM + t * MT + lrow;
-#pragma unroll
-    for (int i = 0; i < KS; ++i) {
-      const int ks = kg * KS + i;
-      a_rd[t][i] = row * BK + (((ks * CPS + lkq) ^ swz<BK>(row)) << 4);
-    }
-  }
-#pragma unroll
-  for (int t = 0; t < TN; ++t) {
-    const int row = wn * WTN + t * MT + lrow;
-#pragma unroll
-    for (int i = 0; i < KS; ++i) {
-      const int ks = kg * KS + i;
-      const int c = ks * CPS + lkq;   // this lane's 16-k chunk of the K-tile
-      if constexpr (!W4) {
-        b_rd[t][i] = A_STAGE + row * BK + ((c ^ swz<BK>(row)) << 4);
-      } else {   // packed: 16 k-values = 8 bytes, half (c & 1) of the 32-k piece c >> 1
-        constexpr int KSP = BK / 32;
-        b_rd[t][i] = A_STAGE + row * (BK / 2) + (((c >> 1) ^ ((row >> 3) & (KSP - 1))) << 4) +
-                     (c & 1) * 8;
-      }
-    }
-  }
-
   using acc_i = typename std::conditional<MT == 32, v16i, v4i>::type;
   using acc_f = typename std::conditional<MT == 32, v16f, v4f>::type;
   using acc_t = typename std::conditional<F16, acc_f, acc_i>::type;
@@ -675,12 +670,6 @@ void igemm_kernel(MIXDQ_IGEMM_HEAD_PARAMS const IgemmParams p_in) {
     }
   };
   acc_t acc[TN][TM];
-#pragma unroll
-  for (int a = 0; a < TN; ++a)
-#pragma unroll
-    for (int b = 0; b < TM; ++b)
-#pragma unroll
-      for (int e = 0; e < ACC; ++e) acc[a][b][e] = 0;
 
   // ---- main loop: STAGES LDS buffers, STAGES-1 K-tiles of LDS-DMA in flight.  Per K-tile ONE
   //      counted wait (never vmcnt(0)) + ONE raw s_barrier: the wait retires this wave's DMA
@@ -761,17 +750,62 @@ void igemm_kernel(MIXDQ_IGEMM_HEAD_PARAMS const IgemmParams p_in) {
   };
   if constexpr (!PHASED) {
     stage(0, 0);
+    MIXDQ_STAMP_AT(12);
     late_args();
+    MIXDQ_STAMP_AT(13);
 #pragma unroll
     for (int s = 1; s < PRE; ++s) stage(s, s * BK);
   } else {
     stage_unit(0, 0, 0);
     stage_unit(0, 0, 1);
+    MIXDQ_STAMP_AT(12);
     late_args();
+    MIXDQ_STAMP_AT(13);
     stage_unit(0, 0, 2);
     stage_unit(0, 0, 3);
   }
   MIXDQ_STAMP_AT(1);
+  // (everything below is needed by the main loop only: it is computed behind the prologue DMAs, whose
+  //  requests are on their way meanwhile)
+  // ---- fragment read offsets (loop invariant; the LDS buffer base is a compile-time constant
+  //      after the K loop is unrolled by STAGES, so each ds_read_b128 needs no address arithmetic)
+  // lane -> (tile row, 16-byte k-chunk of the k-step): 32x32x32 has the row on lane & 31 and two
+  // chunks (lane >> 5), 16x16x64 the row on lane & 15 and four chunks (lane >> 4)
+  constexpr int KS = BK / KSTEP / KSPLIT;            // k-steps of a K-tile this wave computes
+  static_assert((BK / KSTEP) % KSPLIT == 0 && KS >= 1, "k-split groups take whole k-steps");
+  int a_rd[TM][KS], b_rd[TN][KS];
+#pragma unroll
+  for (int t = 0; t < TM; ++t) {
+    const int row = wm * WTM + t * MT + lrow;
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+      const int ks = kg * KS + i;
+      a_rd[t][i] = row * BK + (((ks * CPS + lkq) ^ swz<BK>(row)) << 4);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    const int row = wn * WTN + t * MT + lrow;
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+      const int ks = kg * KS + i;
+      const int c = ks * CPS + lkq;   // this lane's 16-k chunk of the K-tile
+      if constexpr (!W4) {
+        b_rd[t][i] = A_STAGE + row * BK + ((c ^ swz<BK>(row)) << 4);
+      } else {   // packed: 16 k-values = 8 bytes, half (c & 1) of the 32-k piece c >> 1
+        constexpr int KSP = BK / 32;
+        b_rd[t][i] = A_STAGE + row * (BK / 2) + (((c >> 1) ^ ((row >> 3) & (KSP - 1))) << 4) +
+                     (c & 1) * 8;
+      }
+    }
+  }
+
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b)
+#pragma unroll
+      for (int e = 0; e < ACC; ++e) acc[a][b][e] = 0;
   constexpr int PARAM_OFF = igemm_main_bytes<BM, BN, BK, STAGES>();
   float* P_B0 = reinterpret_cast<float*>(smem + PARAM_OFF);
   float* P_SC = P_B0 + BN;
@@ -933,7 +967,34 @@ void igemm_kernel(MIXDQ_IGEMM_HEAD_PARAMS const IgemmParams p_in) {
   }
   // the zero-page DMAs staged for tiles >= nk are still in flight: drain before LDS is reused
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  asm volatile("" ::"v"(karg_warm));     // (the warm-up load's only use: nothing waits for it before this)
   MIXDQ_STAMP_AT(3);
+  // ---- residual operand of the LARGE tiles (more than two 16-byte chunks per thread: not parked in
+  //      registers across the main loop): every chunk of it is requested at once -- in front of the
+  //      accumulator pass where the registers are there for it (the address unit is idle during that pass),
+  //      behind it otherwise (the accumulators are dead by then).  (Read inside the store loop, one dependent memory round trip per iteration -- the
+  //      compiler cannot move a load of `res` across a store to `D` -- the store phase of an (8192, 1280,
+  //      1280) launch with a residual took 8.1-8.9 us of its 28 us: tools/stamp_report.py 8192 1280 1280
+  //      --cfg 25 --res.)
+  constexpr int ST_ITERS_ = (BM * (BN / 8) + 64 * WM * WN * KSPLIT - 1) / (64 * WM * WN * KSPLIT);
+  constexpr bool RES_LATE = !RES_PRE && !ATT && !GROUPED && (ST_ITERS_ <= 10 || (PHASED && ST_ITERS_ <= 16));
+  constexpr bool RES_LATE_EARLY = RES_LATE && TN * TM * ACC + 4 * ST_ITERS_ + 80 <= REG_CAP;   // accumulators + chunks + the pass
+  v4i res_late[RES_LATE ? ST_ITERS_ : 1];
+  const bool res_late_on = RES_LATE && p.res != nullptr && (p.N & 7) == 0;
+  auto request_residual = [&]() {
+    if constexpr (RES_LATE) {
+      if (res_late_on) {
+#pragma unroll
+        for (int it = 0; it < ST_ITERS_; ++it) {
+          const int idx = min(tid + it * (64 * WM * WN * KSPLIT), BM * (BN / 8) - 1);
+          const int row = idx / (BN / 8), cc = idx - row * (BN / 8);
+          const int64_t m = min(m0 + row, p.M - 1);
+          const int n = n0 + cc * 8 < p.N ? n0 + cc * 8 : 0;
+          res_late[it] = *reinterpret_cast<const v4i*>(p.res + (p.res_div == 1 ? m : m / p.res_div) * p.N + n);
+        }
+      }
+    }
+  };
   if (pre_on) {      // the epilogue vectors -> LDS (their own region: no one reads it before the barrier)
     v4f b0 = {0.f, 0.f, 0.f, 0.f}, sc = {0.f, 0.f, 0.f, 0.f};
     uint2 bs = make_uint2(0u, 0u);
@@ -945,9 +1006,20 @@ void igemm_kernel(MIXDQ_IGEMM_HEAD_PARAMS const IgemmParams p_in) {
     *reinterpret_cast<v4f*>(P_SC + tid * 4) = sc;
     *reinterpret_cast<uint2*>(P_BS + tid * 4) = bs;
   }
+  // (behind the stores above: they use registers loaded before the main loop, whose loads the compiler cannot
+  //  count across the loop -- it waits vmcnt(0) for them, which would wait for the residual chunks as well:
+  //  3 us in front of the accumulator pass when the request came first)
+  if constexpr (RES_LATE_EARLY) request_residual();
 
   // ---- epilogue: registers -> f16 tile in LDS -> whole-row 16-byte stores --------------------
-  __syncthreads();   // every wave is done reading the stage buffers
+  // (With residual chunks in flight the barriers of this pass are raw: __syncthreads() waits vmcnt(0) as well
+  //  -- it would wait for the very loads that are meant to land under the pass.  What the barriers order here
+  //  is LDS traffic only: the DMAs were drained above.)
+  auto epi_barrier = [&]() {
+    if constexpr (RES_LATE_EARLY) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else __syncthreads();
+  };
+  epi_barrier();     // every wave is done reading the stage buffers
   MIXDQ_STAMP_AT(4);
   if constexpr (KSPLIT > 1) {
     // groups 1.. park their partial accumulators (behind the fp16 tile's area), group 0 adds them
@@ -966,7 +1038,7 @@ void igemm_kernel(MIXDQ_IGEMM_HEAD_PARAMS const IgemmParams p_in) {
           for (int e = 0; e < ACC; ++e)
             part[(kg - 1) * GROUP_INTS + ((a * TM + b) * ACC + e) * 64] = acc[a][b][e];
     }
-    __syncthreads();
+    epi_barrier();
     if (kg == 0) {
 #pragma unroll
       for (int g = 0; g < KSPLIT - 1; ++g)
@@ -1026,41 +1098,58 @@ void igemm_kernel(MIXDQ_IGEMM_HEAD_PARAMS const IgemmParams p_in) {
       uint2 hv[TM][OQ], hg[TM][OQ];               // the wave's patch as packed fp16 quads
       auto to_regs = [&](auto mode_c, int tm) {   // MFMA row-tile tm of the patch
         constexpr int MODE = decltype(mode_c)::value;   // as to_tile below
-        {
+        // The per-channel vectors of a BATCH of quads are read from LDS first, all of them, and only then
+        // the batch is computed (a scheduling fence between the two): left to itself hipcc issued the three
+        // reads of a quad, waited lgkmcnt(0), computed, read the next -- forty exposed LDS round trips per
+        // lane in the 128x320 tile's pass (2.5 of the launch's 23 us, the other wave of the SIMD in the
+        // same state).
+        // (Batches of 4 quad-halves where the tile has its CU -- and so the registers -- to itself; the
+        // tiles that share a CU keep one quad at a time: batched, they spilled.)
+        constexpr int HB = (REG_CAP >= 192 && (MT == 16 || TN * TM * ACC <= 96)) ? 4 : 1;   // quad-halves per batch
 #pragma unroll
-          for (int oq = 0; oq < OQ; ++oq) {
+        for (int h0 = 0; h0 < 2 * OQ; h0 += HB) {
+          v4f b0[HB], sc[HB];
+          v4h bsh[HB];
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {      // value quad, gate quad
-              const int nl = vcol(oq) + 16 * half;
-              const int tn = MT == 32 ? (oq >> 1) : 2 * oq + half;
-              const int e0 = MT == 32 ? 4 * ((oq & 1) + 2 * half) : 0;
-              v4f b0 = *reinterpret_cast<const v4f*>(P_B0 + nl);
-              v4f sc = *reinterpret_cast<const v4f*>(P_SC + nl);
-              if constexpr (W4) { b0 = b0 * 16.0f; sc = sc * 0.0625f; }   // exact: the MFMA ran on 16*q
-              v4f bs = {0.f, 0.f, 0.f, 0.f};
-              if constexpr (MODE != 0)
-                bs = __builtin_convertvector(*reinterpret_cast<const v4h*>(P_BS + nl), v4f);
-              uint32_t packed[2];
-#pragma unroll
-              for (int e2 = 0; e2 < 2; ++e2) {
-                v2f x = {(float)acc[tn][tm][e0 + 2 * e2], (float)acc[tn][tm][e0 + 2 * e2 + 1]};
-                const v2f b0e = {b0[2 * e2], b0[2 * e2 + 1]};
-                const v2f sce = {sc[2 * e2], sc[2 * e2 + 1]};
-                const v2f bse = {bs[2 * e2], bs[2 * e2 + 1]};
-                v2f r;
-                x = x - b0e;
-                if constexpr (MODE == 0) r = x * sce;
-                else if constexpr (MODE == 2) r = x * sce + bse;
-                else r = __builtin_elementwise_fma(x, sce, bse);
-                asm("" : "+v"(r));
-                const v2h h = __builtin_convertvector(r, v2h);
-                packed[e2] = *reinterpret_cast<const uint32_t*>(&h);
-              }
-              if (half == 0) hv[tm][oq] = make_uint2(packed[0], packed[1]);
-              else hg[tm][oq] = make_uint2(packed[0], packed[1]);
-            }
-            if (oq % 2 == 1) __builtin_amdgcn_sched_barrier(0);
+          for (int j = 0; j < HB; ++j) {
+            if (h0 + j >= 2 * OQ) break;
+            const int oq = (h0 + j) >> 1, half = (h0 + j) & 1;
+            const int nl = vcol(oq) + 16 * half;
+            b0[j] = *reinterpret_cast<const v4f*>(P_B0 + nl);
+            sc[j] = *reinterpret_cast<const v4f*>(P_SC + nl);
+            if constexpr (MODE != 0) bsh[j] = *reinterpret_cast<const v4h*>(P_BS + nl);
           }
+          if constexpr (HB > 1) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < HB; ++j) {
+            if (h0 + j >= 2 * OQ) break;
+            const int oq = (h0 + j) >> 1, half = (h0 + j) & 1;      // value quad, gate quad
+            const int tn = MT == 32 ? (oq >> 1) : 2 * oq + half;
+            const int e0 = MT == 32 ? 4 * ((oq & 1) + 2 * half) : 0;
+            v4f b0q = b0[j], scq = sc[j];
+            if constexpr (W4) { b0q = b0q * 16.0f; scq = scq * 0.0625f; }   // exact: the MFMA ran on 16*q
+            v4f bs = {0.f, 0.f, 0.f, 0.f};
+            if constexpr (MODE != 0) bs = __builtin_convertvector(bsh[j], v4f);
+            uint32_t packed[2];
+#pragma unroll
+            for (int e2 = 0; e2 < 2; ++e2) {
+              v2f x = {(float)acc[tn][tm][e0 + 2 * e2], (float)acc[tn][tm][e0 + 2 * e2 + 1]};
+              const v2f b0e = {b0q[2 * e2], b0q[2 * e2 + 1]};
+              const v2f sce = {scq[2 * e2], scq[2 * e2 + 1]};
+              const v2f bse = {bs[2 * e2], bs[2 * e2 + 1]};
+              v2f r;
+              x = x - b0e;
+              if constexpr (MODE == 0) r = x * sce;
+              else if constexpr (MODE == 2) r = x * sce + bse;
+              else r = __builtin_elementwise_fma(x, sce, bse);
+              asm("" : "+v"(r));
+              const v2h h = __builtin_convertvector(r, v2h);
+              packed[e2] = *reinterpret_cast<const uint32_t*>(&h);
+            }
+            if (half == 0) hv[tm][oq] = make_uint2(packed[0], packed[1]);
+            else hg[tm][oq] = make_uint2(packed[0], packed[1]);
+          }
+          if (HB > 1 || (h0 & 3) == 3) __builtin_amdgcn_sched_barrier(0);
         }
       };
       const bool mine = KSPLIT == 1 || kg == 0;   // k-split: group 0 holds the sums
@@ -1217,6 +1306,7 @@ void igemm_kernel(MIXDQ_IGEMM_HEAD_PARAMS const IgemmParams p_in) {
     else to_tile(std::integral_constant<int, 2>{});
   }
   MIXDQ_STAMP_AT(5);
+  if constexpr (RES_LATE && !RES_LATE_EARLY) request_residual();
   __syncthreads();
   MIXDQ_STAMP_AT(6);
   if constexpr (ATT) {
@@ -1392,6 +1482,7 @@ void igemm_kernel(MIXDQ_IGEMM_HEAD_PARAMS const IgemmParams p_in) {
       if (n8) {
         uint4 r;
         if constexpr (RES_PRE) r = res_pre[it];     // requested before the main loop
+        else if constexpr (RES_LATE) r = __builtin_bit_cast(uint4, res_late[it]);   // requested around the accumulator pass
         else r = *reinterpret_cast<const uint4*>(rp);
         rw[0] = r.x; rw[1] = r.y; rw[2] = r.z; rw[3] = r.w;
       } else {
@@ -1416,7 +1507,11 @@ void igemm_kernel(MIXDQ_IGEMM_HEAD_PARAMS const IgemmParams p_in) {
         // the operand panels out of the XCD's L2 ((32768, 1920, 640): 73 vs 86 us, (8192, 10240,
         // 1280): 150 vs 160 us; neutral at batch 1)
         const v4i vv = {(int)v.x, (int)v.y, (int)v.z, (int)v.w};
-        asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst), "v"(vv) : "memory");
+        // global_store_dwordx4 ... nt, through the builtin: the compiler then counts the store in vmcnt and pads
+        // the gfx950 store-data hazard (a store of more than 64 bits reads its data registers up to two wait
+        // states after issue).  As inline asm it did neither: a VALU write of the first data register right
+        // behind the asm was picked up by the store (tests/test_ops_gpu.py halo cases, round 4).
+        __builtin_nontemporal_store(vv, reinterpret_cast<v4i*>(dst));
       }
     } else {   // N % 8 == 4: rows are only 8-byte aligned
       *reinterpret_cast<uint2*>(dst) = make_uint2(v.x, v.y);
@@ -1428,6 +1523,16 @@ void igemm_kernel(MIXDQ_IGEMM_HEAD_PARAMS const IgemmParams p_in) {
     if (tid < BM * CPRO) store_chunk(std::integral_constant<int, 0>{}, tid);
     if constexpr (ST_ITERS == 2)
       if (tid + NTHREADS < BM * CPRO) store_chunk(std::integral_constant<int, 1>{}, tid + NTHREADS);
+  } else if constexpr (RES_LATE) {
+    static_assert(ST_ITERS == ST_ITERS_, "the residual was requested with this loop's mapping");
+    if (res_late_on) {      // compile-time slots of the requested residual chunks: the loop is unrolled
+      igemm_unrolled<ST_ITERS>([&](auto it_c) {
+        const int idx = tid + decltype(it_c)::value * NTHREADS;
+        if (idx < BM * CPRO) store_chunk(it_c, idx);
+      });
+    } else {
+      for (int idx = tid; idx < BM * CPRO; idx += NTHREADS) store_chunk(std::integral_constant<int, 0>{}, idx);
+    }
   } else {
     for (int idx = tid; idx < BM * CPRO; idx += NTHREADS) store_chunk(std::integral_constant<int, 0>{}, idx);
   }
@@ -1624,6 +1729,7 @@ int launch_tile(IgemmParams& p, hipStream_t stream) {
   X(18, 256, 128, 128, 2, 4, 2, 1, 32, false)    \
   X(20, 256, 256, 128, 2, 4, 2, 1, 32, false)    \
   X(25, 128, 320, 128, 2, 4, 2, 1, 32, false)    \
+  X(27, 128, 320, 128, 2, 8, 2, 1, 16, false)    \
   X(35, 128, 128, 64, 3, 4, 2, 1, 32, false)     \
   X(37, 64, 64, 128, 3, 2, 2, 2, 32, false)      \
   X(41, 64, 128, 128, 3, 2, 4, 1, 32, false)     \
@@ -1694,7 +1800,7 @@ inline int select_cfg(int64_t M, int N, int Ktot, bool whole64 = false, bool pha
   // where this tile looks GELU up in LDS: (4096, 5120, 640) 30.3 vs 35.9 us)
   if (N % 320 == 0 && Ktot % 128 == 0 && (Ktot >= 1024 || whole64) &&
       (b320 == kNumCU || b320 == 2 * kNumCU))
-    return 25;
+    return 27;   // the 128x320 tile on 16 waves of 16 x 160 (25: the same tile on 8 waves of 32 x 160)
   // from 1.5 workgroups of 256x256 per CU on: the four-phase loop (fewest L2->LDS bytes per MAC, the
   // reads and the DMA of one wave group under the other's MFMAs): (8192, 10240, 1280) 135 vs 153 us on
   // 256x128, (8192, 3840, 1280) 56 vs 62, (32768, 1920, 640) 77 vs 84 (tools/bench_gemm.py --bs 8)
@@ -1865,6 +1971,7 @@ inline int select_cfg_f16(int64_t M, int N, int k_bytes) {
       return c;
     case 37: return 4;              // k-split 64x64 -> the plain 64x64 tile
     case 45: case 56: case 42: return 41;   // exact-fit 64x80 (16x16 MFMA, k-split) -> 64x128
+    case 27: return 25;             // 16 waves of 16x16x64 MFMAs -> the same tile on 8 waves of 32x32
     case 70: case 14: case 18: return 20;
     default: return 35;
   }

@@ -81,7 +81,7 @@ def test_tile_choice_is_a_host_function_of_the_shape():
     sel = lib.mixdq_igemm_select_id
     # batch 1: exactly one workgroup per CU (64x80), six stages for cold K <= 2048, four beyond
     assert sel(1024, 1280, 1280, 1280) == 56 and sel(1024, 1280, 5120, 5120) == 45
-    assert sel(1024, 10240, 1280, 1280) == 25 and sel(4096, 640, 2560, 2560) == 44
+    assert sel(1024, 10240, 1280, 1280) == 27 and sel(4096, 640, 2560, 2560) == 44
     # batch 8: the four-phase 256x256 loop for plain Linear launches from 1.5 workgroups per CU on ...
     assert sel(8192, 10240, 1280, 1280) == 70 and sel(8192, 3840, 1280, 1280) == 70
     assert sel(32768, 1920, 640, 640) == 70
@@ -90,7 +90,7 @@ def test_tile_choice_is_a_host_function_of_the_shape():
     # ... nor a K that is not whole 128-byte tiles; GEMM + GEGLU does (its epilogue runs in registers)
     assert sel(8192, 10240, 1296, 1296) != 70
     assert lib.mixdq_igemm_select_id_geglu(8192, 10240, 1280, 0) == 70
-    assert lib.mixdq_igemm_select_id_geglu(1024, 10240, 1280, 0) == 25
+    assert lib.mixdq_igemm_select_id_geglu(1024, 10240, 1280, 0) == 27
     assert lib.mixdq_igemm_select_id_geglu(1024, 10240 + 16, 1280, 0) == -1      # N % 32 != 0
     # packed W4: 32x32x32 tiles (every wave unpacks what it multiplies)
     assert lib.mixdq_igemm_select_id_w4(1024, 1280, 1280, 1280) == 41

@@ -192,7 +192,7 @@ GEGLU_GEMM_CASES = [  # M, D, K, forced tile config (0 = automatic), bias
     # the four-phase 256x256 loop: M tail, several column tiles, a K tail (one-phase fallback)
     (300, 256, 256, 70, True), (513, 384, 384, 70, False), (257, 256, 192, 70, True),
     # every remaining tile family: 64x64x64, the k-split 64x64, 128x128 8-wave, 128x256, 256x256,
-    # the deeper 128x320 pipelines, the four-phase loop on 64-byte K-tiles; D = 16 (one group)
+    # the deeper 128x320 pipelines; D = 16 (one group)
     (96, 64, 64, 1, True), (130, 64, 256, 37, True), (200, 128, 128, 35, False), (300, 128, 128, 15, True),
     (257, 256, 128, 14, True), (300, 320, 320, 47, True), (40, 16, 64, 0, True),
 ]

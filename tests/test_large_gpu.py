@@ -66,7 +66,7 @@ def test_qlinear_full_batch_sampled_rows_vs_oracle(C, oracle, B, T, N, K, bias):
     want_res = oracle.add_f16(want, res.numpy()[rows])
     assert np.array_equal(bits(out_res.cpu().numpy()[rows]), bits(want_res))
     # which tile ran: at these sizes the automatic choice must be one of the large / 8-wave tiles
-    assert C.igemm_select_id(M, N, K) in (13, 20, 25, 35, 41, 44, 70), C.igemm_select_id(M, N, K)
+    assert C.igemm_select_id(M, N, K) in (13, 20, 25, 27, 35, 41, 44, 70), C.igemm_select_id(M, N, K)
 
 
 @pytest.mark.parametrize("B", [8, 16])

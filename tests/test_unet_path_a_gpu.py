@@ -122,8 +122,12 @@ def test_full_unet_512px_hip_path_matches_host_path_a_within_quantization_noise(
     print(msg)
     assert n_mean < 0.1 * spread, msg                              # the quantized network still tracks the FP32 one
     for tag, r in report.items():
-        # the two implementations of the SAME quantized network agree to within its quantization noise
-        assert r["d_mean"] <= 1.0 * n_mean + 1e-4, (tag, msg)
+        # the two implementations of the SAME quantized network agree to within its quantization noise.
+        # (Not far below it: across 794 layers every differently-rounded activation flips INT8 values
+        # downstream, so two faithful implementations end up as two near-independent realisations of the
+        # same noise -- measured on MI355X: d_mean = 0.91 x n_mean, d_max = 0.92 x n_max; sqrt(2) is the
+        # independent limit.)
+        assert r["d_mean"] <= 1.3 * n_mean + 1e-4, (tag, msg)
         assert r["d_max"] <= 3.0 * n_max + 1e-3, (tag, msg)
         # ... and the HIP path is no further from the FP32 network than Path A is
         assert r["e_mean"] <= 1.25 * n_mean + 1e-4, (tag, msg)

@@ -3,7 +3,7 @@
 
     MIXDQ_HIP_LIB=$PWD/build/stamp/libmixdq_stamp.so python tools/stamp_report.py M N K [--geglu] [--cfg id] [--res]
 
-Slots: 0 entry | 1 prologue DMA issued | 2 first K-tile landed | 3 main loop done (this wave) | 4 past
+Slots: 0 entry | 12 first prologue stage issued | 13 rest of the argument block arrived, epilogue operands requested | 1 prologue DMA issued | 2 first K-tile landed | 3 main loop done (this wave) | 4 past
 the barrier behind the main loop | 5 accumulators -> fp16 tile in LDS (this wave) | 6 past the barrier
 behind it | 7 stores / GEGLU done | 10, 11 (register GEGLU of the 256x256 tile): INT8 tile written, past
 the barrier behind it.  The shader clocks of different XCDs are not synchronised, so every
@@ -87,7 +87,7 @@ def main():
         ok = dt_rt > 0
         ghz = float(np.median(dt_clk[ok] / dt_rt[ok])) * 0.1 if ok.any() else 2.0
         parts = []
-        for slot in (1, 2, 3, 4, 5, 6, 10, 11, 7):
+        for slot in (12, 13, 1, 2, 3, 4, 5, 6, 10, 11, 7):
             v = s[:, :, slot]
             have = used & (v != 0)
             if not have.any():
