@@ -269,7 +269,10 @@ __device__ __forceinline__ float wave_sum(float v) {
 // latency chain per wave (load -> reduce -> reduce -> store); at batch 1 every wave has one row and
 // the chain IS the kernel, from 8192 rows on two rows per wave keep the grid at one round of four
 // waves per SIMD and put twice the bytes in flight per chain (batch 8: 13.0 us per launch at
-// 2.4 TB/s before).  The arithmetic of a row does not depend on ROWS.
+// 2.4 TB/s before).  The arithmetic of a row does not depend on ROWS.  (Round 4: a streamed form -- a
+// wave walks 4 or 8 consecutive rows and requests row r + 1 before it reduces row r -- was built and
+// measured SLOWER: [8192, 1280] 11.4 vs 9.9 us, [32768, 640] 28.2 vs 21.3: fewer, longer waves put fewer
+// bytes in flight than one round of short ones.  Removed.)
 template <bool UNFUSED, int NQ, bool WANT_H, int ROWS>
 __global__ __launch_bounds__(256) void ln_quant_kernel(
     const __half* __restrict__ x, const __half* __restrict__ gamma, const __half* __restrict__ beta,

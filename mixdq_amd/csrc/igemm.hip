@@ -978,20 +978,27 @@ void igemm_kernel(MIXDQ_IGEMM_HEAD_PARAMS const IgemmParams p_in) {
   //      --cfg 25 --res.)
   constexpr int ST_ITERS_ = (BM * (BN / 8) + 64 * WM * WN * KSPLIT - 1) / (64 * WM * WN * KSPLIT);
   constexpr bool RES_LATE = !RES_PRE && !ATT && !GROUPED && (ST_ITERS_ <= 10 || (PHASED && ST_ITERS_ <= 16));
-  constexpr bool RES_LATE_EARLY = RES_LATE && TN * TM * ACC + 4 * ST_ITERS_ + 80 <= REG_CAP;   // accumulators + chunks + the pass
+  // EARLY: the requests are interleaved with the accumulator pass (one chunk every few quads: asked for in
+  // one burst they are 80 KB through an address unit that takes ~1 KiB per 40 cycles -- every wave of the CU
+  // stood in that queue for ~3 us before its pass could start; tools/stamp_report.py).  Needs the registers
+  // for accumulators + chunks + the pass, and every wave in the pass (no k-split groups).
+  constexpr bool RES_LATE_EARLY = RES_LATE && !PHASED && KSPLIT == 1 &&
+                                  TN * TM * ACC + 4 * ST_ITERS_ + 60 <= REG_CAP;
   v4i res_late[RES_LATE ? ST_ITERS_ : 1];
   const bool res_late_on = RES_LATE && p.res != nullptr && (p.N & 7) == 0;
+  const bool res_late_full = p.res_div == 1;
+  auto request_residual_one = [&](int it) {   // `it`: a compile-time constant at every call site
+    const int idx = min(tid + it * (64 * WM * WN * KSPLIT), BM * (BN / 8) - 1);
+    const int row = idx / (BN / 8), cc = idx - row * (BN / 8);
+    const int64_t m = min(m0 + row, p.M - 1);
+    const int n = n0 + cc * 8 < p.N ? n0 + cc * 8 : 0;
+    res_late[it] = *reinterpret_cast<const v4i*>(p.res + (res_late_full ? m : m / p.res_div) * p.N + n);
+  };
   auto request_residual = [&]() {
     if constexpr (RES_LATE) {
       if (res_late_on) {
 #pragma unroll
-        for (int it = 0; it < ST_ITERS_; ++it) {
-          const int idx = min(tid + it * (64 * WM * WN * KSPLIT), BM * (BN / 8) - 1);
-          const int row = idx / (BN / 8), cc = idx - row * (BN / 8);
-          const int64_t m = min(m0 + row, p.M - 1);
-          const int n = n0 + cc * 8 < p.N ? n0 + cc * 8 : 0;
-          res_late[it] = *reinterpret_cast<const v4i*>(p.res + (p.res_div == 1 ? m : m / p.res_div) * p.N + n);
-        }
+        for (int it = 0; it < ST_ITERS_; ++it) request_residual_one(it);
       }
     }
   };
@@ -1006,10 +1013,6 @@ void igemm_kernel(MIXDQ_IGEMM_HEAD_PARAMS const IgemmParams p_in) {
     *reinterpret_cast<v4f*>(P_SC + tid * 4) = sc;
     *reinterpret_cast<uint2*>(P_BS + tid * 4) = bs;
   }
-  // (behind the stores above: they use registers loaded before the main loop, whose loads the compiler cannot
-  //  count across the loop -- it waits vmcnt(0) for them, which would wait for the residual chunks as well:
-  //  3 us in front of the accumulator pass when the request came first)
-  if constexpr (RES_LATE_EARLY) request_residual();
 
   // ---- epilogue: registers -> f16 tile in LDS -> whole-row 16-byte stores --------------------
   // (With residual chunks in flight the barriers of this pass are raw: __syncthreads() waits vmcnt(0) as well
@@ -1256,6 +1259,11 @@ void igemm_kernel(MIXDQ_IGEMM_HEAD_PARAMS const IgemmParams p_in) {
       for (int tn = 0; tn < TN; ++tn) {
 #pragma unroll
         for (int g = 0; g < ACC / 4; ++g) {     // register quads: 4 consecutive output channels each
+          if constexpr (RES_LATE_EARLY) {       // one residual chunk requested every QSTEP quads of the pass
+            constexpr int NQUADS = TM * TN * (ACC / 4), QSTEP = NQUADS / ST_ITERS_ > 0 ? NQUADS / ST_ITERS_ : 1;
+            const int qi = (tm * TN + tn) * (ACC / 4) + g;
+            if (res_late_on && qi % QSTEP == 0 && qi / QSTEP < ST_ITERS_) request_residual_one(qi / QSTEP);
+          }
           const int nl = wn * WTN + tn * MT + (MT == 32 ? 8 * g + 4 * lkq : 4 * lkq);
           v4f b0 = *reinterpret_cast<const v4f*>(P_B0 + nl);
           if constexpr (CONV) {
@@ -1307,6 +1315,14 @@ void igemm_kernel(MIXDQ_IGEMM_HEAD_PARAMS const IgemmParams p_in) {
   }
   MIXDQ_STAMP_AT(5);
   if constexpr (RES_LATE && !RES_LATE_EARLY) request_residual();
+  if constexpr (RES_LATE_EARLY) {
+    constexpr int NQUADS = TM * TN * (ACC / 4), QSTEP = NQUADS / ST_ITERS_ > 0 ? NQUADS / ST_ITERS_ : 1;
+    constexpr int COVERED = (NQUADS + QSTEP - 1) / QSTEP < ST_ITERS_ ? (NQUADS + QSTEP - 1) / QSTEP : ST_ITERS_;
+    if (res_late_on) {
+#pragma unroll
+      for (int it = COVERED; it < ST_ITERS_; ++it) request_residual_one(it);
+    }
+  }
   __syncthreads();
   MIXDQ_STAMP_AT(6);
   if constexpr (ATT) {
