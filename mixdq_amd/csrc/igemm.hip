@@ -512,6 +512,12 @@ void igemm_kernel(MIXDQ_IGEMM_HEAD_PARAMS const IgemmParams p_in) {
 
   const char* zero = reinterpret_cast<const char*>(&g_zero16);
   const int Ktot = p.Ktot;
+  // (Round 4, measured and removed -- "K rotation": every tile of the Linear fast path started at its own K-tile,
+  //  (m + 3 n) mod nk, and wrapped, so that the workgroups that share an operand panel in an XCD's L2 would not
+  //  all request a line while its first request is still on its way to memory.  Integer accumulation is exact in
+  //  any order, the results were bit-identical -- and no launch got faster: (8192, 1280, 5120) 59.2 -> 63.2 us,
+  //  the rest within +-1 %, batch-1 step 11.61 -> 11.69 ms.  The per-CU request rate, not the latency of a
+  //  shared miss, is the bound.  profiles/r04_k_rotation_ab.txt)
 
   // ---- per-lane staging state -------------------------------------------------------------
   const int8_t* a_base[A_NI];   // linear: row pointer + chunk offset; conv: image base
