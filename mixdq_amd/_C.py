@@ -101,6 +101,7 @@ IGEMM_CONFIGS = {1: (64, 64, 64, 2), 3: (128, 128, 64, 2), 4: (64, 64, 128, 3),
                  13: (256, 128, 64, 3), 14: (256, 256, 64, 3), 15: (128, 256, 64, 3),
                  18: (256, 128, 128, 2), 20: (256, 256, 128, 2), 25: (128, 320, 128, 2),
                  27: (128, 320, 128, 2),   # the same tile on 16 waves of 16 x 160 (16x16x64 MFMAs)
+                 28: (128, 320, 128, 2),   # ... on 16 waves of 32 x 80 (7 fragment reads per 10 MFMAs instead of 11)
                  35: (128, 128, 64, 3), 37: (64, 64, 128, 3), 41: (64, 128, 128, 3),
                  # 16x16x64-MFMA tiles (exactly one workgroup per CU on the UNet's M = 1024 / 4096
                  # layers; 45 / 56: deeper pipelines) and the 4-stage 128x320 tile
@@ -441,7 +442,7 @@ def qlinear_geglu(input_int8, weight_int8, scale, bias0, bias, out_scale_inv, ou
 if hasattr(_lib, "mixdq_conv_halo_select"):      # (absent in older builds used for A/B runs)
     _lib.mixdq_conv_halo_select.argtypes = [_i32] * 9
     _lib.mixdq_conv_halo_select.restype = _i32
-HALO_TILES = {90: (8, 16, 80), 91: (8, 8, 80), 92: (16, 16, 80)}   # csrc/iconv.hip: output pixels (rows, columns), channels
+HALO_TILES = {90: (8, 16, 80), 91: (8, 8, 80), 92: (16, 16, 80), 93: (16, 16, 160)}   # csrc/iconv.hip: output pixels (rows, columns), channels
 
 
 def conv_halo_select(N, H, W, C, K, R, S, stride, padding) -> int:
@@ -531,7 +532,7 @@ def qconv2d_w8_a8_ohalf(input_int8, weight_int8, weight_scale, input_scale, inpu
     sc = _f32vec(scale)
     bs = None if bias is None else bias.contiguous()
     kind = "conv"
-    if RECORD is not None and _cfg in (0, 90, 91, 92) and not _w4 and dilation == 1:
+    if RECORD is not None and _cfg in (0, 90, 91, 92, 93) and not _w4 and dilation == 1:
         tile = _cfg or conv_halo_select(N, H, W, C, K, R, S, stride, padding)
         kind = f"conv_halo{tile}" if tile else "conv"
     _record(kind, N * P * Q, K, R * S * C, C, _w4, qconv2d_w8_a8_ohalf,

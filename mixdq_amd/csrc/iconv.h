@@ -20,7 +20,7 @@ struct HaloConvArgs {
                           //    upsampling (Upsample2D: conv(interpolate(x))) without materialising it
 };
 
-// Tile id the halo kernel would run this problem on (90: 8x16 pixels x 80 channels, 91: 8x8 x 80), or 0
+// Tile id the halo kernel would run this problem on (90: 8x16 pixels x 80 channels, 91: 8x8 x 80, 92: 16x16 x 80, 93: 16x16 x 160), or 0
 // when the problem is outside its range (then the implicit-GEMM family of csrc/igemm.hip runs it).
 int halo_conv_select(int NI, int H, int W, int C, int K, int R, int S, int stride, int pad);
 

@@ -45,12 +45,14 @@ __device__ __forceinline__ uint32_t add_f16x2_(uint32_t a, uint32_t b) {
 
 // CK: bytes of a channel chunk (a row of the LDS images): 128 with two k-split wave groups (each takes
 // one 64-byte MFMA k-step of a chunk; 4 waves x BM / 4 pixels), or 64 with eight waves x BM / 8 pixels.
-template <int TH, int TW, int BN, int CK>
+// WNG: wave groups over the BN channels (1: every wave computes all BN channels of its pixels; 2: a wave
+// computes BN / 2 channels of twice the pixels -- 9 fragment reads per 20 MFMAs instead of 7 per 10).
+template <int TH, int TW, int BN, int CK, int WNG = 1>
 struct HaloGeom {
   static constexpr int BM = TH * TW;                                  // output pixels per workgroup
   static constexpr int HWP = TW + 2, HP = (TH + 2) * HWP;             // halo row length, halo pixels
   static constexpr int KSPLIT = CK / 64;                              // k-split wave groups
-  static constexpr int NWAVES = 8, NTHREADS = 512, WPX = NWAVES / KSPLIT;   // waves over the pixels
+  static constexpr int NWAVES = 8, NTHREADS = 512, WPX = NWAVES / KSPLIT / WNG;   // waves over the pixels
   static constexpr int PPP = 1024 / CK, LPP = CK / 16;                // pixels per 1-KiB DMA piece; lanes per pixel
   static constexpr int H_NI = ((HP + PPP - 1) / PPP + NWAVES - 1) / NWAVES;   // halo pieces per wave
   static constexpr int HALO_BYTES = H_NI * NWAVES * 1024;
@@ -60,21 +62,35 @@ struct HaloGeom {
   static constexpr int HALO_OFF = 3 * W_STAGE;
   static constexpr int MAIN_BYTES = HALO_OFF + 2 * HALO_BYTES;
   static constexpr int CS_STRIDE = BN * 2 + 16;                       // epilogue tile row stride
-  static constexpr int WTM = BM / WPX, TM = WTM / 16, TN = BN / 16;   // wave tile: WTM pixels x BN channels
+  static constexpr int WTN = BN / WNG;                                // channels per wave
+  static constexpr int WTM = BM / WPX, TM = WTM / 16, TN = WTN / 16;  // wave tile: WTM pixels x WTN channels
   static constexpr int PART_BYTES = (KSPLIT - 1) * WPX * TM * TN * 4 * 64 * 4;   // k-split partials
   static constexpr int SMEM = MAIN_BYTES + 9 * BN * 4 + BN * 6;       // + 9 border-class rows, scale, bias
   static_assert(CK == 64 || CK == 128, "one or two 64-byte MFMA k-steps per chunk");
-  static_assert(W_TAP % 1024 == 0 && BN % 16 == 0 && WTM % 16 == 0, "whole DMA pieces / MFMA tiles");
+  static_assert(W_TAP % 1024 == 0 && WTN % 16 == 0 && WTM % 16 == 0, "whole DMA pieces / MFMA tiles");
+  static_assert(WNG == 1 || KSPLIT == 1, "channel wave groups only without the k-split");
   static_assert(BM * CS_STRIDE + PART_BYTES <= MAIN_BYTES, "epilogue staging overlays the main buffers");
   static_assert(SMEM <= 160 * 1024, "LDS is 160 KiB per CU");
   static_assert(H_NI + 2 * W_NI <= 63, "vmcnt is a 6-bit counter");
-  // 16-byte chunk swizzle of an image row (256-byte LDS bank rows hold 2 or 4 image rows)
-  __device__ static int swz(int row) { return CK == 128 ? (row >> 1) & 7 : (row >> 2) & 3; }
+  // 16-byte chunk swizzle of an image row (256-byte LDS bank rows hold 2 or 4 image rows).  A
+  // ds_read_b128 is served in four groups of 16 lanes -- {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}
+  // and the same + 32 -- i.e. with one pixel per lane & 15 and the k-chunk on lane >> 4, rows
+  // b .. b+3 and b+12 .. b+15 with chunk c next to rows b+4 .. b+11 with chunk c ^ 1.  The taps
+  // shift b by any amount, so the XOR term must separate those 16 lanes for EVERY b: the terms below
+  // do (exhaustive check over b, both k-split groups); igemm.hip's (row >> 2) & 3 / (row >> 1) & 7,
+  // which are conflict-free for its 32-row lane mapping and for b % 16 == 0, cost 1.9x / 1.7x the LDS
+  // cycles here (SQ_LDS_BANK_CONFLICT 0.49 of SQ_LDS_IDX_ACTIVE on the 16 x 16 / 64-byte tile,
+  // profiles/r04_pmc_summary.json).  Patches 8 pixels wide (two image rows per fragment) keep the old
+  // term: no XOR of row bits does better than 1.8x there.
+  __device__ static int swz(int row) {
+    if (CK == 64) return ((row >> 2) & 1) << 1;
+    return TW == 16 ? ((row >> 1) & 3) << 1 : (row >> 1) & 7;
+  }
 };
 
-template <int TH, int TW, int BN, int CK>
+template <int TH, int TW, int BN, int CK, int WNG = 1>
 __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloConvArgs p) {
-  using G = HaloGeom<TH, TW, BN, CK>;
+  using G = HaloGeom<TH, TW, BN, CK, WNG>;
   constexpr int BM = G::BM, HWP = G::HWP, HP = G::HP, TM = G::TM, TN = G::TN;
   constexpr int CS_STRIDE = G::CS_STRIDE;
   MIXDQ_ARGS_NOW(p.X, p.Wt, p.scale, p.bias, p.table, p.zp, p.D, p.res, p.res_div, p.NI, p.H, p.W, p.C,
@@ -82,7 +98,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloConvArgs
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kg = wid / G::WPX, wm = wid % G::WPX;     // k-split group (0 when CK == 64), pixel group
+  const int kg = WNG == 1 ? wid / G::WPX : 0;         // k-split group (0 when CK == 64)
+  const int wn = WNG == 1 ? 0 : wid / G::WPX;         // channel group
+  const int wm = wid % G::WPX;                        // pixel group
   const int lrow = lane & 15, lkq = lane >> 4;
 
   // ---- XCD-aware tile map (as igemm.hip): every XCD gets a contiguous run of the tile sequence,
@@ -215,7 +233,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloConvArgs
   int w_rd[TN];
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
-    const int row = tn * 16 + lrow;
+    const int row = wn * G::WTN + tn * 16 + lrow;
     w_rd[tn] = row * CK + (((kg * 4 + lkq) ^ G::swz(row)) << 4);
   }
   v4i acc[TN][TM];
@@ -314,7 +332,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloConvArgs
       const float* b0row = P_TAB + (rc * 3 + cc) * BN;
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) {
-        const int nl = tn * 16 + 4 * lkq;
+        const int nl = wn * G::WTN + tn * 16 + 4 * lkq;
         v4f b0 = *reinterpret_cast<const v4f*>(b0row + nl);
         b0 = b0 * zpv;                                 // f32(sum of in-image taps) * zp, one rounding
         const v4f sc = *reinterpret_cast<const v4f*>(P_SC + nl);
@@ -354,7 +372,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloConvArgs
   // (Read inside the store loop it cost one dependent memory round trip per iteration: the compiler
   // cannot move a load of `res` across a store to `D`.)
   constexpr int ST_ITERS = (BM * CPRO + G::NTHREADS - 1) / G::NTHREADS;
-  static_assert(ST_ITERS <= 8, "residual chunks parked in registers");
+  static_assert(ST_ITERS <= 10, "residual chunks parked in registers");
   v4i res_late[ST_ITERS];
   const bool res_late_on = p.res != nullptr && n8;
   if (res_late_on) {
@@ -410,16 +428,16 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloConvArgs
   }
 }
 
-template <int TH, int TW, int BN, int CK>
+template <int TH, int TW, int BN, int CK, int WNG = 1>
 int launch_halo(const HaloConvArgs& a, hipStream_t stream) {
-  using G = HaloGeom<TH, TW, BN, CK>;
+  using G = HaloGeom<TH, TW, BN, CK, WNG>;
   static bool seen[64] = {};
-  if (const int st = lds_opt_in(reinterpret_cast<const void*>(&conv3x3_halo_kernel<TH, TW, BN, CK>),
+  if (const int st = lds_opt_in(reinterpret_cast<const void*>(&conv3x3_halo_kernel<TH, TW, BN, CK, WNG>),
                                 G::SMEM, seen))
     return st;
   const int64_t grid = (int64_t)a.NI * (a.H / TH) * (a.W / TW) * ((a.K + BN - 1) / BN);
   if (grid <= 0 || grid > 0x7fffffff) return MIXDQ_ERR_INVALID_ARG;
-  conv3x3_halo_kernel<TH, TW, BN, CK><<<dim3((unsigned)grid), 512, G::SMEM, stream>>>(a);
+  conv3x3_halo_kernel<TH, TW, BN, CK, WNG><<<dim3((unsigned)grid), 512, G::SMEM, stream>>>(a);
   return launch_status();
 }
 
@@ -436,6 +454,10 @@ int halo_conv_select(int NI, int H, int W, int C, int K, int R, int S, int strid
   // 32-bit per-lane offsets inside one image / the weight tensor
   if ((int64_t)H * W * C >= (1ll << 32) || (int64_t)K * 9 * C >= (1ll << 32)) return 0;
   const int64_t tiles_n = (K + 79) / 80;
+  // 160 channels per workgroup on 4 x 2 waves of 64 pixels x 80 channels: half the halo bytes and 0.64 of
+  // the LDS fragment reads per MAC of tile 92, when that still gives every CU a workgroup
+  if (H % 16 == 0 && W % 16 == 0 && K % 160 == 0 && (int64_t)NI * (H / 16) * (W / 16) * (K / 160) >= kNumCU)
+    return 93;
   if (H % 16 == 0 && W % 16 == 0 && (int64_t)NI * (H / 16) * (W / 16) * tiles_n >= kNumCU) return 92;
   if (W % 16 == 0 && (int64_t)NI * (H / 8) * (W / 16) * tiles_n >= kNumCU) return 90;
   return 91;
@@ -446,6 +468,7 @@ int halo_conv_launch(const HaloConvArgs& a, int tile, hipStream_t stream) {
     case 90: return launch_halo<8, 16, 80, 128>(a, stream);
     case 91: return launch_halo<8, 8, 80, 128>(a, stream);
     case 92: return launch_halo<16, 16, 80, 64>(a, stream);
+    case 93: return launch_halo<16, 16, 160, 64, 2>(a, stream);
     default: return MIXDQ_ERR_INVALID_ARG;
   }
 }

@@ -1081,7 +1081,7 @@ void igemm_kernel(MIXDQ_IGEMM_HEAD_PARAMS const IgemmParams p_in) {
   //      fp16, product -> fp16, quantize) is kept: the INT8 tensor is the one mixdq_geglu_quantize
   //      produces from this GEMM's fp16 output.  ((8192, 10240, 1280) on the 256x256 tile: 117 us;
   //      142 with the fp16 tile staged through LDS and GELU computed, as round 2 did.)
-  if constexpr (BN % 32 == 0 && !CONV && !F16 && !ATT && !GROUPED) {
+  if constexpr (BN % 32 == 0 && WTN % 32 == 0 && !CONV && !F16 && !ATT && !GROUPED) {
     if (p.Dq != nullptr) {
       constexpr int QS = BN / 2 + 16;             // INT8 tile row stride (bytes)
       constexpr bool TAB = igemm_gelu_table_fits<BM, BN, BK, STAGES>();
@@ -1696,7 +1696,8 @@ template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool CONV, bool FA
 int launch_kernel(IgemmParams& p, hipStream_t stream) {
   constexpr int SMEM = igemm_smem_bytes<BM, BN, BK, STAGES>();
   static_assert(SMEM <= 160 * 1024, "LDS is 160 KiB per CU");
-  if (p.Dq != nullptr && BN % 32 != 0) return MIXDQ_ERR_GEGLU_SHAPE;   // whole value|gate groups per tile
+  if (p.Dq != nullptr && (BN % 32 != 0 || (BN / WN) % 32 != 0))        // whole value|gate groups per tile, per wave
+    return MIXDQ_ERR_GEGLU_SHAPE;
   if constexpr (SMEM > 64 * 1024) {   // opt in to > 64 KiB of dynamic LDS, once per instantiation and device
     static bool seen[64] = {};
     if (const int st = lds_opt_in(
@@ -1752,6 +1753,7 @@ int launch_tile(IgemmParams& p, hipStream_t stream) {
   X(20, 256, 256, 128, 2, 4, 2, 1, 32, false)    \
   X(25, 128, 320, 128, 2, 4, 2, 1, 32, false)    \
   X(27, 128, 320, 128, 2, 8, 2, 1, 16, false)    \
+  X(28, 128, 320, 128, 2, 4, 4, 1, 16, false)    \
   X(35, 128, 128, 64, 3, 4, 2, 1, 32, false)     \
   X(37, 64, 64, 128, 3, 2, 2, 2, 32, false)      \
   X(41, 64, 128, 128, 3, 2, 4, 1, 32, false)     \
@@ -1822,7 +1824,11 @@ inline int select_cfg(int64_t M, int N, int Ktot, bool whole64 = false, bool pha
   // where this tile looks GELU up in LDS: (4096, 5120, 640) 30.3 vs 35.9 us)
   if (N % 320 == 0 && Ktot % 128 == 0 && (Ktot >= 1024 || whole64) &&
       (b320 == kNumCU || b320 == 2 * kNumCU))
-    return 27;   // the 128x320 tile on 16 waves of 16 x 160 (25: the same tile on 8 waves of 32 x 160)
+    // the 128x320 tile on 16 waves: 8 x 2 waves of 16 x 160 (27; GEMM+GEGLU needs 32-column groups per
+    // wave), or -- long K, where the main loop is what counts -- 4 x 4 waves of 32 x 80 (28: 7 fragment
+    // reads per 10 MFMAs instead of 11; (8192, 1280, 5120) 53.8 vs 59.6 us, (32768, 640, 2560) 62.6 vs
+    // 66.5, (8192, 1280, 1280) 21.2 vs 20.9).  (25: the same tile on 8 waves of 32 x 160.)
+    return (!whole64 && Ktot >= 2048) ? 28 : 27;
   // from 1.5 workgroups of 256x256 per CU on: the four-phase loop (fewest L2->LDS bytes per MAC, the
   // reads and the DMA of one wave group under the other's MFMAs): (8192, 10240, 1280) 135 vs 153 us on
   // 256x128, (8192, 3840, 1280) 56 vs 62, (32768, 1920, 640) 77 vs 84 (tools/bench_gemm.py --bs 8)
@@ -1993,7 +1999,7 @@ inline int select_cfg_f16(int64_t M, int N, int k_bytes) {
       return c;
     case 37: return 4;              // k-split 64x64 -> the plain 64x64 tile
     case 45: case 56: case 42: return 41;   // exact-fit 64x80 (16x16 MFMA, k-split) -> 64x128
-    case 27: return 25;             // 16 waves of 16x16x64 MFMAs -> the same tile on 8 waves of 32x32
+    case 27: case 28: return 25;    // 16 waves of 16x16x64 MFMAs -> the same tile on 8 waves of 32x32
     case 70: case 14: case 18: return 20;
     default: return 35;
   }
@@ -2219,7 +2225,7 @@ extern "C" int mixdq_qconv2d_w8a8_table(const int8_t* X, const int8_t* Wt, const
   const int Q = (W + 2 * pad - (S - 1) - 1) / stride + 1;
   if (P <= 0 || Q <= 0 || N == 0) return MIXDQ_OK;
   // 3x3 / stride 1 / pad 1 with the input halo resident in LDS (csrc/iconv.hip): the automatic choice
-  // wherever it applies; tile ids 90 / 91 / 92 force it, any other forced id keeps the implicit-GEMM family
+  // wherever it applies; tile ids 90 .. 93 force it, any other forced id keeps the implicit-GEMM family
   // (MIXDQ_HALO_CONV=0: off, for A/B runs)
   {
     static const bool halo_on = [] { const char* e = getenv("MIXDQ_HALO_CONV"); return !(e && e[0] == '0'); }();
@@ -2228,10 +2234,10 @@ extern "C" int mixdq_qconv2d_w8a8_table(const int8_t* X, const int8_t* Wt, const
                             (uintptr_t)D | (uintptr_t)residual_f16_or_null) & 15) &&
                          !((uintptr_t)bias_f16_or_null & 7);
     int tile = 0;
-    if (!(flags & MIXDQ_FLAG_W4) && aligned && (forced == 90 || forced == 91 || forced == 92 || (forced == 0 && halo_on)))
+    if (!(flags & MIXDQ_FLAG_W4) && aligned && ((forced >= 90 && forced <= 93) || (forced == 0 && halo_on)))
       tile = halo_conv_select(N, H, W, C, K, R, S, stride, pad);
-    if (forced == 90 || forced == 91 || forced == 92) {
-      if (tile == 0 || (forced != 91 && W % 16 != 0) || (forced == 92 && H % 16 != 0)) return MIXDQ_ERR_SHAPE;
+    if (forced >= 90 && forced <= 93) {
+      if (tile == 0 || (forced != 91 && W % 16 != 0) || (forced >= 92 && H % 16 != 0)) return MIXDQ_ERR_SHAPE;
       tile = forced;
     }
     if ((flags & MIXDQ_FLAG_UPSAMPLE2X) && (tile == 0 || (H & 1) || (W & 1))) return MIXDQ_ERR_SHAPE;

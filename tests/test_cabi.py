@@ -82,6 +82,7 @@ def test_tile_choice_is_a_host_function_of_the_shape():
     # batch 1: exactly one workgroup per CU (64x80), six stages for cold K <= 2048, four beyond
     assert sel(1024, 1280, 1280, 1280) == 56 and sel(1024, 1280, 5120, 5120) == 45
     assert sel(1024, 10240, 1280, 1280) == 27 and sel(4096, 640, 2560, 2560) == 44
+    assert sel(8192, 1280, 5120, 5120) == 28 and sel(8192, 1280, 1280, 1280) == 27      # 128x320: 4 x 4 waves for long K
     # batch 8: the four-phase 256x256 loop for plain Linear launches from 1.5 workgroups per CU on ...
     assert sel(8192, 10240, 1280, 1280) == 70 and sel(8192, 3840, 1280, 1280) == 70
     assert sel(32768, 1920, 640, 640) == 70

@@ -276,6 +276,8 @@ def test_qlinear_geglu_rejects_tiles_without_whole_value_gate_groups(C):
     v = torch.ones(320, device=DEV)
     with pytest.raises(RuntimeError, match="N % 32"):
         C.qlinear_geglu(a, w, v, v, None, scal(1.0), scal(0.0), _cfg=42)
+    with pytest.raises(RuntimeError, match="N % 32"):        # 128x320 on 4 x 4 waves: 80 columns per wave
+        C.qlinear_geglu(a, w, v, v, None, scal(1.0), scal(0.0), _cfg=28)
 
 
 def test_qlinear_geglu_argument_checks(C):

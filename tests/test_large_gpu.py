@@ -66,7 +66,7 @@ def test_qlinear_full_batch_sampled_rows_vs_oracle(C, oracle, B, T, N, K, bias):
     want_res = oracle.add_f16(want, res.numpy()[rows])
     assert np.array_equal(bits(out_res.cpu().numpy()[rows]), bits(want_res))
     # which tile ran: at these sizes the automatic choice must be one of the large / 8-wave tiles
-    assert C.igemm_select_id(M, N, K) in (13, 20, 25, 27, 35, 41, 44, 70), C.igemm_select_id(M, N, K)
+    assert C.igemm_select_id(M, N, K) in (13, 20, 25, 27, 28, 35, 41, 44, 70), C.igemm_select_id(M, N, K)
 
 
 @pytest.mark.parametrize("B", [8, 16])
@@ -258,7 +258,7 @@ def test_shard_size_conv_equals_per_image_and_oracle(C, oracle, B, ks, Cin, Cout
 
     full = run(x, res)
     if ks == 3:
-        assert C.conv_halo_select(B, HW, HW, Cin, Cout, 3, 3, 1, 1) == 92
+        assert C.conv_halo_select(B, HW, HW, Cin, Cout, 3, 3, 1, 1) == 93      # 16 x 16 pixels x 160 channels
     for i in (0, B // 2, B - 1):                                 # batch equivariance, bit for bit
         assert torch.equal(full[i:i + 1], run(x[i:i + 1], None if res is None else res[i:i + 1])), f"image {i}"
     rows = 4                                                     # a top band of the LAST image vs the oracle

@@ -464,6 +464,10 @@ HALO_CASES = [  # n, h, w, c, k, bias, residual ("", "full", "image"), forced ti
     (1, 16, 32, 320, 168, True, "full", 92),     # 16 x 16 patches, 64-byte chunks (5 of them), N tail
     (2, 32, 16, 64, 80, False, "image", 92),     # one chunk
     (1, 16, 16, 192, 72, True, "", 92),          # a single all-border patch
+    (1, 32, 16, 320, 320, True, "full", 93),     # 16 x 16 patches x 160 channels on 4 x 2 waves, two channel tiles
+    (2, 16, 32, 128, 168, True, "image", 93),    # N tail in the second channel tile (8 of 160)
+    (1, 16, 16, 64, 72, False, "", 93),          # N tail inside the first wave group; all-border patch
+    (8, 32, 32, 64, 160, True, "full", 0),       # automatic, batch 8 (too few 160-channel workgroups for 93)
 ]
 
 
@@ -480,7 +484,7 @@ def test_qconv2d_halo_kernel_bit_exact(C, oracle, case):
     in_zp = -11.0
     bias = dd.f16(904, (k,), -1, 1) if has_bias else None
     wsum = wt.astype(np.float32).sum(axis=3, dtype=np.float32)
-    assert C.conv_halo_select(n, h, w_, c, k, 3, 3, 1, 1) in (90, 91, 92)
+    assert C.conv_halo_select(n, h, w_, c, k, 3, 3, 1, 1) in (90, 91, 92, 93)
     args = (t(x).permute(0, 3, 1, 2), t(wt).permute(0, 3, 1, 2), t(scale), scal(1.0), scal(in_zp),
             t(scale), t(wsum.reshape(k, 1, 3, 3)), None, None if bias is None else t(bias), 1, 1)
     kw = {}
@@ -500,7 +504,7 @@ def test_qconv2d_halo_kernel_bit_exact(C, oracle, case):
     assert torch.equal(got, C.qconv2d_w8_a8_ohalf(*args, _cfg=4, **kw)), "halo != implicit GEMM"
 
 
-@pytest.mark.parametrize("n,h,w_,c,k,tile", [(2, 8, 8, 192, 168, 0), (1, 16, 8, 64, 80, 92), (1, 4, 8, 320, 72, 91),
+@pytest.mark.parametrize("n,h,w_,c,k,tile", [(2, 8, 8, 192, 168, 0), (1, 16, 8, 64, 80, 92), (1, 8, 8, 128, 168, 93), (1, 4, 8, 320, 72, 91),
                                              (3, 8, 16, 128, 96, 90)])
 def test_qconv2d_upsample2x_reads_the_small_tensor(C, n, h, w_, c, k, tile):
     """MIXDQ_FLAG_UPSAMPLE2X: conv(nearest-2x-upsample(x)) from the [n, h, w] tensor == the conv on
