@@ -23,6 +23,7 @@
 // Softmax in FP32 with base-2 exponentials (v_exp_f32), P rounded to FP16 for the second MFMA, row
 // sums accumulated in FP32 from that rounded P (a third MFMA with a ones operand); O staged through LDS and stored as whole 128-B rows.
 #include "common.h"
+#include <cstdlib>
 #include "attn_core.h"
 
 namespace mixdq {
@@ -409,6 +410,196 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2
   }
 }
 
+// SHORT key sequences (tkv <= 128: the UNet's cross-attention, 77 keys): a workgroup's life is one
+// memory round trip (K / V staged, Q fetched) and ~1.5 us of arithmetic -- a latency chain, and the
+// pipelined kernel above holds 2 waves per SIMD (its three-deep pipeline needs 200+ registers), so at
+// batch >= 2, where the fused to_q + cross-attention launch (igemm.hip) is not used, the launch ran in
+// 2.5 rounds of two workgroups per CU.  This kernel runs the same arithmetic in the same order --
+// tile by tile, unpipelined, exactly the sequence of the fused epilogue in igemm.hip -- in <= 128
+// registers: four workgroups per CU, 32 KB of LDS each.  Bit-identical to attn_fwd_kernel
+// (tests/test_attention_gpu.py).
+template <bool QUANT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_short_kernel(const AttnParams p) {
+  MIXDQ_ARGS_NOW(p.q, p.k, p.v, p.out, p.q_bs, p.q_rs, p.k_bs, p.k_rs, p.v_bs, p.v_rs, p.o_bs, p.o_rs,
+                 p.tq, p.tkv, p.heads, p.qblocks);
+  MIXDQ_ARGS_NOW(p.scale_log2, p.s_inv, p.zp, p.unfused);
+  constexpr int WAVES = 4, NI = 16 / WAVES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l32 = lane & 31, hh = lane >> 5;
+  const int qb = blockIdx.x % p.qblocks;
+  const int head = (blockIdx.x / p.qblocks) % p.heads;
+  const int b = blockIdx.x / (p.qblocks * p.heads);
+  const int q0 = qb * (WAVES * 32) + wave * 32;
+  const int ntiles = (p.tkv + kKeys - 1) / kKeys;      // 1 or 2
+
+  v8h qf[4];
+  {
+    const int qr = min(q0 + l32, p.tq - 1);
+    const __half* qrow = p.q + b * p.q_bs + (long)qr * p.q_rs + head * kHeadDim + hh * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *reinterpret_cast<const v8h*>(qrow + ks * 16);
+  }
+  // staging: as attn_fwd_kernel (waves 0, 1: K, waves 2, 3: V; same images), real tiles only
+  {
+    const int srow = lane >> 3, spos = lane & 7;
+    const bool stage_v = wave * NI >= 8;
+    const char* sbase = reinterpret_cast<const char*>(
+        (stage_v ? p.v + b * p.v_bs : p.k + b * p.k_bs) + head * kHeadDim);
+    const unsigned srs = 2u * (unsigned)(stage_v ? p.v_rs : p.k_rs);
+    const int last_key = p.tkv - 1;
+    for (int t = 0; t < ntiles; ++t) {
+      char* dst = smem + t * kStageBytes + wave * NI * 1024;
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int krow = ((wave * NI + i) & 7) * 8 + srow;
+        const int sw = stage_v ? ((krow >> 1) & 1) << 2 : (krow >> 1) & 7;
+        const int key = min(t * kKeys + krow, last_key);   // past the end: the last key, masked below
+        glds16(sbase + ((unsigned)key * srs + (unsigned)((spos ^ sw) * 16)), dst + i * 1024);
+      }
+    }
+  }
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  unsigned k_a[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) k_a[ks] = lds0 + l32 * kRow + (((2 * ks + hh) ^ ((l32 >> 1) & 7)) << 4);
+  const int q4 = (lane & 15) >> 2, pp = lane & 3, g16 = (lane >> 4) & 1;
+  const int v_rd0 = kTileBytes + (4 * hh + q4) * kRow +
+                    (((2 * g16 + (pp >> 1)) ^ (((q4 >> 1) & 1) << 2)) << 4) + 8 * (pp & 1);
+  const unsigned v_a0 = lds0 + v_rd0, v_a1 = lds0 + (v_rd0 ^ 64);
+  v16f o[2], lsum;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { o[0][i] = 0.f; o[1][i] = 0.f; lsum[i] = 0.f; }
+  float m_i = -INFINITY;
+  const float c = p.scale_log2;
+  v8h ones;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ones[i] = (_Float16)1.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    if (t >= ntiles) break;
+    v16f sc[2];
+    {
+      v8h kf[2][4];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          kf[kb][ks] = *(const __attribute__((address_space(3))) v8h*)(size_t)(
+              k_a[ks] + (t * kStageBytes + kb * 32 * kRow));
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sc[kb][i] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][ks], qf[ks], sc[kb], 0, 0, 0);
+      }
+    }
+    if (t == ntiles - 1 && (p.tkv & (kKeys - 1)) != 0) {     // mask the absent keys
+      const int lim = p.tkv - t * kKeys - 4 * hh;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (32 * kb + 8 * (r >> 2) + (r & 3) >= lim) sc[kb][r] = -INFINITY;
+    }
+    float mx = sc[0][0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sc[0][r]);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[1][r]);
+    mx = half_max(mx);
+    const float m_new = fmaxf(m_i, mx);
+    const bool grew = m_new > m_i;
+    const float mc = m_new * c;
+    v8h pf[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        pf[kb][r >> 3][r & 7] = (_Float16)__builtin_amdgcn_exp2f(__builtin_fmaf(sc[kb][r], c, -mc));
+    if (__builtin_amdgcn_ballot_w64(grew)) {
+      const float alpha = __builtin_amdgcn_exp2f((m_i - m_new) * c);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { o[0][i] *= alpha; o[1][i] *= alpha; }
+      lsum[0] *= alpha;
+    }
+    m_i = m_new;
+    // V^T fragments two 16-key groups at a time (registers), in the product order of attn_pv_tile
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      VFrag vf[2][2];
+      const unsigned a0 = v_a0 + t * kStageBytes, a1 = v_a1 + t * kStageBytes;
+      if (kb == 0) {
+        tr_read2_imm<0 * kRow>(vf[0][0], a0);
+        tr_read2_imm<0 * kRow>(vf[0][1], a1);
+        tr_read2_imm<16 * kRow>(vf[1][0], a0);
+        tr_read2_imm<16 * kRow>(vf[1][1], a1);
+      } else {
+        tr_read2_imm<32 * kRow>(vf[0][0], a0);
+        tr_read2_imm<32 * kRow>(vf[0][1], a1);
+        tr_read2_imm<48 * kRow>(vf[1][0], a0);
+        tr_read2_imm<48 * kRow>(vf[1][1], a1);
+      }
+      s_waitcnt_lgkm0();
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+          o[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[u][db].h, pf[kb][u], o[db], 0, 0, 0);
+        lsum = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, pf[kb][u], lsum, 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();                                   // every wave is done with the K / V images
+  const float inv = 1.f / lsum[0];
+  char* Os = smem + wave * (32 * kORow);
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      v4h w;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) w[j] = (_Float16)(o[db][4 * g + j] * inv);
+      *reinterpret_cast<v4h*>(Os + l32 * kORow + (32 * db + 8 * g + 4 * hh) * 2) = w;
+    }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private staging: no block barrier
+  float s_inv = 0.f, zp = 0.f;
+  if constexpr (QUANT) { s_inv = *p.s_inv; zp = *p.zp; }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int id = lane + 64 * i, row = id >> 3, ch = id & 7;
+    if (q0 + row >= p.tq) continue;
+    const uint4 w = *reinterpret_cast<const uint4*>(Os + row * kORow + ch * 16);
+    const long off = b * p.o_bs + (long)(q0 + row) * p.o_rs + head * kHeadDim + ch * 8;
+    if constexpr (!QUANT) {
+      *reinterpret_cast<uint4*>(reinterpret_cast<__half*>(p.out) + off) = w;
+    } else {
+      const __half* hv = reinterpret_cast<const __half*>(&w);
+      uint32_t pk[2] = {0u, 0u};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float x = __half2float(hv[j]);
+        const int qv = p.unfused ? quantize_one<true>(x, s_inv, zp) : quantize_one<false>(x, s_inv, zp);
+        pk[j >> 2] |= (uint32_t)(qv & 0xff) << (8 * (j & 3));
+      }
+      *reinterpret_cast<uint2*>(reinterpret_cast<int8_t*>(p.out) + off) = make_uint2(pk[0], pk[1]);
+    }
+  }
+}
+
+int launch_attn_short(const AttnParams& p, int batch, bool quant, hipStream_t stream) {
+  const int grid = p.qblocks * p.heads * batch;
+  const int smem = 2 * kStageBytes;                  // two K | V tiles; the output staging overlays them
+  if (quant) hipLaunchKernelGGL((attn_short_kernel<true>), dim3(grid), dim3(256), smem, stream, p);
+  else hipLaunchKernelGGL((attn_short_kernel<false>), dim3(grid), dim3(256), smem, stream, p);
+  return launch_status();
+}
+
 constexpr int attn_smem_bytes(int waves, int stages) {
   const int kv = stages * kStageBytes;
   const int os = waves * 32 * kORow;
@@ -478,7 +669,13 @@ extern "C" int mixdq_attention_f16(const void* q, const void* k, const void* v, 
   // gone: after the loop was pipelined it no longer won -- 16.9 vs 16.2 us, tools/bench_attn.py --
   // and, merging two partial softmaxes, it made a batch-1 result differ in its last bits from the
   // same image inside a batch.)
-  const int force = (flags >> 8) & 0xff;         // 4 / 2: waves per workgroup
+  const int force = (flags >> 8) & 0xff;         // 4 / 2: waves per workgroup of the pipelined kernel; 1: the short-key kernel
+  if (force == 1 && tkv > 2 * kKeys) return MIXDQ_ERR_SHAPE;
+  static const bool short_on = [] { const char* e = getenv("MIXDQ_ATTN_SHORT"); return !(e && e[0] == '0'); }();   // A/B runs
+  if (force == 1 || (force == 0 && short_on && tkv <= 2 * kKeys)) {   // cross-attention: 77 keys
+    p.qblocks = (tq + 127) / 128;
+    return launch_attn_short(p, batch, quant, stream);
+  }
   const long blocks128 = (long)((tq + 127) / 128) * heads;
   const bool big = force ? force == 4 : blocks128 >= kNumCU / 2;
   p.qblocks = big ? (tq + 127) / 128 : (tq + 63) / 64;

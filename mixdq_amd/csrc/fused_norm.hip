@@ -499,6 +499,17 @@ extern "C" int mixdq_groupnorm_silu_quantize3(const void* x_nhwc, int C1, const 
     stats = partial + (size_t)N * g.nchunk * G;
     gn_finalize_kernel<<<dim3(G, N), 64, 0, stream>>>(partial, stats, g, eps);
   }
+  // The apply pass is elementwise (any split gives the same bits).  With SiLU it is a VALU chain per lane
+  // (exp and a correctly rounded division per element); at small batch -- fewer than 1024 statistics blocks,
+  // every block's chain on the launch's critical path -- half-length blocks end sooner: (1, 128 x 128, 960)
+  // 42.5 -> 38.3 us for the three launches, (1, 64 x 64, 1920) 26.6 -> 25.5, (1, 32 x 32, 1280) 13.6 -> 13.0.
+  // Shorter still, or from batch 2 on, or without SiLU: equal or slower.  From 2048 blocks on, FEWER and longer
+  // blocks are slower too ((8, 128 x 128, 320): 75 us at 512 per image, 80 at 256, 99 at 64), and requesting
+  // the next pixel one iteration ahead changes nothing (tools/gpu_s12.sh, tools/gpu_s13.sh).
+  if (apply_silu && (int64_t)N * g.nchunk < 1024 && g.ppb >= 2 * g.PP) {
+    g.ppb_apply = (g.ppb / 2 / g.PP) * g.PP;
+    g.nchunk_apply = (int)((HW + g.ppb_apply - 1) / g.ppb_apply);
+  }
   const dim3 grid(g.nchunk_apply, N);
   const bool unfused = flags & MIXDQ_FLAG_UNFUSED;
 #define GN_APPLY(S, U)                                                                          \

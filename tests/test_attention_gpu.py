@@ -61,6 +61,10 @@ SMALL = [  # B, Tq, Tkv, C, fused layout, forced workgroup shape
     # more shapes on the 64-query (two-wave) workgroups
     (2, 256, 256, 192, True, 2), (2, 96, 130, 64, False, 2), (1, 64, 640, 64, True, 2),
     (1, 320, 704, 128, False, 2), (1, 1, 300, 128, False, 2),
+    # the short-key kernel (tkv <= 128; automatic there, forced = 1): one and two tiles, whole and ragged,
+    # ragged queries, a single key, batch + fused k|v layout
+    (1, 128, 64, 128, False, 1), (1, 100, 77, 128, False, 1), (2, 96, 128, 64, False, 1),
+    (3, 33, 1, 64, False, 1), (2, 300, 100, 192, False, 1), (2, 128, 128, 128, True, 1),
 ]
 
 
@@ -78,6 +82,27 @@ def test_attention_workgroup_shapes_agree_bit_for_bit_and_rows_of_a_batch_equal_
     for b in range(B):
         one = C.attention_f16(qd[b:b + 1], kd[b:b + 1], vd[b:b + 1], Cc // 64)
         assert torch.equal(one, auto[b:b + 1])
+
+
+@pytest.mark.parametrize("B,tq,tkv,Cc", [(2, 1024, 77, 1280), (1, 100, 77, 128), (3, 160, 128, 64), (2, 96, 64, 192),
+                                         (1, 4096, 77, 640), (2, 130, 1, 64), (1, 256, 65, 128)])
+def test_attention_short_key_kernel_is_bit_identical_to_the_pipelined_one(C, B, tq, tkv, Cc):
+    """tkv <= 128 (the UNet's cross-attention: 77 keys) runs attn_short_kernel -- the same arithmetic in the
+    same order, unpipelined, at four workgroups per CU.  Same bits as both pipelined launch shapes, FP16 and
+    INT8 output; beyond 128 keys forcing it is an error."""
+    host, _ = make(91, B, tq, tkv, Cc, False)
+    qd, kd, vd = device_views(host, tq, tkv, Cc, False)
+    heads = Cc // 64
+    auto = C.attention_f16(qd, kd, vd, heads)
+    assert torch.equal(auto, C.attention_f16(qd, kd, vd, heads, _cfg=1))
+    assert torch.equal(auto, C.attention_f16(qd, kd, vd, heads, _cfg=4))
+    assert torch.equal(auto, C.attention_f16(qd, kd, vd, heads, _cfg=2))
+    s_inv, zp = scal(float(np.float32(1) / np.float32(0.0173))), scal(7.0)
+    assert torch.equal(C.attention_f16(qd, kd, vd, heads, s_inv, zp, _cfg=1),
+                       C.attention_f16(qd, kd, vd, heads, s_inv, zp, _cfg=4))
+    long_k = t(dd.normal_f16(92, (B, 129, Cc), 1.0))
+    with pytest.raises(RuntimeError):
+        C.attention_f16(qd, long_k, long_k, heads, _cfg=1)
 
 
 @pytest.mark.parametrize("case", SMALL, ids=[f"b{c[0]}_q{c[1]}_k{c[2]}_c{c[3]}_{'f' if c[4] else 's'}_w{c[5]}" for c in SMALL])

@@ -37,10 +37,13 @@ def main():
     ap.add_argument("--bs", type=int, default=1)
     ap.add_argument("--impl", default="torch,hip")
     ap.add_argument("--cfg", type=lambda x: int(x, 0), default=0)
+    ap.add_argument("--only", default="", help="substring of the shape name (e.g. cross)")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
     total = {}
     for name, tq, tkv, c, calls in SHAPES:
+        if a.only not in name:
+            continue
         h = c // 64
         torch.manual_seed(0)
         if tq == tkv:

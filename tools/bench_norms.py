@@ -22,7 +22,7 @@ for M, Cc in ((8192, 1280), (32768, 640), (1024, 1280), (4096, 640), (16384, 128
     t_q = timed(lambda: C.quantize_per_tensor_to_int8(x, one, z), 20)
     by = 3 * M * Cc
     print(f"LN ({M},{Cc}) rows={os.environ.get('MIXDQ_LN_ROWS', 'auto')}: {t_ln:6.2f} us = {by / t_ln / 1e6:5.2f} TB/s | torch f16->i8 copy {t_cp:6.2f} us | quantize {t_q:6.2f} us", flush=True)
-for N, HW, Cc in ((8, 128, 320), (8, 64, 640), (8, 32, 1280), (1, 128, 320)):
+for N, HW, Cc in ((8, 128, 320), (8, 64, 640), (8, 32, 1280), (1, 128, 320), (1, 128, 960), (1, 64, 640), (1, 64, 1920), (1, 32, 1280), (2, 128, 320)):
     x = torch.randn(N, Cc, HW, HW, device=DEV).half().contiguous(memory_format=torch.channels_last)
     w, b = torch.ones(Cc, device=DEV).half(), torch.zeros(Cc, device=DEV).half()
     o = torch.empty(N, HW, HW, Cc, dtype=torch.int8, device=DEV)
