@@ -183,7 +183,8 @@ def roofline_sweep(run_eager, device, reps):
     groups = {}
     for kind, (M, N, K, k_align), w4, replay in rec:
         if kind == "attention":          # FP16 attention core: M = B * heads * Tq, N = Tkv, K = head_dim
-            g_ = groups.setdefault(f"attn_fwd_kernel<Tkv={N}>", dict(fns=[], ops=0.0, bytes=0.0, f16=True))
+            kern = "attn_short_kernel" if N <= 128 else "attn_fwd_kernel"     # csrc/attention.hip's rule
+            g_ = groups.setdefault(f"{kern}<Tkv={N}>", dict(fns=[], ops=0.0, bytes=0.0, f16=True))
             g_["fns"].append(replay)
             g_["ops"] += 4.0 * M * N * K                       # Q K^T and P V
             g_["bytes"] += 2.0 * (2 * M * K) + 0.0             # q read + o written (k / v are re-read per q block)
