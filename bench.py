@@ -252,7 +252,7 @@ def roofline_object(roof_stats, B, reps, px, tiny):
     if os.path.exists(pmc) and px == 1024 and not tiny:
         with open(pmc) as f:      # sections by batch size of the probed launches (bs1, bs8)
             pmc_all = json.load(f).get(f"bs{B}", {})
-        entry = pmc_all.get(dom.split("#")[0], {})
+        entry = pmc_all.get(dom) or pmc_all.get(dom.split("#")[0], {})     # "...#cfgNN" where a tile has several wave layouts
         traffic, mfma_util = entry.get("hbm_bytes_per_launch"), entry.get("mfma_util")
     per_kernel = {}
     for k, v in sorted(roof_stats.items()):
@@ -261,7 +261,8 @@ def roofline_object(roof_stats, B, reps, px, tiny):
         per_kernel[k] = {"ms_per_step": v["ms"] / reps, "launches": v["launches"] // reps,
                          "avg_launch_us": 1e3 * v["ms"] / v["launches"], "tops": tops,
                          "frac": tops / peak, "peak": peak}
-        e = pmc_all.get(k.split("#")[0])
+        e = pmc_all.get(k) or (None if any(n.startswith(k.split("#")[0] + "#") for n in pmc_all)
+                               else pmc_all.get(k.split("#")[0]))
         if e:
             per_kernel[k].update({kk: e[kk] for kk in ("mfma_util", "hbm_bytes_per_launch", "valu_util")
                                   if kk in e})

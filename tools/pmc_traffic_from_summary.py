@@ -27,6 +27,8 @@ for key, e in json.load(open(src)).items():
     else:
         kind = "linear_geglu" if shape.startswith("geglu") else "linear"
         name = f"igemm_kernel<{args[0]},{args[1]},{args[2]},{args[3]},{kind}>"
+        if args[:4] == ["128", "320", "128", "2"]:      # one tile, three wave layouts: keep them apart
+            name += {("4", "2"): "#cfg25", ("8", "2"): "#cfg27", ("4", "4"): "#cfg28"}.get((args[4], args[5]), "")
         bs = max(1, int(re.search(r"M(\d+)", shape).group(1)) // 1024)
     out.setdefault(f"bs{bs}", {})[name] = {
         "shape": shape, "hbm_bytes_per_launch": e["hbm_bytes_per_launch"],
