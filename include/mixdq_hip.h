@@ -320,6 +320,26 @@ int mixdq_attention_f16(const void* q_f16, const void* k_f16, const void* v_f16,
                         float softmax_scale, const float* out_scale_inv_or_null,
                         const float* out_zero_point_or_null, int flags, mixdq_stream_t stream);
 
+/* mixdq_attention_f16 with a PREFETCH payload: beside the attention workgroups the launch carries
+ * workgroups that do nothing but read the `n_prefetch` (<= 8) given byte ranges (HOST arrays of device
+ * pointers / sizes) -- the INT8 weights of the layers that FOLLOW this attention in the network.  At
+ * batch 1 a 1024-token self-attention occupies 62 % of the SIMDs for ~17 us and leaves HBM idle, while
+ * every GEMM behind it streams weights that were last touched a step ago (2.6 GB per step: nothing
+ * survives in the 256 MB Infinity Cache); read here, they are served from that cache when their GEMM
+ * runs.  The payload has no effect on any result.  No reference counterpart.
+ * Ranges may be null / empty; the attention itself is mixdq_attention_f16's, bit for bit.  Launches on
+ * the short-key kernel (tkv <= 128) ignore the payload. */
+int mixdq_attention_f16_prefetch(const void* q_f16, const void* k_f16, const void* v_f16, void* out,
+                                 int batch, int heads, int head_dim, int tq, int tkv,
+                                 int64_t q_batch_stride, int64_t q_row_stride,
+                                 int64_t k_batch_stride, int64_t k_row_stride,
+                                 int64_t v_batch_stride, int64_t v_row_stride,
+                                 int64_t out_batch_stride, int64_t out_row_stride,
+                                 float softmax_scale, const float* out_scale_inv_or_null,
+                                 const float* out_zero_point_or_null,
+                                 const void* const* prefetch_ptrs, const int64_t* prefetch_bytes,
+                                 int n_prefetch, int flags, mixdq_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * FP16 layers.  Replaces the reference's FP fallback for layers without an activation quantizer
  * or with unsupported weight bits -- F.linear / F.conv2d on the FP16 weight (nn/Linear.py:155-156,

@@ -845,12 +845,22 @@ _lib.mixdq_attention_f16.argtypes = [_vp] * 4 + [_i32] * 5 + [_i64] * 8 + [ctype
 _lib.mixdq_attention_f16.restype = _i32
 
 
-def attention_f16(q, k, v, heads, scale_inv=None, zero_point=None, softmax_scale=None, _cfg=0):
+if hasattr(_lib, "mixdq_attention_f16_prefetch"):     # (absent in older builds used for A/B runs)
+    _lib.mixdq_attention_f16_prefetch.argtypes = [_vp] * 4 + [_i32] * 5 + [_i64] * 8 + [
+        ctypes.c_float, _vp, _vp, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64), _i32, _i32, _vp]
+    _lib.mixdq_attention_f16_prefetch.restype = _i32
+PREFETCH_MAX_RANGES = 8
+
+
+def attention_f16(q, k, v, heads, scale_inv=None, zero_point=None, softmax_scale=None, _cfg=0, _prefetch=None):
     """FP16 attention core (the reference's get_attention_scores + bmm, quant_block.py:630-637).
 
     q [B, Tq, C], k/v [B, Tkv, C] fp16 with unit stride along C (column slices of a fused projection
     are read in place); C = heads * 64.  Returns fp16 [B, Tq, C], or — when `scale_inv`/`zero_point`
     (to_out.0's activation quantizer) are given — its int8 quantization.
+    `_prefetch`: up to 8 GPU tensors (the weights of the layers behind this attention) that payload
+    workgroups of the launch read while the attention runs (mixdq_attention_f16_prefetch); no effect
+    on the result.
     """
     for t, n in ((q, "q"), (k, "k"), (v, "v")):
         _check(t.is_cuda and t.dtype == torch.float16 and t.dim() == 3 and t.stride(-1) == 1,
@@ -862,14 +872,25 @@ def attention_f16(q, k, v, heads, scale_inv=None, zero_point=None, softmax_scale
     # (measurement only) recorded as ("attention", (B * heads * Tq, Tkv, 64, 64)): 4 * M * N * K FLOPs
     _record("attention", B * heads * Tq, k.shape[1], 64, 64, False, attention_f16,
             (q, k, v, heads), dict(scale_inv=scale_inv, zero_point=zero_point,
-                                   softmax_scale=softmax_scale, _cfg=_cfg))
+                                   softmax_scale=softmax_scale, _cfg=_cfg))     # (measured without the payload)
     out = torch.empty((B, Tq, C), dtype=torch.int8 if quant else torch.float16, device=q.device)
     sc = float(softmax_scale) if softmax_scale is not None else 0.125
+    pf = [t for t in (_prefetch or ()) if t is not None and t.is_cuda and t.numel() > 0]
+    _check(len(pf) <= PREFETCH_MAX_RANGES, "at most 8 prefetch ranges")
     with torch.cuda.device(q.device):
-        code = _lib.mixdq_attention_f16(
-            q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, heads, 64, Tq, k.shape[1],
-            q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
-            out.stride(0), out.stride(1), sc, _ptr(scale_inv), _ptr(zero_point),
-            FLAGS | (int(_cfg) << 8), _stream())
+        if pf and hasattr(_lib, "mixdq_attention_f16_prefetch"):
+            ptrs = (ctypes.c_void_p * len(pf))(*[t.data_ptr() for t in pf])
+            sizes = (ctypes.c_int64 * len(pf))(*[t.numel() * t.element_size() for t in pf])
+            code = _lib.mixdq_attention_f16_prefetch(
+                q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, heads, 64, Tq, k.shape[1],
+                q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
+                out.stride(0), out.stride(1), sc, _ptr(scale_inv), _ptr(zero_point), ptrs, sizes, len(pf),
+                FLAGS | (int(_cfg) << 8), _stream())
+        else:
+            code = _lib.mixdq_attention_f16(
+                q.data_ptr(), k.data_ptr(), v.data_ptr(), out.data_ptr(), B, heads, 64, Tq, k.shape[1],
+                q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
+                out.stride(0), out.stride(1), sc, _ptr(scale_inv), _ptr(zero_point),
+                FLAGS | (int(_cfg) << 8), _stream())
     _status(code, "attention_f16")
     return out

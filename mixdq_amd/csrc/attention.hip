@@ -39,7 +39,41 @@ struct AttnParams {
   float scale_log2;                // softmax scale * log2(e)
   const float* s_inv; const float* zp;
   int unfused;
+  // prefetch payload (mixdq_attention_f16_prefetch): workgroups attn_blocks .. attn_blocks + pf_blocks - 1
+  // read these byte ranges and do nothing else
+  int attn_blocks, pf_blocks, n_pf, pf_nt;
+  const char* pf_ptr[8];
+  long pf_bytes[8];
 };
+
+// The prefetch role: every thread reads 16 bytes per step, a workgroup 4 KB, the payload workgroups
+// together a contiguous stripe; eight loads in flight per lane.  The values are folded into a register the
+// compiler must keep (an empty asm consumes it): nothing is written.
+__device__ __forceinline__ void attn_prefetch_role(const AttnParams& p) {
+  const long first = ((long)(blockIdx.x - p.attn_blocks) * blockDim.x + threadIdx.x) * 16;
+  const long stride = (long)p.pf_blocks * blockDim.x * 16;
+  v4i acc = {0, 0, 0, 0};
+  for (int r = 0; r < p.n_pf; ++r) {
+    const char* base = p.pf_ptr[r];
+    const long n = p.pf_bytes[r] & ~15l;           // whole 16-byte pieces (the tail shares their cache line)
+    long off = first;
+    for (; off + 7 * stride < n; off += 8 * stride) {
+      v4i t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const v4i* src = reinterpret_cast<const v4i*>(base + off + u * stride);
+        t[u] = p.pf_nt ? __builtin_nontemporal_load(src) : *src;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc ^= t[u];
+    }
+    for (; off < n; off += stride) {
+      const v4i* src = reinterpret_cast<const v4i*>(base + off);
+      acc ^= p.pf_nt ? __builtin_nontemporal_load(src) : *src;
+    }
+  }
+  asm volatile("" ::"v"(acc));
+}
 
 __device__ __forceinline__ float half_sum(float x) {
   auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
@@ -216,6 +250,10 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2
   MIXDQ_ARGS_NOW(p.q, p.k, p.v, p.out, p.q_bs, p.q_rs, p.k_bs, p.k_rs, p.v_bs, p.v_rs, p.o_bs, p.o_rs,
                  p.tq, p.tkv, p.heads, p.qblocks);
   MIXDQ_ARGS_NOW(p.scale_log2, p.s_inv, p.zp, p.unfused);
+  if ((int)blockIdx.x >= p.attn_blocks) {        // payload workgroups (dispatched after the attention ones)
+    attn_prefetch_role(p);
+    return;
+  }
   constexpr int NI = 16 / WAVES;                 // LDS-DMA wave-instructions per wave per tile
   constexpr int PRE = STAGES - 1;                // tiles staged ahead of the one whose V is consumed
   static_assert(STAGES >= 3, "tiles t (V) and t+1 (K) are read while t+2.. are in flight");
@@ -607,8 +645,11 @@ constexpr int attn_smem_bytes(int waves, int stages) {
 }
 
 template <int WAVES, int STAGES>
-int launch_attn(const AttnParams& p, int batch, bool quant, hipStream_t stream) {
-  const int grid = p.qblocks * p.heads * batch;
+int launch_attn(AttnParams& p, int batch, bool quant, hipStream_t stream) {
+  p.attn_blocks = p.qblocks * p.heads * batch;
+  if (p.n_pf == 0) p.pf_blocks = 0;
+  if ((long)p.attn_blocks + p.pf_blocks > 0x7fffffffl) return MIXDQ_ERR_INVALID_ARG;
+  const int grid = p.attn_blocks + p.pf_blocks;
   const int smem = attn_smem_bytes(WAVES, STAGES);
   const dim3 g(grid), b(WAVES * 64);
   const bool ragged = (p.tkv & (kKeys - 1)) != 0;   // whole key tiles: no masking code at all
@@ -625,15 +666,17 @@ int launch_attn(const AttnParams& p, int batch, bool quant, hipStream_t stream) 
 
 using namespace mixdq;
 
-extern "C" int mixdq_attention_f16(const void* q, const void* k, const void* v, void* out,
-                                   int batch, int heads, int head_dim, int tq, int tkv,
-                                   int64_t q_batch_stride, int64_t q_row_stride,
-                                   int64_t k_batch_stride, int64_t k_row_stride,
-                                   int64_t v_batch_stride, int64_t v_row_stride,
-                                   int64_t out_batch_stride, int64_t out_row_stride,
-                                   float softmax_scale, const float* out_scale_inv,
-                                   const float* out_zero_point, int flags, mixdq_stream_t stream_) {
+static int attention_f16_impl(const void* q, const void* k, const void* v, void* out,
+                              int batch, int heads, int head_dim, int tq, int tkv,
+                              int64_t q_batch_stride, int64_t q_row_stride,
+                              int64_t k_batch_stride, int64_t k_row_stride,
+                              int64_t v_batch_stride, int64_t v_row_stride,
+                              int64_t out_batch_stride, int64_t out_row_stride,
+                              float softmax_scale, const float* out_scale_inv,
+                              const float* out_zero_point, const void* const* pf_ptrs,
+                              const int64_t* pf_bytes, int n_pf, int flags, mixdq_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
+  if (n_pf < 0 || n_pf > 8 || (n_pf > 0 && (!pf_ptrs || !pf_bytes))) return MIXDQ_ERR_INVALID_ARG;
   if (batch < 0 || heads <= 0 || tq < 0 || tkv <= 0) return MIXDQ_ERR_INVALID_ARG;
   if ((out_scale_inv == nullptr) != (out_zero_point == nullptr)) return MIXDQ_ERR_INVALID_ARG;
   if (head_dim != kHeadDim) return MIXDQ_ERR_SHAPE;
@@ -661,6 +704,21 @@ extern "C" int mixdq_attention_f16(const void* q, const void* k, const void* v, 
   p.scale_log2 = softmax_scale * 1.4426950408889634f;
   p.s_inv = out_scale_inv; p.zp = out_zero_point;
   p.unfused = (flags & MIXDQ_FLAG_UNFUSED) ? 1 : 0;
+  p.attn_blocks = 0; p.pf_blocks = 0; p.n_pf = 0; p.pf_nt = 0;
+  for (int i = 0; i < 8; ++i) { p.pf_ptr[i] = nullptr; p.pf_bytes[i] = 0; }
+  for (int i = 0; i < n_pf; ++i) {
+    if (!pf_ptrs[i] || pf_bytes[i] < 16) continue;
+    if ((uintptr_t)pf_ptrs[i] & 15) return MIXDQ_ERR_ALIGNMENT;
+    p.pf_ptr[p.n_pf] = (const char*)pf_ptrs[i];
+    p.pf_bytes[p.n_pf++] = pf_bytes[i];
+  }
+  if (p.n_pf) {   // one payload workgroup per CU by default (MIXDQ_PREFETCH_BLOCKS / MIXDQ_PREFETCH_NT: A/B runs)
+    static const int blocks = [] { const char* e = getenv("MIXDQ_PREFETCH_BLOCKS"); return e ? atoi(e) : kNumCU; }();
+    static const int nt = [] { const char* e = getenv("MIXDQ_PREFETCH_NT"); return e ? atoi(e) : 0; }();
+    p.pf_blocks = blocks > 0 ? blocks : 0;
+    p.pf_nt = nt;
+    if (p.pf_blocks == 0) p.n_pf = 0;
+  }
 
   // 128-query workgroups (4 waves x 32 rows) when ONE IMAGE has at least half a chip of them,
   // 64-query ones otherwise.  The rule looks at the image alone, never at the batch: both kernels
@@ -681,4 +739,34 @@ extern "C" int mixdq_attention_f16(const void* q, const void* k, const void* v, 
   p.qblocks = big ? (tq + 127) / 128 : (tq + 63) / 64;
   if (big) return launch_attn<4, 4>(p, batch, quant, stream);
   return launch_attn<2, 4>(p, batch, quant, stream);
+}
+
+extern "C" int mixdq_attention_f16(const void* q, const void* k, const void* v, void* out,
+                                   int batch, int heads, int head_dim, int tq, int tkv,
+                                   int64_t q_batch_stride, int64_t q_row_stride,
+                                   int64_t k_batch_stride, int64_t k_row_stride,
+                                   int64_t v_batch_stride, int64_t v_row_stride,
+                                   int64_t out_batch_stride, int64_t out_row_stride,
+                                   float softmax_scale, const float* out_scale_inv,
+                                   const float* out_zero_point, int flags, mixdq_stream_t stream) {
+  return attention_f16_impl(q, k, v, out, batch, heads, head_dim, tq, tkv, q_batch_stride, q_row_stride,
+                            k_batch_stride, k_row_stride, v_batch_stride, v_row_stride, out_batch_stride,
+                            out_row_stride, softmax_scale, out_scale_inv, out_zero_point, nullptr, nullptr,
+                            0, flags, stream);
+}
+
+extern "C" int mixdq_attention_f16_prefetch(const void* q, const void* k, const void* v, void* out,
+                                            int batch, int heads, int head_dim, int tq, int tkv,
+                                            int64_t q_batch_stride, int64_t q_row_stride,
+                                            int64_t k_batch_stride, int64_t k_row_stride,
+                                            int64_t v_batch_stride, int64_t v_row_stride,
+                                            int64_t out_batch_stride, int64_t out_row_stride,
+                                            float softmax_scale, const float* out_scale_inv,
+                                            const float* out_zero_point, const void* const* prefetch_ptrs,
+                                            const int64_t* prefetch_bytes, int n_prefetch, int flags,
+                                            mixdq_stream_t stream) {
+  return attention_f16_impl(q, k, v, out, batch, heads, head_dim, tq, tkv, q_batch_stride, q_row_stride,
+                            k_batch_stride, k_row_stride, v_batch_stride, v_row_stride, out_batch_stride,
+                            out_row_stride, softmax_scale, out_scale_inv, out_zero_point, prefetch_ptrs,
+                            prefetch_bytes, n_prefetch, flags, stream);
 }

@@ -477,7 +477,7 @@ class Attention(nn.Module):
             return out.forward_quantized(o_int, residual=residual)
         return self.attend_out(_run(self.to_q, feed_q), k, v, residual)
 
-    def attend_out(self, q, k, v, residual):
+    def attend_out(self, q, k, v, residual, prefetch=None):
         """residual + to_out[0](attention(q, k, v)) on the fused path: the HIP FP16 attention core
         reads q/k/v in place (column slices of the fused projection included) and, when to_out[0]
         is W8A8, emits its INT8 operand directly; the residual add rides in the GEMM epilogue."""
@@ -490,12 +490,15 @@ class Attention(nn.Module):
         if not ok:
             return _linear_res(out, self.attend(q, k, v), residual)
         if _accel(out) and residual.is_contiguous():
-            o_int = _C.attention_f16(q, k, v, self.heads, *_qp(out))
+            o_int = _C.attention_f16(q, k, v, self.heads, *_qp(out), _prefetch=prefetch)
             return out.forward_quantized(o_int, residual=residual)
-        return _linear_res(out, _C.attention_f16(q, k, v, self.heads), residual)
+        return _linear_res(out, _C.attention_f16(q, k, v, self.heads, _prefetch=prefetch), residual)
 
 
 CROSS_FUSE_MAX_ROWS = int(__import__("os").environ.get("MIXDQ_CROSS_FUSE_MAX_ROWS", "4096"))
+# weight prefetch from the self-attention launch: on for launches of up to this many rows
+PREFETCH = __import__("os").environ.get("MIXDQ_PREFETCH", "1") != "0"
+PREFETCH_MAX_ROWS = int(__import__("os").environ.get("MIXDQ_PREFETCH_MAX_ROWS", "4096"))
 
 
 def _cross_fusable(attn, feed, k, v, residual) -> bool:
@@ -616,10 +619,33 @@ class BasicTransformerBlock(nn.Module):
             pack = self.__dict__["_qkv"] = _pack_rows(layers)
         return pack
 
+    def _weights_behind_attn1(self, rows):
+        """What the self-attention launch prefetches (mixdq_attention_f16_prefetch): the weight operands of
+        the layers that follow it in this block -- attn1.to_out.0, attn2.to_q, attn2.to_out.0, ff.net.0.proj,
+        ff.net.2 -- and the next block's q|k|v.  Small batches only: the weights are read once per launch
+        whatever the batch, and from batch 2 on the attention launch fills the chip."""
+        if not PREFETCH or rows > PREFETCH_MAX_ROWS:
+            return None
+
+        def w(m):          # the operand the layer's kernel reads: packed 4-bit, INT8, or the FP16 fallback's
+            if getattr(m, "w_packed4", False):
+                return getattr(m, "weight_int4", None)
+            t = getattr(m, "weight_int", None)
+            t = t if t is not None else getattr(m, "weight", None)
+            return t if (t is not None and t.is_cuda) else None
+        out = [w(self.attn1.to_out[0]), w(self.attn2.to_q), w(self.attn2.to_out[0]),
+               w(self.ff.net[0].proj), w(self.ff.net[2])]
+        nxt = self.__dict__.get("_next_block")
+        if nxt is not None:
+            pack = nxt.__dict__.get("_qkv")
+            out.append(pack["w"] if pack else w(nxt.attn1.to_q))
+        return [t for t in out if t is not None][:8]
+
     def forward_fused(self, x, context):
         x = x.contiguous()
         a = self.attn1
         pack = self._qkv_fused()
+        pf = self._weights_behind_attn1(x.shape[0] * x.shape[1])
         feeds = _ln_feed(self.norm1, x, [a.to_q, a.to_k, a.to_v])
         if pack is not None and feeds[0][1]:
             from mixdq_amd.op.qlinear import qlinear
@@ -627,10 +653,10 @@ class BasicTransformerBlock(nn.Module):
             qkv = qlinear(feeds[0][0], pack["w"], pack["wscale"], q0.act_scales, q0.act_zero_points,
                           pack["wsum"], pack["scale"], pack["bias0"], None, _w4=pack["w4"])
             C = pack["C"]
-            x = a.attend_out(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], x)
+            x = a.attend_out(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], x, prefetch=pf)
         else:
             fq, fk, fv = feeds                                      # x + attn1(norm1(x))
-            x = a.attend_out(_run(a.to_q, fq), _run(a.to_k, fk), _run(a.to_v, fv), x)
+            x = a.attend_out(_run(a.to_q, fq), _run(a.to_k, fk), _run(a.to_v, fv), x, prefetch=pf)
         a = self.attn2
         (fq,) = _ln_feed(self.norm2, x, [a.to_q])
         kv = self.__dict__.pop("_kv", None)
@@ -654,6 +680,8 @@ class Transformer2DModel(nn.Module):
         self.proj_in = nn.Linear(dim, dim)
         self.transformer_blocks = nn.ModuleList(
             [BasicTransformerBlock(dim, cross_dim, head_dim) for _ in range(depth)])
+        for a, b in zip(self.transformer_blocks[:-1], self.transformer_blocks[1:]):
+            a.__dict__["_next_block"] = b              # (not a submodule: the prefetch list's look-ahead)
         self.proj_out = nn.Linear(dim, dim)
 
     fused = False

@@ -105,6 +105,33 @@ def test_attention_short_key_kernel_is_bit_identical_to_the_pipelined_one(C, B, 
         C.attention_f16(qd, long_k, long_k, heads, _cfg=1)
 
 
+@pytest.mark.parametrize("B,tq,tkv,Cc,cfg", [(1, 1024, 1024, 1280, 0), (2, 256, 256, 192, 4), (1, 320, 704, 128, 2),
+                                             (2, 100, 77, 128, 0)])
+def test_attention_prefetch_payload_changes_nothing(C, B, tq, tkv, Cc, cfg):
+    """mixdq_attention_f16_prefetch: the payload workgroups only READ the given ranges (the weights of the
+    layers behind the attention); the attention result is the plain launch's, bit for bit -- for full and
+    ragged ranges, sizes that are not multiples of 16 bytes or of the payload's stripe, empty and missing
+    ranges, FP16 and INT8 output; the ranges themselves are untouched; more than 8 ranges are refused."""
+    host, _ = make(55, B, tq, tkv, Cc, tq == tkv)
+    qd, kd, vd = device_views(host, tq, tkv, Cc, tq == tkv)
+    heads = Cc // 64
+    want = C.attention_f16(qd, kd, vd, heads, _cfg=cfg)
+    g = torch.Generator(device="cpu").manual_seed(5)
+    ranges = [torch.randint(-128, 128, (n,), generator=g, dtype=torch.int8).to(DEV)
+              for n in (13 * 1024 * 1024 + 7, 4096, 1, 48, 1280 * 1280, 16, 5 * 1024 * 1024 + 16)]
+    ranges += [torch.randn(640, 640, generator=g).half().to(DEV)]                     # an FP16 fallback weight
+    before = [r.clone() for r in ranges]
+    got = C.attention_f16(qd, kd, vd, heads, _cfg=cfg, _prefetch=ranges)
+    assert torch.equal(got, want)
+    assert all(torch.equal(a, b) for a, b in zip(ranges, before))
+    assert torch.equal(C.attention_f16(qd, kd, vd, heads, _cfg=cfg, _prefetch=[None, ranges[0][:0], ranges[4]]), want)
+    s_inv, zp = scal(float(np.float32(1) / np.float32(0.0173))), scal(7.0)
+    assert torch.equal(C.attention_f16(qd, kd, vd, heads, s_inv, zp, _cfg=cfg, _prefetch=ranges[:3]),
+                       C.attention_f16(qd, kd, vd, heads, s_inv, zp, _cfg=cfg))
+    with pytest.raises(RuntimeError):
+        C.attention_f16(qd, kd, vd, heads, _cfg=cfg, _prefetch=ranges + ranges[:1])
+
+
 @pytest.mark.parametrize("case", SMALL, ids=[f"b{c[0]}_q{c[1]}_k{c[2]}_c{c[3]}_{'f' if c[4] else 's'}_w{c[5]}" for c in SMALL])
 def test_attention_vs_oracle(C, oracle, case):
     B, tq, tkv, Cc, fused, cfg = case
