@@ -321,7 +321,7 @@ int mixdq_attention_f16(const void* q_f16, const void* k_f16, const void* v_f16,
                         const float* out_zero_point_or_null, int flags, mixdq_stream_t stream);
 
 /* mixdq_attention_f16 with a PREFETCH payload: beside the attention workgroups the launch carries
- * workgroups that do nothing but read the `n_prefetch` (<= 8) given byte ranges (HOST arrays of device
+ * workgroups that do nothing but read the `n_prefetch` (<= 16) given byte ranges (HOST arrays of device
  * pointers / sizes) -- the INT8 weights of the layers that FOLLOW this attention in the network.  At
  * batch 1 a 1024-token self-attention occupies 62 % of the SIMDs for ~17 us and leaves HBM idle, while
  * every GEMM behind it streams weights that were last touched a step ago (2.6 GB per step: nothing

@@ -137,6 +137,21 @@ def _record(name, M, N, K, k_align, w4, fn, args, kwargs):
     RECORD.append((name, (int(M), int(N), int(K), int(k_align)), bool(w4), replay))
 
 
+# Weight trace (mixdq_amd/unet.py's prefetch planner): when a list, every GEMM / conv entry point appends the
+# weight operand it was called with, and every long-key attention launch a marker -- the execution order of
+# the network's weights relative to its self-attention launches.  Costs one list append per launch.
+TRACE = None
+# Prefetch plan of the running forward (set by mixdq_amd/unet.py around a fused forward): PLAN[i] = the tensors
+# the i-th long-key attention launch of the forward carries as its payload; ATT_INDEX counts those launches.
+PLAN = None
+ATT_INDEX = 0
+
+
+def _trace_w(t):
+    if TRACE is not None and t is not None and t.is_cuda:
+        TRACE.append(t)
+
+
 def _check(cond: bool, msg: str):
     if not cond:
         raise RuntimeError(msg)
@@ -205,6 +220,7 @@ def qlinear_w8_a8_ohalf(input_int8, weight_int8, weight_scale, input_scale, inpu
                         weight_sum_by_input_channels, scale, bias0, bias=None, *,
                         _out=None, _row_map=None, _cfg=0, _residual=None, _residual_div=1,
                         _w4=False):
+    _trace_w(weight_int8)
     _check(input_int8.is_cuda, "Input should be on GPU.")
     dev = input_int8.device
     _check(dev == weight_int8.device, "input and weight_int8 should be on the same device.")
@@ -353,6 +369,7 @@ def qlinear_attention(input_int8, weight_int8, scale, bias0, k, v, scale_inv=Non
     with unit stride along N.  Returns the attention output [B, T, N]: int8 (to_out.0's operand)
     when scale_inv / zero_point are given, else fp16.  Bit-identical to qlinear_w8_a8_ohalf
     followed by attention_f16."""
+    _trace_w(weight_int8)
     _check(input_int8.is_cuda and input_int8.dtype == torch.int8 and input_int8.dim() == 3,
            "input_int8 should be an int8 [B, T, K] GPU tensor")
     _check(weight_int8.dtype == torch.int8, "weight_int8 should be int8 type")
@@ -413,6 +430,7 @@ def qlinear_geglu(input_int8, weight_int8, scale, bias0, bias, out_scale_inv, ou
     """int8 [..., K] x value/gate-interleaved W [2D, K] -> int8 [..., D]: ff.net.0.proj + GEGLU +
     the quantizer of ff.net.2 in one launch (include/mixdq_hip.h: mixdq_qlinear_w8a8_geglu).
     `_out`: a contiguous int8 tensor of the result's size to write into (8-byte aligned)."""
+    _trace_w(weight_int8)
     _check(input_int8.is_cuda and input_int8.dtype == torch.int8, "input_int8 should be int8 on GPU")
     _check(weight_int8.dtype == torch.int8, "weight_int8 should be int8 type")
     N, K = weight_int8.size(0), weight_int8.size(1) * (2 if _w4 else 1)
@@ -472,6 +490,7 @@ def qconv2d_w8_a8_ohalf(input_int8, weight_int8, weight_scale, input_scale, inpu
                         scale, weight_sum_by_input_channels, bias0, bias=None, stride=1,
                         padding=0, dilation=1, *, _table=None, _cfg=0, _residual=None,
                         _residual_per_image=False, _w4=False, _upsample2x=False):
+    _trace_w(weight_int8)
     stride = 1 if stride is None else int(stride)
     padding = 0 if padding is None else int(padding)
     dilation = 1 if dilation is None else int(dilation)
@@ -647,6 +666,7 @@ def linear_f16(input, weight, bias=None, *, _residual=None, _cfg=0):
     """F.linear(input, weight, bias) for fp16 GPU tensors: input [..., K], weight [N, K] -> [..., N],
     FP32 accumulation, bias added in FP32, one rounding to fp16; `_residual` (fp16, the output's
     shape) is added after that rounding as a following torch half add would."""
+    _trace_w(weight)
     _check(input.is_cuda and input.dtype == torch.float16, "input should be an fp16 GPU tensor")
     _check(weight.dtype == torch.float16 and weight.device == input.device and weight.dim() == 2,
            "weight should be an fp16 [N, K] tensor on the input's device")
@@ -673,6 +693,7 @@ def conv2d_f16(input, weight, bias=None, stride=1, padding=0, *, _residual=None,
     """F.conv2d(input, weight, bias, stride, padding) for fp16 GPU tensors (square stride / padding,
     dilation 1, groups 1): input [N, C, H, W] and weight [K, C, R, S] are read in channels-last
     memory (converted if they are not), the result is channels-last [N, K, P, Q]."""
+    _trace_w(weight)
     _check(input.is_cuda and input.dtype == torch.float16 and input.dim() == 4,
            "input should be a 4-D fp16 GPU tensor")
     _check(weight.dtype == torch.float16 and weight.device == input.device and weight.dim() == 4,
@@ -849,7 +870,7 @@ if hasattr(_lib, "mixdq_attention_f16_prefetch"):     # (absent in older builds 
     _lib.mixdq_attention_f16_prefetch.argtypes = [_vp] * 4 + [_i32] * 5 + [_i64] * 8 + [
         ctypes.c_float, _vp, _vp, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64), _i32, _i32, _vp]
     _lib.mixdq_attention_f16_prefetch.restype = _i32
-PREFETCH_MAX_RANGES = 8
+PREFETCH_MAX_RANGES = 16
 
 
 def attention_f16(q, k, v, heads, scale_inv=None, zero_point=None, softmax_scale=None, _cfg=0, _prefetch=None):
@@ -858,7 +879,7 @@ def attention_f16(q, k, v, heads, scale_inv=None, zero_point=None, softmax_scale
     q [B, Tq, C], k/v [B, Tkv, C] fp16 with unit stride along C (column slices of a fused projection
     are read in place); C = heads * 64.  Returns fp16 [B, Tq, C], or — when `scale_inv`/`zero_point`
     (to_out.0's activation quantizer) are given — its int8 quantization.
-    `_prefetch`: up to 8 GPU tensors (the weights of the layers behind this attention) that payload
+    `_prefetch`: up to 16 GPU tensors (the weights of the layers behind this attention) that payload
     workgroups of the launch read while the attention runs (mixdq_attention_f16_prefetch); no effect
     on the result.
     """
@@ -875,8 +896,15 @@ def attention_f16(q, k, v, heads, scale_inv=None, zero_point=None, softmax_scale
                                    softmax_scale=softmax_scale, _cfg=_cfg))     # (measured without the payload)
     out = torch.empty((B, Tq, C), dtype=torch.int8 if quant else torch.float16, device=q.device)
     sc = float(softmax_scale) if softmax_scale is not None else 0.125
+    if k.shape[1] > 128:                                    # a launch that can carry a prefetch payload
+        global ATT_INDEX
+        if TRACE is not None:
+            TRACE.append(("attn", B * Tq, k.shape[1]))
+        if _prefetch is None and PLAN is not None and ATT_INDEX < len(PLAN):
+            _prefetch = PLAN[ATT_INDEX]
+        ATT_INDEX += 1
     pf = [t for t in (_prefetch or ()) if t is not None and t.is_cuda and t.numel() > 0]
-    _check(len(pf) <= PREFETCH_MAX_RANGES, "at most 8 prefetch ranges")
+    _check(len(pf) <= PREFETCH_MAX_RANGES, "at most 16 prefetch ranges")
     with torch.cuda.device(q.device):
         if pf and hasattr(_lib, "mixdq_attention_f16_prefetch"):
             ptrs = (ctypes.c_void_p * len(pf))(*[t.data_ptr() for t in pf])

@@ -42,8 +42,8 @@ struct AttnParams {
   // prefetch payload (mixdq_attention_f16_prefetch): workgroups attn_blocks .. attn_blocks + pf_blocks - 1
   // read these byte ranges and do nothing else
   int attn_blocks, pf_blocks, n_pf, pf_nt;
-  const char* pf_ptr[8];
-  long pf_bytes[8];
+  const char* pf_ptr[16];
+  long pf_bytes[16];
 };
 
 // The prefetch role: every thread reads 16 bytes per step, a workgroup 4 KB, the payload workgroups
@@ -676,7 +676,7 @@ static int attention_f16_impl(const void* q, const void* k, const void* v, void*
                               const float* out_zero_point, const void* const* pf_ptrs,
                               const int64_t* pf_bytes, int n_pf, int flags, mixdq_stream_t stream_) {
   hipStream_t stream = (hipStream_t)stream_;
-  if (n_pf < 0 || n_pf > 8 || (n_pf > 0 && (!pf_ptrs || !pf_bytes))) return MIXDQ_ERR_INVALID_ARG;
+  if (n_pf < 0 || n_pf > 16 || (n_pf > 0 && (!pf_ptrs || !pf_bytes))) return MIXDQ_ERR_INVALID_ARG;
   if (batch < 0 || heads <= 0 || tq < 0 || tkv <= 0) return MIXDQ_ERR_INVALID_ARG;
   if ((out_scale_inv == nullptr) != (out_zero_point == nullptr)) return MIXDQ_ERR_INVALID_ARG;
   if (head_dim != kHeadDim) return MIXDQ_ERR_SHAPE;
@@ -705,7 +705,7 @@ static int attention_f16_impl(const void* q, const void* k, const void* v, void*
   p.s_inv = out_scale_inv; p.zp = out_zero_point;
   p.unfused = (flags & MIXDQ_FLAG_UNFUSED) ? 1 : 0;
   p.attn_blocks = 0; p.pf_blocks = 0; p.n_pf = 0; p.pf_nt = 0;
-  for (int i = 0; i < 8; ++i) { p.pf_ptr[i] = nullptr; p.pf_bytes[i] = 0; }
+  for (int i = 0; i < 16; ++i) { p.pf_ptr[i] = nullptr; p.pf_bytes[i] = 0; }
   for (int i = 0; i < n_pf; ++i) {
     if (!pf_ptrs[i] || pf_bytes[i] < 16) continue;
     if ((uintptr_t)pf_ptrs[i] & 15) return MIXDQ_ERR_ALIGNMENT;

@@ -499,6 +499,62 @@ CROSS_FUSE_MAX_ROWS = int(__import__("os").environ.get("MIXDQ_CROSS_FUSE_MAX_ROW
 # weight prefetch from the self-attention launch: on for launches of up to this many rows
 PREFETCH = __import__("os").environ.get("MIXDQ_PREFETCH", "1") != "0"
 PREFETCH_MAX_ROWS = int(__import__("os").environ.get("MIXDQ_PREFETCH_MAX_ROWS", "4096"))
+PREFETCH_MB_PER_LAUNCH = float(__import__("os").environ.get("MIXDQ_PREFETCH_MB", "48"))   # per 1024 x 1024 scores
+PREFETCH_MAX_LEAD = int(__import__("os").environ.get("MIXDQ_PREFETCH_LEAD", "4"))         # launches a weight may be read ahead
+
+
+def _build_prefetch_plan(trace):
+    """Which weights does each self-attention launch of a forward read ahead (mixdq_attention_f16_prefetch)?
+    `trace` (mixdq_amd._C.TRACE) is the forward's execution order: weight operands as the GEMM / conv entry
+    points saw them, and a marker (rows, keys) per long-key attention launch.  Launch j is given the weights
+    used between it and launch j + 1 -- the rest of its transformer block, the next block's q|k|v; at the
+    end of a Transformer2DModel also proj_out, the ResNet convs, shortcuts and samplers up to the next
+    transformer -- up to a byte budget proportional to the launch's own work (it should not outlast the
+    attention) and 16 ranges; what does not fit is offered to launch j - 1, ... j - PREFETCH_MAX_LEAD behind
+    THEIR own intervals (read earlier still: the 256 MB Infinity Cache keeps a few hundred microseconds of
+    the step's weight stream, not more -- an unbounded cascade measured slower than no look-back at all),
+    and stays cold if none of them has room.  Launches of more
+    than PREFETCH_MAX_ROWS rows get nothing: from batch 2 on the attention launch fills the chip and each
+    weight byte is amortised over more rows anyway.  Weights used before the first attention launch have
+    no host and stay cold."""
+    marks = [(i, it) for i, it in enumerate(trace) if isinstance(it, tuple)]
+    if not marks:
+        return None
+    lists = [[] for _ in marks]
+    carry = []                                       # (tensor, launches it has been moved back)
+    nbytes = lambda t: t.numel() * t.element_size()  # noqa: E731
+    for j in range(len(marks) - 1, -1, -1):
+        lo = marks[j][0] + 1
+        hi = marks[j + 1][0] if j + 1 < len(marks) else len(trace)
+        own, seen = [], set()
+        for t in trace[lo:hi]:
+            if isinstance(t, tuple) or t.data_ptr() in seen or nbytes(t) < (64 << 10):
+                continue
+            seen.add(t.data_ptr())
+            own.append(t)
+        _, rows, keys = marks[j][1]
+        budget = 0 if rows > PREFETCH_MAX_ROWS else PREFETCH_MB_PER_LAUNCH * 1e6 * rows * keys / float(1 << 20)
+        budget = min(budget, 160e6)
+        new_carry, blocked = [], False
+        for t in own:                                # the launch's own interval first, in order
+            if not blocked and nbytes(t) <= budget and len(lists[j]) < 16:
+                lists[j].append(t)
+                budget -= nbytes(t)
+            else:
+                blocked = True
+                new_carry.append((t, 1))
+        for t, d in carry:                           # then what later launches could not take
+            if t.data_ptr() in seen:
+                continue
+            seen.add(t.data_ptr())
+            if nbytes(t) <= budget and len(lists[j]) < 16:
+                lists[j].append(t)
+                budget -= nbytes(t)
+            elif d < PREFETCH_MAX_LEAD:
+                new_carry.append((t, d + 1))         # else: stays cold
+        carry = new_carry
+    sig = tuple(it if isinstance(it, tuple) else it.data_ptr() for it in trace)
+    return {"lists": lists, "sig": sig}
 
 
 def _cross_fusable(attn, feed, k, v, residual) -> bool:
@@ -619,33 +675,10 @@ class BasicTransformerBlock(nn.Module):
             pack = self.__dict__["_qkv"] = _pack_rows(layers)
         return pack
 
-    def _weights_behind_attn1(self, rows):
-        """What the self-attention launch prefetches (mixdq_attention_f16_prefetch): the weight operands of
-        the layers that follow it in this block -- attn1.to_out.0, attn2.to_q, attn2.to_out.0, ff.net.0.proj,
-        ff.net.2 -- and the next block's q|k|v.  Small batches only: the weights are read once per launch
-        whatever the batch, and from batch 2 on the attention launch fills the chip."""
-        if not PREFETCH or rows > PREFETCH_MAX_ROWS:
-            return None
-
-        def w(m):          # the operand the layer's kernel reads: packed 4-bit, INT8, or the FP16 fallback's
-            if getattr(m, "w_packed4", False):
-                return getattr(m, "weight_int4", None)
-            t = getattr(m, "weight_int", None)
-            t = t if t is not None else getattr(m, "weight", None)
-            return t if (t is not None and t.is_cuda) else None
-        out = [w(self.attn1.to_out[0]), w(self.attn2.to_q), w(self.attn2.to_out[0]),
-               w(self.ff.net[0].proj), w(self.ff.net[2])]
-        nxt = self.__dict__.get("_next_block")
-        if nxt is not None:
-            pack = nxt.__dict__.get("_qkv")
-            out.append(pack["w"] if pack else w(nxt.attn1.to_q))
-        return [t for t in out if t is not None][:8]
-
     def forward_fused(self, x, context):
         x = x.contiguous()
         a = self.attn1
         pack = self._qkv_fused()
-        pf = self._weights_behind_attn1(x.shape[0] * x.shape[1])
         feeds = _ln_feed(self.norm1, x, [a.to_q, a.to_k, a.to_v])
         if pack is not None and feeds[0][1]:
             from mixdq_amd.op.qlinear import qlinear
@@ -653,10 +686,10 @@ class BasicTransformerBlock(nn.Module):
             qkv = qlinear(feeds[0][0], pack["w"], pack["wscale"], q0.act_scales, q0.act_zero_points,
                           pack["wsum"], pack["scale"], pack["bias0"], None, _w4=pack["w4"])
             C = pack["C"]
-            x = a.attend_out(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], x, prefetch=pf)
+            x = a.attend_out(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], x)
         else:
             fq, fk, fv = feeds                                      # x + attn1(norm1(x))
-            x = a.attend_out(_run(a.to_q, fq), _run(a.to_k, fk), _run(a.to_v, fv), x, prefetch=pf)
+            x = a.attend_out(_run(a.to_q, fq), _run(a.to_k, fk), _run(a.to_v, fv), x)
         a = self.attn2
         (fq,) = _ln_feed(self.norm2, x, [a.to_q])
         kv = self.__dict__.pop("_kv", None)
@@ -680,8 +713,6 @@ class Transformer2DModel(nn.Module):
         self.proj_in = nn.Linear(dim, dim)
         self.transformer_blocks = nn.ModuleList(
             [BasicTransformerBlock(dim, cross_dim, head_dim) for _ in range(depth)])
-        for a, b in zip(self.transformer_blocks[:-1], self.transformer_blocks[1:]):
-            a.__dict__["_next_block"] = b              # (not a submodule: the prefetch list's look-ahead)
         self.proj_out = nn.Linear(dim, dim)
 
     fused = False
@@ -1088,6 +1119,22 @@ class SDXLUNet(nn.Module):
         add = torch.cat([text_embeds, tid.reshape(B, -1).to(dtype)], dim=-1)
         emb = emb + self.add_embedding(add)
 
+        use_pf = bool(self.fused and PREFETCH and sample.is_cuda and _fusable_f16(sample) and not DEFUSE)
+        if use_pf:                                  # trace this forward's weight order; replay the last plan
+            from mixdq_amd import _C
+            plan = self.__dict__.get("_pf_plan")
+            _C.TRACE, _C.ATT_INDEX = [], 0
+            _C.PLAN = plan["lists"] if plan else None
+        try:
+            return self._forward_body(sample, emb, encoder_hidden_states)
+        finally:
+            if use_pf:
+                trace, _C.TRACE, _C.PLAN = _C.TRACE, None, None
+                sig = tuple(it if isinstance(it, tuple) else it.data_ptr() for it in trace)
+                if plan is None or plan["sig"] != sig:       # first forward, or the layers changed
+                    self.__dict__["_pf_plan"] = _build_prefetch_plan(trace)
+
+    def _forward_body(self, sample, emb, encoder_hidden_states):
         if self.fused and _fusable_f16(sample) and not DEFUSE:
             self._project_temb_ahead(emb)
             self._project_context_ahead(encoder_hidden_states)
