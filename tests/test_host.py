@@ -568,3 +568,34 @@ def test_geglu_row_order_is_value_gate_groups_of_16():
         assert blk[16:] == list(range(D + 16 * grp, D + 16 * grp + 16))
     inv = torch.argsort(torch.tensor(perm))
     assert torch.equal(torch.tensor(perm)[inv], torch.arange(2 * D))
+
+
+def test_prefetch_plan_own_interval_first_bounded_look_back_and_row_limit():
+    """mixdq_amd.unet._build_prefetch_plan: launch j reads ahead the weights used between
+    it and launch j + 1, in order, within its byte budget; what does not fit is offered to at most
+    PREFETCH_MAX_LEAD earlier launches behind their own intervals, then dropped; launches over the row limit
+    carry nothing; weights before the first launch have no host; small tensors and repeats are skipped."""
+    from mixdq_amd import unet as U
+
+    def w(mb):
+        return torch.empty(int(mb * 1e6), dtype=torch.int8)
+    a = ("attn", 1024, 1024)                                     # budget = PREFETCH_MB_PER_LAUNCH (48 MB)
+    early, w1, w2, w3, big, small, tail = w(5), w(20), w(20), w(20), w(60), w(0.01), w(10)
+    trace = [early, a, w1, small, a, w2, w3, w1, a, big, tail]
+    plan = U._build_prefetch_plan(trace)
+    ptrs = [[t.data_ptr() for t in lst] for lst in plan["lists"]]
+    assert ptrs[2] == []                                         # 60 MB does not fit; `tail` may not overtake it
+    assert ptrs[1] == [w2.data_ptr(), w3.data_ptr()]             # own interval (w1 repeated: once), 40 of 48 MB; ...
+    assert ptrs[0] == [w1.data_ptr(), tail.data_ptr()]           # ... `tail` (10 MB) moves back behind w1; big is dropped
+    assert all(early.data_ptr() not in p and small.data_ptr() not in p and big.data_ptr() not in p for p in ptrs)
+    assert plan["sig"] == tuple(it if isinstance(it, tuple) else it.data_ptr() for it in trace)
+    over = ("attn", U.PREFETCH_MAX_ROWS * 2, 1024)
+    assert U._build_prefetch_plan([over, w1, over, w2])["lists"] == [[], []]
+    assert U._build_prefetch_plan([w1, w2]) is None              # no attention launch: no plan
+    lead = U.PREFETCH_MAX_LEAD
+    chain = []
+    for _ in range(lead + 2):
+        chain += [a, w(40)]                                      # every launch is full with its own 40 MB ...
+    last = w(30)
+    plan = U._build_prefetch_plan(chain + [last])                # ... so a 30 MB tensor behind the last finds no room
+    assert all(last.data_ptr() not in [t.data_ptr() for t in lst] for lst in plan["lists"])
