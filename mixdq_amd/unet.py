@@ -501,6 +501,7 @@ PREFETCH = __import__("os").environ.get("MIXDQ_PREFETCH", "1") != "0"
 PREFETCH_MAX_ROWS = int(__import__("os").environ.get("MIXDQ_PREFETCH_MAX_ROWS", "4096"))
 PREFETCH_MB_PER_LAUNCH = float(__import__("os").environ.get("MIXDQ_PREFETCH_MB", "48"))   # per 1024 x 1024 scores
 PREFETCH_MAX_LEAD = int(__import__("os").environ.get("MIXDQ_PREFETCH_LEAD", "4"))         # launches a weight may be read ahead
+PREFETCH_SKIP_MB = float(__import__("os").environ.get("MIXDQ_PREFETCH_SKIP_MB", "0"))       # experiment: leave tensors above this cold (0: off)
 
 
 def _build_prefetch_plan(trace):
@@ -529,6 +530,8 @@ def _build_prefetch_plan(trace):
         own, seen = [], set()
         for t in trace[lo:hi]:
             if isinstance(t, tuple) or t.data_ptr() in seen or nbytes(t) < (64 << 10):
+                continue
+            if PREFETCH_SKIP_MB and nbytes(t) > PREFETCH_SKIP_MB * 1e6:
                 continue
             seen.add(t.data_ptr())
             own.append(t)
