@@ -498,7 +498,7 @@ class Attention(nn.Module):
 CROSS_FUSE_MAX_ROWS = int(__import__("os").environ.get("MIXDQ_CROSS_FUSE_MAX_ROWS", "4096"))
 # weight prefetch from the self-attention launch: on for launches of up to this many rows
 PREFETCH = __import__("os").environ.get("MIXDQ_PREFETCH", "1") != "0"
-PREFETCH_MAX_ROWS = int(__import__("os").environ.get("MIXDQ_PREFETCH_MAX_ROWS", "4096"))
+PREFETCH_MAX_ROWS = int(__import__("os").environ.get("MIXDQ_PREFETCH_MAX_ROWS", "0"))      # 0: no limit (see _build_prefetch_plan)
 PREFETCH_MB_PER_LAUNCH = float(__import__("os").environ.get("MIXDQ_PREFETCH_MB", "48"))   # per 1024 x 1024 scores
 PREFETCH_MAX_LEAD = int(__import__("os").environ.get("MIXDQ_PREFETCH_LEAD", "4"))         # launches a weight may be read ahead
 PREFETCH_SKIP_MB = float(__import__("os").environ.get("MIXDQ_PREFETCH_SKIP_MB", "0"))       # experiment: leave tensors above this cold (0: off)
@@ -514,10 +514,11 @@ def _build_prefetch_plan(trace):
     attention) and 16 ranges; what does not fit is offered to launch j - 1, ... j - PREFETCH_MAX_LEAD behind
     THEIR own intervals (read earlier still: the 256 MB Infinity Cache keeps a few hundred microseconds of
     the step's weight stream, not more -- an unbounded cascade measured slower than no look-back at all),
-    and stays cold if none of them has room.  Launches of more
-    than PREFETCH_MAX_ROWS rows get nothing: from batch 2 on the attention launch fills the chip and each
-    weight byte is amortised over more rows anyway.  Weights used before the first attention launch have
-    no host and stay cold."""
+    and stays cold if none of them has room.  MIXDQ_PREFETCH_MAX_ROWS (default 0: off) leaves launches of more
+    rows without a payload: from batch 2 on the attention launch fills the chip, so its payload workgroups run in
+    the launch's tail and lengthen it -- measured, the weights they leave in the cache are still worth more
+    (batch 8: 48.65 -> 47.98 ms, batch 2: 17.17 -> 16.98, batch 4: 27.73 -> 27.60; 4096 was the first default).
+    Weights used before the first attention launch have no host and stay cold."""
     marks = [(i, it) for i, it in enumerate(trace) if isinstance(it, tuple)]
     if not marks:
         return None
@@ -536,7 +537,8 @@ def _build_prefetch_plan(trace):
             seen.add(t.data_ptr())
             own.append(t)
         _, rows, keys = marks[j][1]
-        budget = 0 if rows > PREFETCH_MAX_ROWS else PREFETCH_MB_PER_LAUNCH * 1e6 * rows * keys / float(1 << 20)
+        budget = (0 if PREFETCH_MAX_ROWS and rows > PREFETCH_MAX_ROWS
+                  else PREFETCH_MB_PER_LAUNCH * 1e6 * rows * keys / float(1 << 20))
         budget = min(budget, 160e6)
         new_carry, blocked = [], False
         for t in own:                                # the launch's own interval first, in order

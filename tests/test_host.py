@@ -589,8 +589,12 @@ def test_prefetch_plan_own_interval_first_bounded_look_back_and_row_limit():
     assert ptrs[0] == [w1.data_ptr(), tail.data_ptr()]           # ... `tail` (10 MB) moves back behind w1; big is dropped
     assert all(early.data_ptr() not in p and small.data_ptr() not in p and big.data_ptr() not in p for p in ptrs)
     assert plan["sig"] == tuple(it if isinstance(it, tuple) else it.data_ptr() for it in trace)
-    over = ("attn", U.PREFETCH_MAX_ROWS * 2, 1024)
-    assert U._build_prefetch_plan([over, w1, over, w2])["lists"] == [[], []]
+    saved, U.PREFETCH_MAX_ROWS = U.PREFETCH_MAX_ROWS, 4096                   # the optional row limit
+    try:
+        over = ("attn", 8192, 1024)
+        assert U._build_prefetch_plan([over, w1, over, w2])["lists"] == [[], []]
+    finally:
+        U.PREFETCH_MAX_ROWS = saved
     assert U._build_prefetch_plan([w1, w2]) is None              # no attention launch: no plan
     lead = U.PREFETCH_MAX_LEAD
     chain = []
