@@ -72,7 +72,9 @@ enum mixdq_flags {
      the upsampled tensor (quantizing commutes with nearest upsampling: the INT8 values are the same).
      3x3 / stride 1 / pad 1 shapes of the LDS-halo kernel only (mixdq_conv_halo_select != 0), else
      MIXDQ_ERR_SHAPE.  No reference counterpart. */
-  MIXDQ_FLAG_UPSAMPLE2X = 4
+  MIXDQ_FLAG_UPSAMPLE2X = 4,
+  /* mixdq_qlinear_f16in_w8a8 only: the FP16 operand's rows follow the output row map (see there). */
+  MIXDQ_FLAG_A_ROWMAP = 8
   /* bits 8..15: force a kernel configuration id (tuning / tests); 0 = automatic */
 };
 
@@ -130,6 +132,38 @@ int mixdq_qlinear_w8a8_rows(const int8_t* A, const int8_t* W,
                             int group_rows, int group_stride, int group_offset,
                             const void* residual_f16_or_null, int64_t residual_row_div,
                             int flags, mixdq_stream_t stream);
+
+/* a1 + a2 in ONE launch: the GEMM quantizes its own activation operand ("A8 quant fused into INT8 GEMM").
+ * Replaces the reference's pair of launches per layer -- quant_op(x, act_scales_inv, act_zero_points) followed
+ * by qlinear (nn/Linear.py:162-176); 1x1 / pad-0 convs on NHWC rows too (nn/Conv2d.py:294-311) -- with results
+ * bit-identical to mixdq_quantize_f16_i8 -> mixdq_qlinear_w8a8_rows:
+ *   A_q[m,k] = (int8) clamp(rint(fma(f32(A[m * lda + k]), *act_scale_inv, *act_zero_point)), -128, 127)
+ *   D        = the a2 epilogue over A_q (row map, residual and MIXDQ_FLAG_W4 / _UNFUSED as above).
+ * A_f16: FP16, row m at element offset m * lda (lda >= K, lda % 8 == 0, 16-byte aligned base: a dense
+ * [M, K] matrix, or a column slice x[:, c0:c0+K] of a wider row-major / NHWC tensor).  MIXDQ_FLAG_A_ROWMAP:
+ * the operand's row m is row (m / group_rows) * group_stride + group_offset + m % group_rows of A_f16 --
+ * the same map as the output's, i.e. the BOS slice x[:, 1:, :] of a [B, T, K] tensor read in place.
+ * Range: K a multiple of the chosen tile's K depth (128; 64 on the 128x128 / 256x128 tiles), operands
+ * 16-byte aligned, the FP16 operand below 4 GiB; MIXDQ_ERR_SHAPE otherwise (the caller then issues the
+ * two launches).  mixdq_qlinear_f16in_supported() answers that question without launching. */
+int mixdq_qlinear_f16in_w8a8(const void* A_f16, int64_t lda,
+                             const float* act_scale_inv, const float* act_zero_point,
+                             const int8_t* W, const float* bias0, const float* scale,
+                             const void* bias_f16_or_null, void* D_f16,
+                             int64_t M, int N, int K,
+                             int group_rows, int group_stride, int group_offset,
+                             const void* residual_f16_or_null, int64_t residual_row_div,
+                             int flags, mixdq_stream_t stream);
+/* 1 if mixdq_qlinear_f16in_w8a8 takes this problem (sizes only; pointers must still be 16-byte aligned),
+ * else 0.  `rows_addressed`: rows of A_f16 the operand spans (M, or the mapped extent under a row map). */
+int mixdq_qlinear_f16in_supported(int64_t M, int N, int K, int64_t lda, int64_t rows_addressed, int w4);
+/* 1 if the one launch is expected to be cheaper than mixdq_quantize_f16_i8 + mixdq_qlinear_w8a8_rows for this
+ * problem (a cost model fitted to MI355X measurements, csrc/igemm_aq.hip): every workgroup quantizes the rows of
+ * its own tile, so wide layers at small M repeat the quantizer's arithmetic N / BN times and lose to the
+ * stand-alone kernel.  mixdq_amd's modules fuse where this says 1 (MIXDQ_F16IN=1: wherever supported; 0: never). */
+int mixdq_qlinear_f16in_preferred(int64_t M, int N, int K, int w4);
+/* Configuration id (MIXDQ_IGEMM_CONFIGS) the automatic choice makes for such a launch; -1 = unsupported. */
+int mixdq_qlinear_f16in_select_id(int64_t M, int N, int K, int w4);
 
 /* ---------------------------------------------------------------------------------------------
  * a3 + a4. INT8 NHWC implicit-GEMM conv2d (cross-correlation) with the same epilogue, and the

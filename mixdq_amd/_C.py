@@ -286,6 +286,141 @@ def qlinear_w8_a8_ohalf(input_int8, weight_int8, weight_scale, input_scale, inpu
     return D
 
 
+_lib.mixdq_qlinear_f16in_w8a8.argtypes = [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32,
+                                         _i32, _i32, _i32, _vp, _i64, _i32, _vp]
+_lib.mixdq_qlinear_f16in_w8a8.restype = _i32
+_lib.mixdq_qlinear_f16in_supported.argtypes = [_i64, _i32, _i32, _i64, _i64, _i32]
+_lib.mixdq_qlinear_f16in_supported.restype = _i32
+_lib.mixdq_qlinear_f16in_select_id.argtypes = [_i64, _i32, _i32, _i32]
+_lib.mixdq_qlinear_f16in_select_id.restype = _i32
+_lib.mixdq_qlinear_f16in_preferred.argtypes = [_i64, _i32, _i32, _i32]
+_lib.mixdq_qlinear_f16in_preferred.restype = _i32
+
+FLAG_A_ROWMAP = 8   # MIXDQ_FLAG_A_ROWMAP: the FP16 operand's rows follow the output row map
+
+# Quantize-in-prologue (csrc/igemm_aq.hip): QuantizedLinear / 1x1 QuantizedConv2d hand their FP16 input
+# straight to a GEMM that quantizes it in its staging path -- one launch where the reference has two
+# (nn/Linear.py:162-176).  MIXDQ_F16IN=0 restores the reference's quantize launch (A/B runs, tests).
+# "auto" (default): where the library's cost model expects the one launch to be cheaper
+# (mixdq_qlinear_f16in_preferred: narrow layers -- the 1x1 shortcuts, K <= 640); "1": wherever supported.
+F16IN = os.environ.get("MIXDQ_F16IN", "auto").lower()
+F16IN = {"0": "0", "off": "0", "1": "1", "on": "1"}.get(F16IN, "auto")
+# Tile configurations the quantizing family is built for (csrc/igemm_aq.hip MIXDQ_AQ_CONFIGS)
+F16IN_CONFIGS = (4, 13, 27, 28, 35, 37, 41, 44, 45, 56)
+
+
+def _rows_view(x: torch.Tensor, K: int):
+    """(M, lda, leading shape) if `x` [..., K] can be read in place as M rows of K contiguous FP16 values
+    a constant `lda` elements apart (a dense tensor, or a last-dimension slice of one), else None."""
+    if x.dim() == 0 or x.size(-1) != K or (K > 1 and x.stride(-1) != 1):
+        return None
+    lead = list(x.shape[:-1])
+    M = 1
+    for d in lead:
+        M *= d
+    if M == 0:
+        return None
+    lda = None
+    expect = None                      # stride the next-outer dimension must have
+    for size, stride in zip(reversed(lead), reversed(x.stride()[:-1])):
+        if size == 1:
+            continue
+        if lda is None:
+            lda, expect = stride, stride * size
+        elif stride != expect:
+            return None
+        else:
+            expect = stride * size
+    if lda is None:
+        lda = K
+    return M, lda, lead
+
+
+def qlinear_f16in_supported(x: torch.Tensor, N: int, K: int, *, w4: bool = False, bos: bool = False) -> bool:
+    """True if qlinear_f16in takes `x` (fp16 [..., K]; bos: [B, T, K] whose tokens 1.. are the operand)."""
+    if not (x.is_cuda and x.dtype == torch.float16 and x.data_ptr() % 16 == 0):
+        return False
+    if bos:
+        if x.dim() != 3 or not x.is_contiguous() or x.size(1) < 2:
+            return False
+        B, T = x.size(0), x.size(1)
+        return bool(_lib.mixdq_qlinear_f16in_supported(B * (T - 1), N, K, K, B * T, int(w4)))
+    v = _rows_view(x, K)
+    if v is None:
+        return False
+    M, lda, _ = v
+    return bool(_lib.mixdq_qlinear_f16in_supported(M, N, K, lda, M, int(w4)))
+
+
+def qlinear_f16in_wanted(x: torch.Tensor, N: int, K: int, *, w4: bool = False, bos: bool = False) -> bool:
+    """What the modules ask: fuse this layer's quantize into its GEMM?  Supported, and -- under the default
+    MIXDQ_F16IN=auto -- expected to be cheaper than the two launches (mixdq_qlinear_f16in_preferred)."""
+    if F16IN == "0" or not qlinear_f16in_supported(x, N, K, w4=w4, bos=bos):
+        return False
+    if F16IN == "1":
+        return True
+    M = x.size(0) * (x.size(1) - 1) if bos else x.numel() // K
+    return bool(_lib.mixdq_qlinear_f16in_preferred(M, N, K, int(w4)))
+
+
+def qlinear_f16in(input_f16, scale_inv, zero_point, weight_int8, scale, bias0, bias=None, *,
+                  _out=None, _bos=False, _cfg=0, _residual=None, _residual_div=1, _w4=False):
+    """quantize_per_tensor_to_int8(input, scale_inv, zero_point) -> qlinear_w8_a8_ohalf(...) in ONE launch
+    (bit-identical to the pair).  `input_f16`: fp16 [..., K] readable in place as rows a constant stride
+    apart; `_bos`: input is [B, T, K] and tokens 1.. are the operand, written to rows 1.. of `_out`
+    [B, T, N] (QuantizedLinear's BOS path).  Raises where qlinear_f16in_supported() is False."""
+    _trace_w(weight_int8)
+    _check(input_f16.is_cuda and input_f16.dtype == torch.float16, "input should be fp16 on GPU")
+    dev = input_f16.device
+    for t, nm in ((scale_inv, "scale_inv"), (zero_point, "zero_point"), (weight_int8, "weight_int8"),
+                  (scale, "scale"), (bias0, "bias0")):
+        _check(t.device == dev, f"input and {nm} should be on the same device.")
+    _check(scale_inv.dtype == torch.float32 and zero_point.dtype == torch.float32,
+           "scale_inv and zero_point should be fp32")
+    _check(weight_int8.dtype == torch.int8, "weight_int8 should be int8 type")
+    _check(scale.dtype == torch.float32 and bias0.dtype == torch.float32,
+           "scale and bias0 should be float32")
+    N, K = weight_int8.size(0), weight_int8.size(1) * (2 if _w4 else 1)
+    _check(scale.numel() == N and bias0.numel() == N,
+           "The size of scale and bias0 should be equal to output_channels.")
+    if bias is not None:
+        _check(bias.dtype == torch.float16 and bias.numel() == N and bias.device == dev,
+               "bias should be fp16 of output_channels on the input's device")
+    _check(input_f16.size(-1) == K,
+           f"The last dimension of input and weight should match, got {input_f16.size(-1)} and {K}.")
+    if _bos:
+        _check(input_f16.dim() == 3 and input_f16.is_contiguous() and input_f16.size(1) >= 2,
+               "BOS input should be a contiguous [B, T, K] tensor with T >= 2")
+        B, T = input_f16.size(0), input_f16.size(1)
+        M, lda, rm, flags = B * (T - 1), K, (T - 1, T, 1), FLAG_A_ROWMAP
+        D = _out if _out is not None else torch.empty((B, T, N), dtype=torch.float16, device=dev)
+    else:
+        v = _rows_view(input_f16, K)
+        _check(v is not None, "input rows should be a constant stride apart")
+        M, lda, lead = v
+        rm, flags = (0, 0, 0), 0
+        D = _out if _out is not None else torch.empty(lead + [N], dtype=torch.float16, device=dev)
+    w = weight_int8.contiguous()
+    sc, b0 = _f32vec(scale), _f32vec(bias0)
+    bs = None if bias is None else bias.contiguous()
+    if _residual is not None:
+        _check(_residual.dtype == torch.float16 and _residual.is_contiguous()
+               and _residual.numel() == (M // _residual_div) * N,
+               "residual should be contiguous fp16 of M / residual_div rows")
+    _record("linear_f16in", M, N, K, K, _w4, qlinear_f16in,
+            (input_f16, scale_inv, zero_point, weight_int8, scale, bias0, bias),
+            dict(_out=_out, _bos=_bos, _cfg=_cfg, _residual=_residual, _residual_div=_residual_div,
+                 _w4=_w4))
+    with torch.cuda.device(dev):
+        code = _lib.mixdq_qlinear_f16in_w8a8(
+            input_f16.data_ptr(), lda, scale_inv.data_ptr(), zero_point.data_ptr(), w.data_ptr(),
+            b0.data_ptr(), sc.data_ptr(), _ptr(bs), D.data_ptr(), M, N, K, rm[0], rm[1], rm[2],
+            _ptr(_residual), _residual_div,
+            FLAGS | flags | (_cfg << 8) | (FLAG_W4 if _w4 else 0), _stream())
+    _status(code, "qlinear_f16in")
+    return D
+
+
 _lib.mixdq_qlinear_w8a8_grouped.argtypes = [_vp, _vp, _i32, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp]
 _lib.mixdq_qlinear_w8a8_grouped.restype = _i32
 

@@ -274,10 +274,8 @@ class QuantizedConv2d(nn.Module):
         """forward(cat([x_a, x_b], dim=1)) of a split layer (x_a has `split` channels) without the
         concatenation: each half is quantized with its own activation quantizer where it lies."""
         assert self.valid_for_acceleration and self.split == x_a.shape[1]
-        x_int = quant_op(x_a, self.act_scales_inv, self.act_zero_points)
-        x_int_0 = quant_op(x_b, self.act_scales_inv_0, self.act_zero_points_0)
-        first = self._conv(x_int, "", self.bias)
-        return self._conv(x_int_0, "_0", None, residual=first)
+        first = self._quant_conv(x_a, "", self.bias)
+        return self._quant_conv(x_b, "_0", None, residual=first)
 
     def forward_parts_quantized(self, x_int: torch.Tensor, x_int_0: torch.Tensor) -> torch.Tensor:
         """forward_parts for halves already quantized with this layer's two activation quantizers
@@ -286,18 +284,48 @@ class QuantizedConv2d(nn.Module):
         first = self._conv(x_int, "", self.bias)
         return self._conv(x_int_0, "_0", None, residual=first)
 
+    def _pointwise_f16in(self, x, sfx, bias, residual=None):
+        """quant_op(x) -> _conv in ONE launch for a 1x1 / stride-1 / pad-0 layer (the UNet's conv_shortcut):
+        over NHWC rows it is a Linear, and mixdq_qlinear_f16in_w8a8 quantizes the FP16 rows in its staging
+        path -- a channel slice x[:, a:b] of a channels-last tensor is read in place (row stride = all
+        channels).  Returns None where that launch does not take the problem (the caller then issues the
+        reference's two launches, nn/Conv2d.py:294-311)."""
+        if (self.kernel_size[0] != 1 or self.kernel_size[1] != 1 or self.stride[0] != 1
+                or self.padding[0] != 0 or x.dim() != 4):
+            return None
+        rows = x.permute(0, 2, 3, 1)                      # [N, H, W, C] view of the NHWC memory
+        w = getattr(self, ("weight_int4" if self.w_packed4 else "weight_int") + sfx)
+        w2 = w.permute(0, 2, 3, 1).reshape(w.shape[0], -1)           # [K, C] (or [K, C / 2] packed): a view
+        K = self.out_channels
+        if not _C.qlinear_f16in_wanted(rows, K, x.shape[1], w4=self.w_packed4):
+            return None
+        res = None
+        if residual is not None:
+            if not residual.is_contiguous(memory_format=torch.channels_last):
+                return None
+            res = residual.permute(0, 2, 3, 1)
+        out = _C.qlinear_f16in(rows, getattr(self, "act_scales_inv" + sfx),
+                               getattr(self, "act_zero_points" + sfx), w2, getattr(self, "scale" + sfx),
+                               getattr(self, "bias0" + sfx), bias, _residual=res, _w4=self.w_packed4)
+        return out.permute(0, 3, 1, 2)                    # [N, K, H, W], channels-last in memory
+
+    def _quant_conv(self, x, sfx, bias, residual=None):
+        """The reference's pair per (half of a) layer -- quantize, conv -- as one launch where possible."""
+        y = self._pointwise_f16in(x, sfx, bias, residual)
+        if y is not None:
+            return y
+        x_int = quant_op(x, getattr(self, "act_scales_inv" + sfx), getattr(self, "act_zero_points" + sfx))
+        return self._conv(x_int, sfx, bias, residual=residual)
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if not self.valid_for_acceleration:
             return self.forward_fp(x)
         if x.dtype != torch.float16:
             return self.forward_fallback(x)
         if self.split == 0:
-            x_int = quant_op(x, self.act_scales_inv, self.act_zero_points)
-            return self._conv(x_int, "", self.bias)
-        x_int = quant_op(x[:, :self.split], self.act_scales_inv, self.act_zero_points)
-        x_int_0 = quant_op(x[:, self.split:], self.act_scales_inv_0, self.act_zero_points_0)
+            return self._quant_conv(x, "", self.bias)
         # bias is applied once, in the first half (nn/Conv2d.py:341-343); the reference's half add of
         # the two fp16 outputs rides in the second launch's epilogue (same arithmetic: each output
         # rounded to fp16, then one fp32 add rounded to fp16)
-        first = self._conv(x_int, "", self.bias)
-        return self._conv(x_int_0, "_0", None, residual=first)
+        first = self._quant_conv(x[:, :self.split], "", self.bias)
+        return self._quant_conv(x[:, self.split:], "_0", None, residual=first)

@@ -211,13 +211,31 @@ class QuantizedLinear(nn.Module):
         y = F.linear(x, self.weight, self.bias)
         return y if residual is None else y + residual
 
+    def _gemm_f16in(self, x, out=None, bos=False, residual=None):
+        """quant_op(x) -> _gemm in ONE launch (mixdq_qlinear_f16in_w8a8: the GEMM quantizes its FP16
+        operand in its staging path; bit-identical to the pair)."""
+        from mixdq_amd._C import qlinear_f16in
+        w = self.weight_int4 if self.w_packed4 else self.weight_int
+        return qlinear_f16in(x, self.act_scales_inv, self.act_zero_points, w, self.scale, self.bias0,
+                             self.bias, _out=out, _bos=bos, _residual=residual, _w4=self.w_packed4)
+
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if not self.valid_for_acceleration:
             return self.forward_fp(x)
         if x.dtype != torch.float16:
             return self.forward_fallback(x)
+        from mixdq_amd._C import qlinear_f16in_wanted
+        N, K = self.out_features, self.in_features
         if not getattr(self, "bos", False):
+            # the reference's two launches (nn/Linear.py:162-176) as one wherever the quantizing GEMM
+            # takes the shape; otherwise literally: quantize, then GEMM
+            if qlinear_f16in_wanted(x, N, K, w4=self.w_packed4):
+                return self._gemm_f16in(x)
             return self._gemm(quant_op(x, self.act_scales_inv, self.act_zero_points))
         # BOS carve-out: token 0 is a precomputed FP16 row, tokens 1.. go through the kernels
+        if qlinear_f16in_wanted(x, N, K, w4=self.w_packed4, bos=True):
+            out = torch.empty((x.shape[0], x.shape[1], N), dtype=torch.float16, device=x.device)
+            out[:, :1, :] = self.bos_pre_computed
+            return self._gemm_f16in(x, out=out, bos=True)
         x_int = quant_op(x[:, 1:, :], self.act_scales_inv, self.act_zero_points)
         return self.forward_bos_quantized(x_int, x.shape[0], x.shape[1])

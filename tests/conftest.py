@@ -20,7 +20,7 @@ def pytest_configure(config):
 # of the path: a1-a4), then the module layer, the fused producers, attention, and the UNet-level
 # tolerance tests last -- under the driver's `-x` a failure late in the list cannot hide the
 # operator evidence.  Within a file the definition order is kept.
-_FILE_ORDER = ["test_ops_gpu.py", "test_large_gpu.py", "test_modules_gpu.py", "test_fused_gpu.py",
+_FILE_ORDER = ["test_ops_gpu.py", "test_f16in_gpu.py", "test_large_gpu.py", "test_modules_gpu.py", "test_fused_gpu.py",
                "test_f16_gpu.py", "test_attention_gpu.py", "test_unet_gpu.py", "test_unet_full_gpu.py",
                "test_unet_path_a_gpu.py"]
 

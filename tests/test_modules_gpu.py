@@ -13,6 +13,16 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+@pytest.fixture(autouse=True, params=["0", "1"], ids=["two_launches", "f16in"])
+def f16in_mode(request, monkeypatch):
+    """Every module test runs with the reference's two launches per layer (quantize, GEMM / conv) and with
+    the quantize-in-prologue GEMM wherever it takes the shape (MIXDQ_F16IN=1; the default "auto" picks
+    between the two by cost): the reference classes' outputs must come out of both, bit for bit."""
+    import mixdq_amd._C as C_
+    monkeypatch.setattr(C_, "F16IN", request.param)
+    return request.param
+
+
 def build(c, golden):
     from mixdq_amd.nn import QuantizedConv2d, QuantizedLinear
     cls = QuantizedLinear if c["kind"] == "linear" else QuantizedConv2d
