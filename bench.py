@@ -249,9 +249,20 @@ def roofline_object(roof_stats, B, reps, px, tiny):
     traffic = mfma_util = None
     pmc_all = {}
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    # The counter columns are NOT measured by this run: they are the committed results of the builder's
+    # rocprofv3 --pmc passes over these kernels (a counter pass serialises the launches and cannot run inside
+    # the timed command).  The line says so (`traffic_source`) and drops them when the table was collected on
+    # other kernel sources than the library that is running (`csrc_sha16` of the table != the tree's).
+    traffic_source = {"file": "profiles/pmc_traffic.json", "measured_by_this_run": False}
     if os.path.exists(pmc) and px == 1024 and not tiny:
         with open(pmc) as f:      # sections by batch size of the probed launches (bs1, bs8)
-            pmc_all = json.load(f).get(f"bs{B}", {})
+            table = json.load(f)
+        prov = table.get("_provenance", {})
+        traffic_source.update(prov)
+        traffic_source["csrc_sha16_running"] = csrc_sha16()
+        traffic_source["stale"] = prov.get("csrc_sha16") != traffic_source["csrc_sha16_running"]
+        if not traffic_source["stale"]:
+            pmc_all = table.get(f"bs{B}", {})
         entry = pmc_all.get(dom) or pmc_all.get(dom.split("#")[0], {})     # "...#cfgNN" where a tile has several wave layouts
         traffic, mfma_util = entry.get("hbm_bytes_per_launch"), entry.get("mfma_util")
     per_kernel = {}
@@ -269,7 +280,10 @@ def roofline_object(roof_stats, B, reps, px, tiny):
     return {
         "bound": "mfma", "kernel": dom, "achieved": achieved, "peak": INT8_MFMA_PEAK_TOPS,
         "unit": "TFLOP/s", "frac": achieved / INT8_MFMA_PEAK_TOPS, "traffic": traffic,
-        "mfma_util": mfma_util,
+        "mfma_util": mfma_util, "traffic_source": traffic_source,
+        "clock": "cold replay of the recorded launches, each on its own weights, without the prefetch payload "
+                 "that precedes it in the step (HIP events); in_step_* = the same kernel inside a replay of "
+                 "the benchmarked graph (torch.profiler kernel durations)",
         "launches_per_step": s["launches"] // reps,
         "avg_launch_us": 1e3 * s["ms"] / s["launches"],
         "ops_per_launch": s["ops"] / s["launches"],
@@ -281,6 +295,56 @@ def roofline_object(roof_stats, B, reps, px, tiny):
                       "int8_ops_per_step": tot_ops / reps},
         "per_kernel": per_kernel,
     }
+
+
+def csrc_sha16():
+    """sha256 (first 16 hex digits) over the kernel sources the running library was built from."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "mixdq_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def kernel_name_pattern(kname):
+    """bench.py kernel name -> substring of the (demangled) device kernel name torch.profiler reports."""
+    import re
+    import mixdq_amd._C as C
+    m = re.match(r"igemm_kernel<(\d+),(\d+),(\d+),(\d+),(\w+?)(,w4)?>#cfg(\d+)", kname)
+    if m:
+        wm, wn, ks, mt = C.IGEMM_WAVES[int(m.group(7))]
+        return "igemm_kernel<%s, %s, %s, %s, %d, %d, " % (m.group(1), m.group(2), m.group(3), m.group(4), wm, wn)
+    m = re.match(r"conv3x3_halo_kernel<(\d+),(\d+),(\d+)>", kname)
+    if m:
+        return "conv3x3_halo_kernel<%s, %s, %s, " % m.groups()
+    return kname.split("<")[0]
+
+
+def in_step_kernel_times(fn, device):
+    """One torch.profiler pass over fn() (a replay of the benchmarked graph): {device kernel name:
+    (launches, total us)}, or None.  Traced durations over-state kernels of a few us by 1.5-3 us and long
+    ones by ~0.3; they are the kernel INSIDE the step: warm scalar caches, weights where the
+    prefetch left them."""
+    try:
+        from torch.profiler import ProfilerActivity, profile
+        with torch.no_grad():
+            fn()
+            torch.cuda.synchronize(device)
+            with profile(activities=[ProfilerActivity.CUDA]) as prof:
+                fn()
+                torch.cuda.synchronize(device)
+        out = {}
+        for e in prof.events():
+            if not str(getattr(e, "device_type", "")).endswith("CUDA") or "Memcpy" in e.name or "Memset" in e.name:
+                continue
+            n, t = out.get(e.name, (0, 0.0))
+            out[e.name] = (n + 1, t + float(getattr(e, "device_time", 0.0) or getattr(e, "cuda_time", 0.0)))
+        return out or None
+    except Exception:
+        return None
 
 
 def count_kernels(fn, device):
@@ -303,7 +367,9 @@ def count_kernels(fn, device):
 
 def cpu_fake_quant_baseline(seconds_budget):
     """Path A (qdiff fake-quant) of the 794-layer inventory at 512 px, batch 1, FP32 on the host
-    cores: every 8th layer in inventory order (neighbouring layers are alike), extrapolated x8."""
+    cores: the WHOLE inventory where the host is fast enough (the GPU box: 128 threads, 7-26 s), else a
+    sample spread uniformly over the model within `seconds_budget` with the rest extrapolated by
+    multiply-accumulates -- the returned object says which (whole_inventory, measured_mac_frac)."""
     from oracle.fakequant import quant_layer_forward
     from mixdq_amd.calib import ActRange, weight_delta
     from mixdq_amd.quantize_sdxl import example_inputs
@@ -629,8 +695,11 @@ def main():
     memory["w4a8_mixed" if args.w4_kernel else "w8a8"] = q_meter.report()
 
     roof_stats = None
+    in_step = None
     if not args.no_roofline and rank == 0:
         roof_stats = roofline_sweep(lambda: eager_forward(**inputs), device, args.sweep_reps)
+        if not args.no_graph and not os.environ.get("ROCP_TOOL_LIBRARIES") and not os.environ.get("ROCPROFILER_REGISTER_FORCE_LOAD"):
+            in_step = in_step_kernel_times(run_once, device)    # (not under rocprofv3: two tracers in one process)
 
     # ---- batch 8 beside the headline (north_star: "bs=1/8 on 1 GPU"; also the per-GPU shard of
     #      configs[3] on 8 GPUs): the same network and graph machinery on a batch-8 input, timed AFTER
@@ -718,19 +787,47 @@ def main():
     }
     if fp16:
         out["fp16"] = fp16
+        # three ratios against the FP16 network on this GPU; the like-for-like one is the headline:
+        #   speedup_vs_fp16_like_for_like  same glue kernels (this repo's fused norms / attention) on both
+        #                                  sides: what the INT8 GEMMs / convs themselves buy
+        #   speedup_vs_fp16                against stock PyTorch FP16 ops throughout (the reference's
+        #                                  comparison, kernels/README.md:108-110): glue gains included
+        #   speedup_vs_fp16_dropin         the module swap alone (added below with the drop-in leg)
         out["speedup_vs_fp16"] = fp16["ms_per_step"] / ms
         if "fused_glue_ms_per_step" in fp16:
             out["speedup_vs_fp16_with_fused_glue"] = fp16["fused_glue_ms_per_step"] / ms
+            out["speedup_vs_fp16_like_for_like"] = out["speedup_vs_fp16_with_fused_glue"]
         if "fp16" in memory:
             q = memory[kind]
             out["memory"]["saving_vs_fp16"] = {
                 k: memory["fp16"][k] / q[k] for k in ("static_mb", "dynamic_mb", "peak_mb") if q[k]}
     if roof_stats:
         out["roofline"] = roofline_object(roof_stats, B, args.sweep_reps, args.px, args.tiny)
+        if in_step:
+            # The device kernel behind the dominant instantiation, inside one replay of the benchmarked graph.
+            # (One device kernel serves several of this line's kernel names -- the GEMM+GEGLU epilogue is a
+            # run-time branch of the plain Linear's instantiation -- so ops and time are summed over all of them.)
+            r = out["roofline"]
+            pat = kernel_name_pattern(r["kernel"])
+            hits = [(n, t) for name, (n, t) in in_step.items() if pat in name]
+            n_l, us_all = sum(n for n, _ in hits), sum(t for _, t in hits)
+            ops_all = sum(v["ops"] / args.sweep_reps for k, v in roof_stats.items()
+                          if not v.get("f16") and kernel_name_pattern(k) == pat)
+            if n_l and us_all > 0:
+                r["in_step_avg_launch_us"] = us_all / n_l
+                r["in_step_launches"] = n_l
+                r["frac_in_step"] = ops_all / (us_all * 1e-6) / 1e12 / INT8_MFMA_PEAK_TOPS
+            r["in_step_kernel_time_ms"] = sum(t for _, t in in_step.values()) / 1e3
+            r["in_step_kernels"] = sum(n for n, _ in in_step.values())
     if batch8:
         out["batch8"] = batch8
     if dropin:
         out.update(dropin)
+        if fp16:
+            out["speedup_vs_fp16_dropin"] = fp16["ms_per_step"] / dropin["dropin_unfused_ms_per_step"]
+    if world == 1:
+        out["multi_gpu"] = ("unmeasured: no multi-GPU node was available to this build; RCCL has run under this "
+                            "code at world size 1 only (tests/test_dist_gpu.py)")
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_fake_quant_baseline(args.cpu_seconds)
     print(json.dumps(out))

@@ -17,7 +17,10 @@
  *     device  =>  safe under hipGraph capture;
  *   - return value: MIXDQ_OK (0) or an error code; the shim raises RuntimeError with
  *     mixdq_status_string(code) (reference: TORCH_CHECK -> RuntimeError).
- *   - no global mutable state.
+ *   - no global mutable state that a result depends on: what the library keeps per process is a zero
+ *     page, the GELU table (read-only once built: by the first GEMM+GEGLU call, or mixdq_gelu_table()),
+ *     and one "already set up on this device" flag per kernel instantiation (the > 64 KiB LDS opt-in)
+ *     and for that table.  Entry points may be called from several threads on different devices.
  */
 #ifndef MIXDQ_HIP_H_
 #define MIXDQ_HIP_H_
@@ -412,8 +415,9 @@ int mixdq_igemm_select_id_geglu(int64_t M, int N, int k_total, int w4);
 
 /* Tile id of the LDS-resident-halo kernel (csrc/iconv.hip) that mixdq_qconv2d_w8a8[_table] runs this
  * INT8 conv on when no tile is forced -- 90: 8 x 16 output pixels x 80 channels per workgroup, 91:
- * 8 x 8 x 80, 92: 16 x 16 x 80 (64-byte channel chunks) -- or 0 when the implicit-GEMM family runs it (not 3x3 / stride 1 / pad 1, C % 64 != 0,
- * H or W % 8 != 0, packed-W4 weights).  Ids 90 .. 92 can be forced through bits 8..15 of `flags`. */
+ * 8 x 8 x 80, 92: 16 x 16 x 80 (64-byte channel chunks), 93: 16 x 16 x 160 (K % 160 == 0; the choice from
+ * batch 8 on) -- or 0 when the implicit-GEMM family runs it (not 3x3 / stride 1 / pad 1, C % 64 != 0,
+ * H or W % 8 != 0, packed-W4 weights).  Ids 90 .. 93 can be forced through bits 8..15 of `flags`. */
 int mixdq_conv_halo_select(int N, int H, int W, int C, int K, int R, int S, int stride, int pad);
 
 /* Introspection (tests): the table the GEMM + GEGLU epilogue of the large tiles looks GELU up in --

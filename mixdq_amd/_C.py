@@ -110,6 +110,14 @@ IGEMM_CONFIGS = {1: (64, 64, 64, 2), 3: (128, 128, 64, 2), 4: (64, 64, 128, 3),
                  # 256x256x128 on the four-phase loop (2 x 4 waves of 128x64, 16x16x64 MFMAs)
                  70: (256, 256, 128, 2)}
 
+# id -> (WM, WN, KSPLIT, MT): wave grid, k-split groups and MFMA shape of each configuration (the template
+# arguments that tell two configurations of one tile shape apart in a kernel trace)
+IGEMM_WAVES = {1: (2, 2, 1, 32), 3: (2, 2, 1, 32), 4: (2, 2, 1, 32), 13: (4, 2, 1, 32), 14: (4, 2, 1, 32),
+               15: (2, 4, 1, 32), 18: (4, 2, 1, 32), 20: (4, 2, 1, 32), 25: (4, 2, 1, 32), 27: (8, 2, 1, 16),
+               28: (4, 4, 1, 16), 35: (4, 2, 1, 32), 37: (2, 2, 2, 32), 41: (2, 4, 1, 32), 42: (4, 1, 2, 16),
+               43: (4, 1, 2, 16), 44: (4, 1, 2, 16), 45: (4, 1, 2, 16), 46: (4, 2, 1, 32), 47: (4, 2, 1, 32),
+               56: (4, 1, 2, 16), 70: (2, 4, 1, 16)}
+
 FLAG_W4 = 2   # MIXDQ_FLAG_W4: the weight tensor holds packed signed 4-bit values
 FLAG_UPSAMPLE2X = 4   # MIXDQ_FLAG_UPSAMPLE2X: the conv input is read through a nearest 2x upsampling
 
@@ -137,19 +145,67 @@ def _record(name, M, N, K, k_align, w4, fn, args, kwargs):
     RECORD.append((name, (int(M), int(N), int(K), int(k_align)), bool(w4), replay))
 
 
-# Weight trace (mixdq_amd/unet.py's prefetch planner): when a list, every GEMM / conv entry point appends the
-# weight operand it was called with, and every long-key attention launch a marker -- the execution order of
-# the network's weights relative to its self-attention launches.  Costs one list append per launch.
-TRACE = None
-# Prefetch plan of the running forward (set by mixdq_amd/unet.py around a fused forward): PLAN[i] = the tensors
-# the i-th long-key attention launch of the forward carries as its payload; ATT_INDEX counts those launches.
-PLAN = None
-ATT_INDEX = 0
+class PrefetchContext:
+    """One forward's weight trace and prefetch plan (mixdq_amd/unet.py's planner).
+
+    While a context is active on the calling THREAD (`with ctx:`), every GEMM / conv entry point appends the
+    weight operand it was called with to `trace` and every long-key attention launch a marker -- the
+    execution order of the network's weights relative to its self-attention launches -- and the i-th such
+    attention launch carries `plan[i]` (weak references to weight tensors) as its payload.  The state lives
+    in the object, never in the module: two UNets, or two threads each driving a device, keep their own.
+    Only tensors on `device` are traced or handed to a launch (a payload address of another device would be
+    dereferenced by the kernel).  A context does not nest: entering one while another is active on the
+    thread leaves the outer one in charge and makes the inner one a no-op."""
+    __slots__ = ("device", "trace", "plan", "att_index", "_outer", "_live")
+
+    def __init__(self, device, plan=None):
+        self.device = torch.device(device)
+        self.trace = []
+        self.plan = plan
+        self.att_index = 0
+        self._outer = None
+        self._live = False
+
+    def __enter__(self):
+        self._outer = getattr(_TLS, "ctx", None)
+        if self._outer is None:
+            _TLS.ctx = self
+            self._live = True
+        return self
+
+    def __exit__(self, *exc):
+        if self._live:
+            _TLS.ctx = None
+            self._live = False
+        return False
+
+    def payload(self):
+        """The tensors of the next long-key attention launch (dead references and other devices dropped)."""
+        i, self.att_index = self.att_index, self.att_index + 1
+        if self.plan is None or i >= len(self.plan):
+            return None
+        out = []
+        for ref in self.plan[i]:
+            t = ref()
+            if t is not None and t.device == self.device:
+                out.append(t)
+        return out
+
+
+import threading as _threading   # noqa: E402
+import weakref as _weakref       # noqa: E402, F401  (plans hold weakref.ref(tensor))
+_TLS = _threading.local()
+
+
+def prefetch_context():
+    """The PrefetchContext active on this thread, or None."""
+    return getattr(_TLS, "ctx", None)
 
 
 def _trace_w(t):
-    if TRACE is not None and t is not None and t.is_cuda:
-        TRACE.append(t)
+    ctx = getattr(_TLS, "ctx", None)
+    if ctx is not None and t is not None and t.device == ctx.device:
+        ctx.trace.append(t)
 
 
 def _check(cond: bool, msg: str):
@@ -1031,14 +1087,14 @@ def attention_f16(q, k, v, heads, scale_inv=None, zero_point=None, softmax_scale
                                    softmax_scale=softmax_scale, _cfg=_cfg))     # (measured without the payload)
     out = torch.empty((B, Tq, C), dtype=torch.int8 if quant else torch.float16, device=q.device)
     sc = float(softmax_scale) if softmax_scale is not None else 0.125
-    if k.shape[1] > 128:                                    # a launch that can carry a prefetch payload
-        global ATT_INDEX
-        if TRACE is not None:
-            TRACE.append(("attn", B * Tq, k.shape[1]))
-        if _prefetch is None and PLAN is not None and ATT_INDEX < len(PLAN):
-            _prefetch = PLAN[ATT_INDEX]
-        ATT_INDEX += 1
-    pf = [t for t in (_prefetch or ()) if t is not None and t.is_cuda and t.numel() > 0]
+    ctx = getattr(_TLS, "ctx", None)
+    if k.shape[1] > 128 and ctx is not None and ctx.device == q.device:   # a launch that can carry a payload
+        ctx.trace.append(("attn", B * Tq, k.shape[1]))
+        planned = ctx.payload()
+        if _prefetch is None:
+            _prefetch = planned
+    # (a payload address of another device would be dereferenced by this device's kernel: dropped)
+    pf = [t for t in (_prefetch or ()) if t is not None and t.device == q.device and t.numel() > 0]
     _check(len(pf) <= PREFETCH_MAX_RANGES, "at most 16 prefetch ranges")
     with torch.cuda.device(q.device):
         if pf and hasattr(_lib, "mixdq_attention_f16_prefetch"):

@@ -708,9 +708,13 @@ static int attention_f16_impl(const void* q, const void* k, const void* v, void*
   for (int i = 0; i < 16; ++i) { p.pf_ptr[i] = nullptr; p.pf_bytes[i] = 0; }
   for (int i = 0; i < n_pf; ++i) {
     if (!pf_ptrs[i] || pf_bytes[i] < 16) continue;
-    if ((uintptr_t)pf_ptrs[i] & 15) return MIXDQ_ERR_ALIGNMENT;
-    p.pf_ptr[p.n_pf] = (const char*)pf_ptrs[i];
-    p.pf_bytes[p.n_pf++] = pf_bytes[i];
+    // the payload is a hint and must never fail a launch: a range that does not start on a 16-byte boundary
+    // (a weight view at an odd offset) is rounded inward to the part that 16-byte loads can read
+    const uintptr_t b = ((uintptr_t)pf_ptrs[i] + 15) & ~(uintptr_t)15;
+    const int64_t cut = (int64_t)(b - (uintptr_t)pf_ptrs[i]);
+    if (pf_bytes[i] - cut < 16) continue;
+    p.pf_ptr[p.n_pf] = (const char*)b;
+    p.pf_bytes[p.n_pf++] = pf_bytes[i] - cut;
   }
   if (p.n_pf) {   // one payload workgroup per CU by default (MIXDQ_PREFETCH_BLOCKS / MIXDQ_PREFETCH_NT: A/B runs)
     static const int blocks = [] { const char* e = getenv("MIXDQ_PREFETCH_BLOCKS"); return e ? atoi(e) : kNumCU; }();

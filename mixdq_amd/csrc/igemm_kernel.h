@@ -143,21 +143,30 @@ __global__ __launch_bounds__(256) void gelu_table_init_kernel() {
 // The table is built once per device by the first launch that needs it.  `done[dev]` is only set once
 // the table IS in memory for every stream: outside a capture the init kernel runs on the caller's
 // stream and is waited for (one host synchronisation per device and process, at first use).  Inside a
-// stream capture nothing may synchronise and the kernel is only RECORDED, so the init is recorded in
-// front of the consumer in that graph (idempotent: every replay rewrites the same bits) and `done`
-// stays false -- an eager launch or a later capture before the first replay builds the table itself.
+// stream capture nothing may synchronise and the kernel is only RECORDED: the init is recorded in front
+// of the FIRST consumer of that capture (idempotent: every replay rewrites the same bits; later
+// consumers of the same capture are ordered behind it by the stream -- `in_capture[dev]` remembers the
+// capture's id, so a UNet graph captured cold carries one init kernel, not seventy that rewrite the
+// table under each other's readers) and `done` stays false -- an eager launch or another capture before
+// the first replay builds the table itself.  mixdq_amd builds it eagerly (mixdq_gelu_table from
+// SDXLUNet.prepare_fused_), so its captures record none.
 inline int ensure_gelu_table(hipStream_t stream) {
   static bool done[64] = {};
+  static unsigned long long in_capture[64] = {};
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MIXDQ_ERR_LAUNCH;
   if (done[dev]) return MIXDQ_OK;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(stream, &cap) != hipSuccess) return MIXDQ_ERR_LAUNCH;
+  unsigned long long cap_id = 0;
+  if (hipStreamGetCaptureInfo(stream, &cap, &cap_id) != hipSuccess) return MIXDQ_ERR_LAUNCH;
+  if (cap != hipStreamCaptureStatusNone && cap_id != 0 && in_capture[dev] == cap_id) return MIXDQ_OK;
   gelu_table_init_kernel<<<(2 * kGeluTabMag + 255) / 256, 256, 0, stream>>>();
   if (hipGetLastError() != hipSuccess) return MIXDQ_ERR_LAUNCH;
   if (cap == hipStreamCaptureStatusNone) {
     if (hipStreamSynchronize(stream) != hipSuccess) return MIXDQ_ERR_LAUNCH;
     done[dev] = true;
+  } else {
+    in_capture[dev] = cap_id;
   }
   return MIXDQ_OK;
 }

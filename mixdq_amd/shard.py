@@ -68,8 +68,8 @@ def _leaves(d):
 def broadcast_module_state(module: torch.nn.Module, src: int = 0, bucket_bytes: int = 256 << 20):
     """Broadcast every parameter and buffer of `module` from `src`, packed per dtype into
     buckets of up to `bucket_bytes`.  Returns the number of bytes broadcast."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        return 0
+    if not (dist.is_available() and dist.is_initialized()):
+        return 0          # (a process group of ONE rank still runs the collective: tests/test_dist_gpu.py)
     tensors = [t for t in list(module.parameters()) + list(module.buffers()) if t.numel() > 0]
     by_dtype = {}
     for t in tensors:
@@ -101,7 +101,7 @@ def broadcast_module_state(module: torch.nn.Module, src: int = 0, bucket_bytes: 
 
 
 def max_over_ranks(value: float, device) -> float:
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -109,5 +109,5 @@ def max_over_ranks(value: float, device) -> float:
 
 
 def barrier():
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.barrier()

@@ -504,9 +504,23 @@ PREFETCH_MAX_LEAD = int(__import__("os").environ.get("MIXDQ_PREFETCH_LEAD", "4")
 PREFETCH_SKIP_MB = float(__import__("os").environ.get("MIXDQ_PREFETCH_SKIP_MB", "0"))       # experiment: leave tensors above this cold (0: off)
 
 
+def _trace_signature(trace):
+    return tuple(it if isinstance(it, tuple) else (it.data_ptr(), it.numel()) for it in trace)
+
+
+def _plan_alive(plan, device) -> bool:
+    """Every tensor of the plan still exists, at the address it was planned at, on `device`."""
+    for lst in plan["lists"]:
+        for ref, ptr in zip(lst, plan["ptrs"][id(lst)]):
+            t = ref()
+            if t is None or t.device != device or t.data_ptr() != ptr:
+                return False
+    return True
+
+
 def _build_prefetch_plan(trace):
     """Which weights does each self-attention launch of a forward read ahead (mixdq_attention_f16_prefetch)?
-    `trace` (mixdq_amd._C.TRACE) is the forward's execution order: weight operands as the GEMM / conv entry
+    `trace` (mixdq_amd._C.PrefetchContext.trace) is the forward's execution order: weight operands as the GEMM / conv entry
     points saw them, and a marker (rows, keys) per long-key attention launch.  Launch j is given the weights
     used between it and launch j + 1 -- the rest of its transformer block, the next block's q|k|v; at the
     end of a Transformer2DModel also proj_out, the ResNet convs, shortcuts and samplers up to the next
@@ -558,8 +572,10 @@ def _build_prefetch_plan(trace):
             elif d < PREFETCH_MAX_LEAD:
                 new_carry.append((t, d + 1))         # else: stays cold
         carry = new_carry
-    sig = tuple(it if isinstance(it, tuple) else it.data_ptr() for it in trace)
-    return {"lists": lists, "sig": sig}
+    import weakref
+    ref_lists = [[weakref.ref(t) for t in lst] for lst in lists]       # never keeps a replaced weight alive
+    ptrs = {id(rl): [t.data_ptr() for t in lst] for rl, lst in zip(ref_lists, lists)}
+    return {"lists": ref_lists, "ptrs": ptrs, "sig": _trace_signature(trace)}
 
 
 def _cross_fusable(attn, feed, k, v, residual) -> bool:
@@ -1095,10 +1111,17 @@ class SDXLUNet(nn.Module):
                     and len(set(_quantizer_groups(_memo(blk), "kv", kv))) == 1
                     and unify_packed_storage_(kv)):
                 self._kv_pack(blk)
+        # the GELU table of the GEMM+GEGLU launches is built here, eagerly: a first use inside a stream
+        # capture could only RECORD its init kernel into that graph (csrc/igemm_kernel.h ensure_gelu_table)
+        dev = next((b.device for b in self.buffers() if b.is_cuda), None)
+        if dev is not None:
+            from mixdq_amd import _C
+            _C.gelu_table(dev)
         return self
 
     def set_fused(self, enabled: bool = True):
         """Switch the producer fusions on or off for the whole graph (see the top of this file)."""
+        self.__dict__.pop("_pf_plans", None)
         for m in self.modules():
             if hasattr(type(m), "fused"):
                 m.fused = bool(enabled)
@@ -1125,19 +1148,40 @@ class SDXLUNet(nn.Module):
         emb = emb + self.add_embedding(add)
 
         use_pf = bool(self.fused and PREFETCH and sample.is_cuda and _fusable_f16(sample) and not DEFUSE)
-        if use_pf:                                  # trace this forward's weight order; replay the last plan
-            from mixdq_amd import _C
-            plan = self.__dict__.get("_pf_plan")
-            _C.TRACE, _C.ATT_INDEX = [], 0
-            _C.PLAN = plan["lists"] if plan else None
-        try:
+        if not use_pf:
             return self._forward_body(sample, emb, encoder_hidden_states)
+        # Trace this forward's weight order and replay the plan of the last forward ON THIS DEVICE: the state
+        # is this call's own PrefetchContext (thread-local while it runs), the plans are kept per device in
+        # the instance and hold weak references -- a plan made for another device, or for weights that have
+        # been replaced since (`.to()`, re-quantization, load_state_dict: cleared in _apply / below, and
+        # dropped here when a reference is dead or points elsewhere), is never handed to a launch.
+        from mixdq_amd import _C
+        plans = self.__dict__.setdefault("_pf_plans", {})
+        plan = plans.get(sample.device)
+        if plan is not None and not _plan_alive(plan, sample.device):
+            plans.pop(sample.device, None)
+            plan = None
+        ctx = _C.PrefetchContext(sample.device, plan["lists"] if plan else None)
+        try:
+            with ctx:
+                return self._forward_body(sample, emb, encoder_hidden_states)
         finally:
-            if use_pf:
-                trace, _C.TRACE, _C.PLAN = _C.TRACE, None, None
-                sig = tuple(it if isinstance(it, tuple) else it.data_ptr() for it in trace)
-                if plan is None or plan["sig"] != sig:       # first forward, or the layers changed
-                    self.__dict__["_pf_plan"] = _build_prefetch_plan(trace)
+            if ctx._outer is None:                               # (an inner, inactive context traced nothing)
+                sig = _trace_signature(ctx.trace)
+                if plan is None or plan["sig"] != sig:           # first forward here, or the layers changed
+                    new = _build_prefetch_plan(ctx.trace)
+                    if new is None:
+                        plans.pop(sample.device, None)
+                    else:
+                        plans[sample.device] = new
+
+    def _apply(self, fn, recurse=True):          # .to() / .cuda() / .half(): the weights move, the plans go
+        self.__dict__.pop("_pf_plans", None)
+        return super()._apply(fn, recurse)
+
+    def load_state_dict(self, *args, **kwargs):
+        self.__dict__.pop("_pf_plans", None)
+        return super().load_state_dict(*args, **kwargs)
 
     def _forward_body(self, sample, emb, encoder_hidden_states):
         if self.fused and _fusable_f16(sample) and not DEFUSE:

@@ -22,7 +22,7 @@ def pytest_configure(config):
 # operator evidence.  Within a file the definition order is kept.
 _FILE_ORDER = ["test_ops_gpu.py", "test_f16in_gpu.py", "test_large_gpu.py", "test_modules_gpu.py", "test_fused_gpu.py",
                "test_f16_gpu.py", "test_attention_gpu.py", "test_unet_gpu.py", "test_unet_full_gpu.py",
-               "test_unet_path_a_gpu.py"]
+               "test_unet_path_a_gpu.py", "test_dist_gpu.py"]
 
 
 def pytest_collection_modifyitems(config, items):

@@ -583,12 +583,12 @@ def test_prefetch_plan_own_interval_first_bounded_look_back_and_row_limit():
     early, w1, w2, w3, big, small, tail = w(5), w(20), w(20), w(20), w(60), w(0.01), w(10)
     trace = [early, a, w1, small, a, w2, w3, w1, a, big, tail]
     plan = U._build_prefetch_plan(trace)
-    ptrs = [[t.data_ptr() for t in lst] for lst in plan["lists"]]
+    ptrs = [[ref().data_ptr() for ref in lst] for lst in plan["lists"]]      # the plan holds weak references
     assert ptrs[2] == []                                         # 60 MB does not fit; `tail` may not overtake it
     assert ptrs[1] == [w2.data_ptr(), w3.data_ptr()]             # own interval (w1 repeated: once), 40 of 48 MB; ...
     assert ptrs[0] == [w1.data_ptr(), tail.data_ptr()]           # ... `tail` (10 MB) moves back behind w1; big is dropped
     assert all(early.data_ptr() not in p and small.data_ptr() not in p and big.data_ptr() not in p for p in ptrs)
-    assert plan["sig"] == tuple(it if isinstance(it, tuple) else it.data_ptr() for it in trace)
+    assert plan["sig"] == U._trace_signature(trace) and U._plan_alive(plan, torch.device("cpu"))
     saved, U.PREFETCH_MAX_ROWS = U.PREFETCH_MAX_ROWS, 4096                   # the optional row limit
     try:
         over = ("attn", 8192, 1024)
@@ -602,4 +602,55 @@ def test_prefetch_plan_own_interval_first_bounded_look_back_and_row_limit():
         chain += [a, w(40)]                                      # every launch is full with its own 40 MB ...
     last = w(30)
     plan = U._build_prefetch_plan(chain + [last])                # ... so a 30 MB tensor behind the last finds no room
-    assert all(last.data_ptr() not in [t.data_ptr() for t in lst] for lst in plan["lists"])
+    assert all(last.data_ptr() not in [ref().data_ptr() for ref in lst] for lst in plan["lists"])
+    # a plan never keeps a replaced weight alive, and notices that it is gone
+    keep = [w(30), w(30)]
+    plan = U._build_prefetch_plan([a, keep[0], a, keep[1]])
+    assert U._plan_alive(plan, torch.device("cpu"))
+    del keep[1]
+    import gc
+    gc.collect()
+    assert not U._plan_alive(plan, torch.device("cpu"))
+
+
+def test_prefetch_state_is_per_forward_and_per_thread():
+    """mixdq_amd._C.PrefetchContext: the weight trace / plan / launch counter of a forward live in
+    an object that is active on ONE thread while that forward runs -- two UNets whose forwards interleave
+    (threads, one per device) cannot mix their traces; a nested forward leaves the outer context in charge;
+    tensors of another device are neither traced nor handed to a launch."""
+    import threading
+    import weakref
+    from mixdq_amd import _C
+    assert _C.prefetch_context() is None and not hasattr(_C, "TRACE") and not hasattr(_C, "PLAN")
+    wa, wb = torch.empty(4, dtype=torch.int8), torch.empty(8, dtype=torch.int8)
+    ctx_a = _C.PrefetchContext("cpu", plan=[[weakref.ref(wa)], [weakref.ref(wb)]])
+    with ctx_a:
+        assert _C.prefetch_context() is ctx_a
+        _C._trace_w(wa)
+        inner = _C.PrefetchContext("cpu")
+        with inner:                                   # nested: a no-op, the outer one keeps tracing
+            assert _C.prefetch_context() is ctx_a
+            _C._trace_w(wb)
+        assert _C.prefetch_context() is ctx_a and inner.trace == []
+        seen = {}
+
+        def other_thread():                           # another thread sees no context, and gets its own
+            seen["before"] = _C.prefetch_context()
+            with _C.PrefetchContext("cpu") as c:
+                _C._trace_w(wb)
+                seen["own"] = c.trace
+            seen["after"] = _C.prefetch_context()
+        th = threading.Thread(target=other_thread)
+        th.start()
+        th.join()
+        assert seen["before"] is None and seen["after"] is None and len(seen["own"]) == 1
+        assert [t.data_ptr() for t in ctx_a.trace] == [wa.data_ptr(), wb.data_ptr()]
+        assert [t.data_ptr() for t in ctx_a.payload()] == [wa.data_ptr()]      # launch 0, then launch 1 ...
+        assert [t.data_ptr() for t in ctx_a.payload()] == [wb.data_ptr()]
+        assert ctx_a.payload() is None                                            # ... then nothing planned
+    assert _C.prefetch_context() is None
+    # another device's tensors: not traced, never in a payload
+    ctx_m = _C.PrefetchContext("meta", plan=[[weakref.ref(wa)]])
+    with ctx_m:
+        _C._trace_w(wa)
+        assert ctx_m.trace == [] and ctx_m.payload() == []

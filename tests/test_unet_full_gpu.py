@@ -112,3 +112,38 @@ def test_full_unet_w4a8_mixed_fused_equals_defused_graph_and_batch_rows(C):
     _check_graph(unet, inputs2, expect_accel=719)
     del unet
     torch.cuda.empty_cache()
+
+
+def test_full_unet_w8a8_batch8_graph_fused_equals_defused_and_rows_equal_batch1(C):
+    """The graph behind bench.py's `batch8` object and behind every rank of BASELINE.json configs[3] on 8 GPUs
+    (64 images = 8 per GPU): at batch 8 the tile rule picks other kernels than at batch 1 / 2 (the four-phase
+    256x256 tile, the 160-channel halo conv, un-fused to_q + cross-attention, prefetch payloads in a full
+    attention launch).  Fused == de-fused bit for bit; hipGraph replay == eager; row 3 and row 7 equal the
+    batch-1 runs of those images -- 8 images on one GPU and 1 image on each of 8 give the same tensors."""
+    import mixdq_amd.unet as U
+    from mixdq_amd.quantize_sdxl import example_inputs, hip_graph_opt
+    unet, _ = _build("weight/uniform_8", "act/act_8.00", False)
+    unet.set_fused(True)
+    inputs8 = example_inputs(8, 128, DEV, seed=1042)
+    with torch.no_grad():
+        fused8 = unet(**inputs8)[0].clone()
+        with U.defused():
+            ref8 = unet(**inputs8)[0].clone()
+        singles = {i: unet(**_slice_inputs(inputs8, i, i + 1))[0].clone() for i in (3, 7)}
+    assert torch.isfinite(fused8).all()
+    diff = (fused8.float() - ref8.float()).abs()
+    assert torch.equal(fused8, ref8), (f"batch 8: fused != de-fused: {int((diff > 0).sum())} of "
+                                       f"{diff.numel()} elements, max {diff.max().item():.4g}")
+    for i, one in singles.items():
+        assert torch.equal(fused8[i:i + 1], one), f"row {i} of the batch-8 run != its batch-1 run"
+    eager = unet.forward
+    hip_graph_opt(unet)
+    try:
+        with torch.no_grad():
+            g1 = unet(**inputs8)[0].clone()
+            g2 = unet(**inputs8)[0].clone()
+    finally:
+        unet.forward = eager
+    assert torch.equal(g1, fused8) and torch.equal(g2, fused8)
+    del unet
+    torch.cuda.empty_cache()
