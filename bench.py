@@ -282,8 +282,8 @@ def roofline_object(roof_stats, B, reps, px, tiny):
         "unit": "TFLOP/s", "frac": achieved / INT8_MFMA_PEAK_TOPS, "traffic": traffic,
         "mfma_util": mfma_util, "traffic_source": traffic_source,
         "clock": "cold replay of the recorded launches, each on its own weights, without the prefetch payload "
-                 "that precedes it in the step (HIP events); in_step_* = the same kernel inside a replay of "
-                 "the benchmarked graph (torch.profiler kernel durations)",
+                 "that precedes it in the step (HIP events); in_step_* = the same kernel inside an eager "
+                 "forward of the benchmarked network, prefetch payloads included (torch.profiler durations)",
         "launches_per_step": s["launches"] // reps,
         "avg_launch_us": 1e3 * s["ms"] / s["launches"],
         "ops_per_launch": s["ops"] / s["launches"],
@@ -324,8 +324,8 @@ def kernel_name_pattern(kname):
 
 
 def in_step_kernel_times(fn, device):
-    """One torch.profiler pass over fn() (a replay of the benchmarked graph): {device kernel name:
-    (launches, total us)}, or None.  Traced durations over-state kernels of a few us by 1.5-3 us and long
+    """One torch.profiler pass over fn() (an eager forward of the benchmarked graph's launches): {device
+    kernel name: (launches, total us)}, or None.  Traced durations over-state kernels of a few us by 1.5-3 us and long
     ones by ~0.3; they are the kernel INSIDE the step: warm scalar caches, weights where the
     prefetch left them."""
     try:
@@ -698,8 +698,10 @@ def main():
     in_step = None
     if not args.no_roofline and rank == 0:
         roof_stats = roofline_sweep(lambda: eager_forward(**inputs), device, args.sweep_reps)
-        if not args.no_graph and not os.environ.get("ROCP_TOOL_LIBRARIES") and not os.environ.get("ROCPROFILER_REGISTER_FORCE_LOAD"):
-            in_step = in_step_kernel_times(run_once, device)    # (not under rocprofv3: two tracers in one process)
+        if not os.environ.get("ROCP_TOOL_LIBRARIES") and not os.environ.get("ROCPROFILER_REGISTER_FORCE_LOAD"):
+            # (an EAGER forward of the timed graph's launches -- tracing a hipGraph replay through torch.profiler
+            #  crashed the process on ROCm 7.2; and not under rocprofv3: two tracers in one process)
+            in_step = in_step_kernel_times(lambda: eager_forward(**inputs), device)
 
     # ---- batch 8 beside the headline (north_star: "bs=1/8 on 1 GPU"; also the per-GPU shard of
     #      configs[3] on 8 GPUs): the same network and graph machinery on a batch-8 input, timed AFTER
