@@ -193,6 +193,10 @@ def roofline_sweep(run_eager, device, reps):
             cid = 37 if M <= 64 else 35
         elif kind == "linear_attn":      # to_q + cross-attention: always the 64x128 8-wave tile
             cid = 41
+        elif kind == "linear_ln":        # GEMM + residual + LayerNorm + quantize: csrc/igemm_ln.hip's rule
+            cid = int(C._lib.mixdq_qlinear_ln_select_id(M, N, K))
+        elif kind == "linear_f16in":     # quantize-in-prologue GEMM: csrc/igemm_aq.hip's rule
+            cid = int(C._lib.mixdq_qlinear_f16in_select_id(M, N, K, int(w4)))
         else:
             cid = C.igemm_select_id(M, N, k_align, K, w4=w4, geglu=kind == "linear_geglu")
         bm, bn, bk, st = C.IGEMM_CONFIGS.get(cid, (0, 0, 0, 0))

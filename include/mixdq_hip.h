@@ -276,12 +276,40 @@ int mixdq_groupnorm_silu_quantize3(const void* x_nhwc_f16, int C1, const void* x
 
 /* LayerNorm over the last dimension of x [M, C] (fp16) + up to three quantizers of the same
  * normalised FP16 value (to_q / to_k / to_v have their own activation scales).  HOST arrays of
- * n_out device pointers.  C % 8 == 0, C <= 2048. */
+ * n_out device pointers.  C % 16 == 0, C <= 2048 (MIXDQ_ERR_SHAPE otherwise).  Row statistics in the
+ * tiling-independent order of oracle/mixdq_oracle.c (per-16-column partials, Chan's combination), so that
+ * mixdq_qlinear_w8a8_ln -- the same LayerNorm in the epilogue of the GEMM that produces x -- gives the same bits. */
 int mixdq_layernorm_quantize(const void* x_f16, const void* gamma_f16, const void* beta_f16,
                              float eps, int64_t M, int C, int n_out,
                              const float* const* scale_inv, const float* const* zero_point,
                              int8_t* const* out_q, void* out_f16_or_null, int flags,
                              mixdq_stream_t stream);
+
+/* a2 + residual + LayerNorm + quantize in ONE launch: the GEMM of mixdq_qlinear_w8a8_rows (bias, residual as
+ * there; no row map) whose output rows D [M, N] are ALSO normalised over their N columns and quantized for up to
+ * three consumers, exactly as mixdq_layernorm_quantize(D, ...) would do in a second launch:
+ *   out_q[i][m, n] = quantize_i( f16( fma((D[m,n] - mean_m) * rstd_m, gamma[n], beta[n]) ) ),  out_f16 = that FP16.
+ * A column tile of 80 columns is exactly one unit of the LayerNorm's reduction order (oracle/mixdq_oracle.c):
+ * every tile publishes ONE 16-byte record per row -- {sum, centred sum of squares, launch tag} -- into
+ * `workspace` with a write-through store, polls the N / 80 records of each of its rows until they carry this
+ * launch's tag, combines them and normalises the columns it still holds in LDS; the bits equal the two-launch
+ * chain.  Range: N = 1280 or 640 (N / 80 a power of two <= 16 that equals the LayerNorm's unit count),
+ * K % 128 == 0, and the whole launch resident at once -- at most one 64 x 80 (or 128 x 80) tile per CU:
+ * M <= 1024 at N = 1280 (2048 on 128-row tiles), M <= 4096 at N = 640 -- MIXDQ_ERR_SHAPE otherwise
+ * (mixdq_qlinear_ln_select_id() < 0; the caller then issues the two launches).
+ * `workspace`: mixdq_qlinear_ln_workspace_bytes(M, N) bytes, 16-byte aligned, ZERO before the first use (its
+ * first page holds a launch counter that tags the records: a launch of any shape may follow on the same
+ * buffer).  One launch at a time per workspace (launches of one stream are).
+ * No reference counterpart (stock nn.LayerNorm + quant_op, nn/Linear.py:162-164). */
+size_t mixdq_qlinear_ln_workspace_bytes(int64_t M, int N);
+int mixdq_qlinear_ln_select_id(int64_t M, int N, int K);   /* tile id (44, 45, 56) or -1 = not supported */
+int mixdq_qlinear_w8a8_ln(const int8_t* A, const int8_t* W, const float* bias0, const float* scale,
+                          const void* bias_f16_or_null, void* D_f16, int64_t M, int N, int K,
+                          const void* residual_f16_or_null, int64_t residual_row_div,
+                          const void* gamma_f16, const void* beta_f16, float eps, int n_out,
+                          const float* const* scale_inv, const float* const* zero_point,
+                          int8_t* const* out_q, void* out_f16_or_null, void* workspace,
+                          int flags, mixdq_stream_t stream);
 
 /* GEGLU + quantize: h [M, 2D] fp16 (ff.net.0.proj output) -> fp16(h[:, :D] * fp16(gelu(h[:, D:])))
  * -> int8 [M, D] and/or fp16 [M, D].  D % 8 == 0. */

@@ -1034,6 +1034,73 @@ def layernorm_quantize(x, weight, bias, eps, qparams, want_f16=False):
     return outs, out_h
 
 
+_lib.mixdq_qlinear_ln_workspace_bytes.restype = _sz
+_lib.mixdq_qlinear_ln_workspace_bytes.argtypes = [_i64, _i32]
+_lib.mixdq_qlinear_ln_select_id.restype = _i32
+_lib.mixdq_qlinear_ln_select_id.argtypes = [_i64, _i32, _i32]
+_lib.mixdq_qlinear_w8a8_ln.restype = _i32
+_lib.mixdq_qlinear_w8a8_ln.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _vp,
+                                       ctypes.c_float, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _vp]
+
+# GEMM + residual + LayerNorm + quantize in one launch (csrc/igemm_ln.hip).  MIXDQ_LN_FUSE=0: off (A/B runs).
+LN_FUSE = os.environ.get("MIXDQ_LN_FUSE", "1") != "0"
+
+
+def qlinear_ln_supported(M: int, N: int, K: int) -> bool:
+    return bool(LN_FUSE and _lib.mixdq_qlinear_ln_select_id(int(M), int(N), int(K)) > 0)
+
+
+def qlinear_ln_workspace(M: int, N: int, device) -> torch.Tensor:
+    """A zeroed exchange buffer for qlinear_ln launches of up to M rows x N columns (partials + counters; a
+    launch leaves the counters at zero).  Owned by the caller: one launch at a time per buffer."""
+    return torch.zeros(int(_lib.mixdq_qlinear_ln_workspace_bytes(int(M), int(N))), dtype=torch.uint8,
+                       device=device)
+
+
+def qlinear_ln(input_int8, weight_int8, scale, bias0, bias, residual, ln_weight, ln_bias, eps, qparams,
+               workspace, *, want_f16=False, _cfg=0):
+    """y = qlinear_w8_a8_ohalf(input_int8, ...) [+ residual];  layernorm_quantize(y, ln_weight, ln_bias, eps,
+    qparams, want_f16) -- in ONE launch, bit-identical to the two (mixdq_qlinear_w8a8_ln).  Returns
+    (y fp16 [..., N], [int8 ...], fp16 or None).  Raises where qlinear_ln_supported() is False."""
+    _trace_w(weight_int8)
+    _check(input_int8.is_cuda and input_int8.dtype == torch.int8, "input_int8 should be int8 on GPU")
+    dev = input_int8.device
+    N, K = weight_int8.size(0), weight_int8.size(1)
+    _check(input_int8.size(-1) == K, "The last dimension of input and weight should match")
+    a, w = input_int8.contiguous(), weight_int8.contiguous()
+    M = a.numel() // K if K else 0
+    lead = list(input_int8.shape[:-1])
+    D = torch.empty(lead + [N], dtype=torch.float16, device=dev)
+    n = len(qparams)
+    _check(n <= 3 and (n > 0 or want_f16), "qlinear_ln: 1..3 quantizers or want_f16")
+    outs = [torch.empty(lead + [N], dtype=torch.int8, device=dev) for _ in range(n)]
+    out_h = torch.empty(lead + [N], dtype=torch.float16, device=dev) if want_f16 else None
+    arr = ctypes.c_void_p * max(n, 1)
+    si = arr(*[p[0].data_ptr() for p in qparams])
+    zp = arr(*[p[1].data_ptr() for p in qparams])
+    oq = arr(*[o.data_ptr() for o in outs])
+    sc, b0 = _f32vec(scale), _f32vec(bias0)
+    bs = None if bias is None else bias.contiguous()
+    g, b = ln_weight.contiguous(), ln_bias.contiguous()
+    _check(g.dtype == torch.float16 and b.dtype == torch.float16 and g.numel() == N and b.numel() == N,
+           "LayerNorm weight / bias should be fp16 [N]")
+    if residual is not None:
+        _check(residual.dtype == torch.float16 and residual.is_contiguous() and residual.numel() == M * N,
+               "residual should be contiguous fp16 [M, N]")
+    _check(workspace.is_cuda and workspace.device == dev and workspace.numel() >=
+           _lib.mixdq_qlinear_ln_workspace_bytes(M, N), "workspace too small (qlinear_ln_workspace)")
+    _record("linear_ln", M, N, K, K, False, qlinear_ln,
+            (input_int8, weight_int8, scale, bias0, bias, residual, ln_weight, ln_bias, eps, qparams, workspace),
+            dict(want_f16=want_f16, _cfg=_cfg))
+    with torch.cuda.device(dev):
+        code = _lib.mixdq_qlinear_w8a8_ln(a.data_ptr(), w.data_ptr(), b0.data_ptr(), sc.data_ptr(), _ptr(bs),
+                                          D.data_ptr(), M, N, K, _ptr(residual), 1, g.data_ptr(), b.data_ptr(),
+                                          float(eps), n, si, zp, oq, _ptr(out_h), workspace.data_ptr(),
+                                          FLAGS | (_cfg << 8), _stream())
+    _status(code, "qlinear_ln")
+    return D, outs, out_h
+
+
 def geglu_quantize(h, scale_inv=None, zero_point=None, want_f16=False):
     """h: fp16 [..., 2D] contiguous -> (int8 [..., D] or None, fp16 [..., D] or None)."""
     _check(h.is_cuda and h.dtype == torch.float16 and h.is_contiguous(),

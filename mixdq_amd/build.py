@@ -11,7 +11,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libmixdq_hip.so")
-SOURCES = ["quantize.hip", "igemm.hip", "igemm_aq.hip", "iconv.hip", "fused_norm.hip", "attention.hip"]
+SOURCES = ["quantize.hip", "igemm.hip", "igemm_aq.hip", "igemm_ln.hip", "iconv.hip", "fused_norm.hip", "attention.hip"]
 HEADERS = ["common.h", "attn_core.h", "iconv.h", "igemm_kernel.h", os.path.join("..", "..", "include", "mixdq_hip.h"),
            os.path.join("..", "..", "include", "mixdq_math.h")]
 # -ffp-contract=off: every fused multiply-add in the arithmetic specification is written
@@ -28,7 +28,8 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
 # launch (quantize on 8 elements: 1.58 -> 1.71 us).
 EXTRA = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
          "igemm.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=14"],
-         "igemm_aq.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=14"]}
+         "igemm_aq.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=14"],
+         "igemm_ln.hip": ["-mllvm", "-amdgpu-kernarg-preload-count=14"]}
 OBJ = os.path.join(PKG, "_obj")
 
 

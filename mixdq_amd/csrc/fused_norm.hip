@@ -253,16 +253,21 @@ inline bool make_gn_geom(int N, int64_t HW, int C, int G, GnGeom& g) {
 }
 
 // ------------------------------------------------------------------------------- LayerNorm
-// One wave per row.  Lane l owns the 8-element chunks l, l + 64, l + 128, ... (at most 4);
-// per-lane sequential sums, then a 6-step xor butterfly (every lane ends with the same bits).
+// One wave per row.  Lane l owns the 8-element chunks l, l + 64, l + 128, ... (at most 4).
+// The row statistics follow the tiling-independent order of oracle/mixdq_oracle.c (round 5), which the
+// GEMM epilogue of csrc/igemm_ln.hip reproduces from ONE record per row and column tile: per 16-column
+// group (a pair of neighbouring lanes) the sum and the centred sum of squares; `per` consecutive groups
+// form a unit (80 columns at C = 1280 / 640: the GEMM's column tile) whose groups are folded left to right
+// with Chan's combination (through a wave-private LDS row, one lane per unit); the U <= 16 units are
+// combined by a balanced tree (xor butterfly among lanes 0 .. U-1).
 constexpr int kLnMaxChunks = 4;   // C <= 2048
+constexpr int kLnMaxGroups = 64 * kLnMaxChunks / 2;
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off >= 1; off >>= 1) v = __fadd_rn(v, __shfl_xor(v, off, 64));
-  return v;
+// balanced tree over the values of lanes 0 .. U-1 (U a power of two <= 16); every lane returns the total
+__device__ __forceinline__ float ln_tree(float t, int U) {
+  for (int off = 1; off < U; off <<= 1) t = __fadd_rn(t, __shfl_xor(t, off, 64));
+  return __shfl(t, 0, 64);
 }
-
 // NQ: quantizers in use (0..3), WANT_H: the FP16 copy is written -- compile-time, so a launch with one
 // consumer does not run the other two quantizers' arithmetic on its one-wave-per-SIMD critical path.
 // ROWS: rows a wave carries through the chain together (all loaded up front).  The kernel is a
@@ -309,34 +314,64 @@ __global__ __launch_bounds__(256) void ln_quant_kernel(
   const float si1 = NQ > 1 ? *s_inv1 : 0.f, z1 = NQ > 1 ? *zp1 : 0.f;
   const float si2 = NQ > 2 ? *s_inv2 : 0.f, z2 = NQ > 2 ? *zp2 : 0.f;
   float mean[ROWS], rstd[ROWS];
+  __shared__ float ln_sh[4][ROWS][kLnMaxGroups + 16];
+  const int wv = threadIdx.x >> 6;
+  const int G = C / 16;
+  int U = 1;
+  while (U < 16 && G % (2 * U) == 0) U *= 2;
+  const int per = G / U;
+  const float n_u = (float)(16 * per);
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) {
-    float s = 0.f;
+    float mg[kLnMaxChunks], m2[kLnMaxChunks];
+    float* sh = ln_sh[wv][r];            // [G] group values, then [16] unit means
 #pragma unroll
     for (int i = 0; i < kLnMaxChunks; ++i) {
       const int c = lane + 64 * i;
-      if (c < nch) {
+      mg[i] = m2[i] = 0.f;
+      if (c < nch) {        // (nch is even: both lanes of a pair take the branch)
+        float s8 = half_at(h[r][i], 0);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s = __fadd_rn(s, half_at(h[r][i], j));
-      }
-    }
-    mean[r] = wave_sum(s) / (float)C;
-  }
-#pragma unroll
-  for (int r = 0; r < ROWS; ++r) {
-    float v = 0.f;
-#pragma unroll
-    for (int i = 0; i < kLnMaxChunks; ++i) {
-      const int c = lane + 64 * i;
-      if (c < nch) {
+        for (int j = 1; j < 8; ++j) s8 = __fadd_rn(s8, half_at(h[r][i], j));
+        const float s1 = __fadd_rn(s8, __shfl_xor(s8, 1, 64));      // the group's two halves
+        mg[i] = __fmul_rn(s1, 0.0625f);
+        float q8 = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float d = __fsub_rn(half_at(h[r][i], j), mean[r]);
-          v = __builtin_fmaf(d, d, v);
+          const float d = __fsub_rn(half_at(h[r][i], j), mg[i]);
+          q8 = __builtin_fmaf(d, d, q8);
         }
+        m2[i] = __fadd_rn(q8, __shfl_xor(q8, 1, 64));
+        if ((lane & 1) == 0) sh[c >> 1] = s1;
       }
     }
-    rstd[r] = 1.0f / sqrtf(__fadd_rn(wave_sum(v) / (float)C, eps));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // wave-private row: no block barrier
+    float s1u = 0.f, mu = 0.f;
+    if (lane < U) {                                                  // one lane per unit: its groups, left to right
+      s1u = sh[lane * per];
+      for (int g = 1; g < per; ++g) s1u = __fadd_rn(s1u, sh[lane * per + g]);
+      mu = s1u / n_u;
+      sh[kLnMaxGroups + lane] = mu;
+    }
+    mean[r] = ln_tree(s1u, U) / (float)C;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < kLnMaxChunks; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch && (lane & 1) == 0) {
+        const float e = __fsub_rn(mg[i], sh[kLnMaxGroups + (c >> 1) / per]);
+        sh[c >> 1] = __builtin_fmaf(__fmul_rn(e, 16.0f), e, m2[i]);
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    float du = 0.f;
+    if (lane < U) {
+      float m2u = sh[lane * per];
+      for (int g = 1; g < per; ++g) m2u = __fadd_rn(m2u, sh[lane * per + g]);
+      const float e = __fsub_rn(mu, mean[r]);
+      du = __builtin_fmaf(__fmul_rn(e, n_u), e, m2u);
+    }
+    rstd[r] = 1.0f / sqrtf(__fadd_rn(ln_tree(du, U) / (float)C, eps));
   }
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) {
@@ -529,7 +564,7 @@ extern "C" int mixdq_layernorm_quantize(const void* x, const void* gamma, const 
                                         const float* const* zero_point, int8_t* const* out_q,
                                         void* out_f16_or_null, int flags, mixdq_stream_t stream_) {
   if (M < 0 || C <= 0 || n_out < 0 || n_out > 3) return MIXDQ_ERR_INVALID_ARG;
-  if (C % 8 != 0 || C / 8 > 64 * kLnMaxChunks) return MIXDQ_ERR_SHAPE;
+  if (C % 16 != 0 || C / 8 > 64 * kLnMaxChunks) return MIXDQ_ERR_SHAPE;   // (16-column groups: the statistics' order)
   if (M == 0) return MIXDQ_OK;
   if (!x || !gamma || !beta || (n_out == 0 && !out_f16_or_null)) return MIXDQ_ERR_INVALID_ARG;
   const float* si[3] = {nullptr, nullptr, nullptr};

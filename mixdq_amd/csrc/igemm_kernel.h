@@ -97,6 +97,19 @@ struct IgemmParams {
   const float* a_sinv; const float* a_zp;
   int64_t a_ld;
   int a_rowmap;
+  // LNQ kernels: LayerNorm over the N columns of the FINAL output rows (epilogue + residual) and up to three
+  // quantizers of the normalised FP16 value -- the consumer layers' INT8 operands -- in the GEMM's own launch.
+  // The column tiles of a row block exchange per-16-column partials through `ln_part` and meet at the
+  // arrival counter `ln_cnt[2 * tile_m]` (all of them co-resident: the launcher guarantees it).
+  const __half* ln_gamma; const __half* ln_beta;
+  float ln_eps;
+  int ln_nq;
+  const float* ln_sinv[3]; const float* ln_zp[3];
+  int8_t* ln_q[3];
+  __half* ln_h;          // optional FP16 copy of the normalised rows
+  float* ln_part;        // [M][N / BN] 16-byte records: {sum, centred sum of squares, launch tag, 0} of each unit
+  int* ln_cnt;           // [0]: epoch (launches completed on this workspace), [1]: departures of the running one
+  int ln_local;          // 1: row blocks are laid out XCD by XCD and the records are first looked for in that L2
 };
 
 template <int BK>
@@ -341,6 +354,23 @@ __device__ __forceinline__ uint32_t add_f16x2(uint32_t a, uint32_t b) {
 // so staging, swizzle and fragment reads are unchanged -- all sizes (K, C, BK) are in bytes.
 // Used for the layers the reference leaves in FP16 (no activation quantizer: conv_in / conv_out,
 // the act-protected ff.net.2 ..., nn/Linear.py:155-156): D = f16(acc + bias) [+ residual].
+// LNQ: balanced tree over the values of the U (4, 8 or 16) lanes of a 16-lane row -- pairs at distance 1, 2, 4, 8,
+// the order of the LayerNorm specification -- by DPP (quad permutes, then half-row and row mirrors: after two
+// levels a quad holds one value, after three a half-row does, so a mirror reads the partner the xor would);
+// every lane of the row returns the total.  (As __shfl_xor -- ds_bpermute, the LDS crossbar -- the two
+// reductions of the row statistics took 1.9 us of the launch: tools/stamp_report.py --ln.)
+template <int CTRL>
+__device__ __forceinline__ float ln_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float ln_row_tree(float t, int U) {
+  t = __fadd_rn(t, ln_dpp<0xB1>(t));                 // quad_perm [1,0,3,2]: distance 1
+  t = __fadd_rn(t, ln_dpp<0x4E>(t));                 // quad_perm [2,3,0,1]: distance 2
+  if (U > 4) t = __fadd_rn(t, ln_dpp<0x141>(t));     // row_half_mirror: the other quad of the half-row
+  if (U > 8) t = __fadd_rn(t, ln_dpp<0x140>(t));     // row_mirror: the other half-row
+  return t;
+}
+
 // AQ: the counted wait for a slot's register loads, tied to the registers (see a_load in igemm_kernel)
 template <int N, int SLOT>
 __device__ __forceinline__ void aq_wait2(v4i& a, v4i& b) {
@@ -356,7 +386,7 @@ __device__ __forceinline__ void aq_wait4(v4i& a, v4i& b, v4i& c, v4i& d) {
 
 template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool CONV, bool FAST, bool W4,
           int KSPLIT = 1, int MT = 32, bool F16 = false, bool ATT = false, bool PHASED = false,
-          bool GROUPED = false, bool AQ = false>
+          bool GROUPED = false, bool AQ = false, bool LNQ = false>
 __global__ __launch_bounds__(
     64 * WM * WN * KSPLIT,
     (ATT ? 2 : igemm_waves_per_simd<BM, BN, BK, STAGES, WM * WN * KSPLIT,
@@ -378,6 +408,8 @@ void igemm_kernel(MIXDQ_IGEMM_HEAD_PARAMS const IgemmParams p_in) {
   // ahead of its use; the weights stay on LDS-DMA.  Fragment reads, MFMAs and epilogue are unchanged.
   static_assert(!AQ || (FAST && !CONV && !F16 && !ATT && !PHASED && !GROUPED),
                 "the quantizing activation stage is built for the Linear fast path");
+  static_assert(!LNQ || (FAST && !CONV && !F16 && !ATT && !PHASED && !GROUPED && !AQ && !W4 && BN % 16 == 0),
+                "the LayerNorm epilogue is built for the exact-fit Linear tiles");
   // every argument requested at once (common.h): 1.2-2.6 us from wave start to the first DMA before.
   // LATE_ARGS (Linear fast path with preloaded head arguments): the tile map, the per-lane staging offsets
   // and the prologue DMAs need the preloaded scalars only, so the rest of the argument block is asked
@@ -394,6 +426,12 @@ void igemm_kernel(MIXDQ_IGEMM_HEAD_PARAMS const IgemmParams p_in) {
                    p_in.grp_rows, p_in.grp_stride, p_in.grp_off, p_in.res_div, p_in.unfused,
                    p_in.g_sinv, p_in.g_zp);
     if constexpr (AQ) MIXDQ_ARGS_NOW(p_in.a_sinv, p_in.a_zp);
+    if constexpr (LNQ) {
+      MIXDQ_ARGS_NOW(p_in.ln_gamma, p_in.ln_beta, p_in.ln_eps, p_in.ln_nq, p_in.ln_h, p_in.ln_part, p_in.ln_cnt,
+                     p_in.ln_local);
+      MIXDQ_ARGS_NOW(p_in.ln_sinv[0], p_in.ln_sinv[1], p_in.ln_sinv[2], p_in.ln_zp[0], p_in.ln_zp[1], p_in.ln_zp[2],
+                     p_in.ln_q[0], p_in.ln_q[1], p_in.ln_q[2]);
+    }
     if constexpr (ATT) {
       MIXDQ_ARGS_NOW(p_in.att_k, p_in.att_v, p_in.att_k_bs, p_in.att_v_bs, p_in.att_k_rs, p_in.att_v_rs,
                      p_in.att_tkv, p_in.att_tq, p_in.att_scale_log2, p_in.att_out, p_in.att_sinv,
@@ -487,7 +525,16 @@ void igemm_kernel(MIXDQ_IGEMM_HEAD_PARAMS const IgemmParams p_in) {
   const int first_m = group * GM;
   const int gsz = min(GM, p.tiles_m - first_m);
   const int rem = wg - group * per_group;
-  const int tile_n = rem / gsz, tile_m = first_m + (rem - tile_n * gsz);
+  int tile_n = rem / gsz, tile_m = first_m + (rem - tile_n * gsz);
+  if constexpr (LNQ) {
+    // the column tiles of a row block exchange their LayerNorm records: n fastest, so that an XCD's contiguous
+    // run of the sequence holds WHOLE row blocks and the records can meet in that XCD's L2.  (Short K only --
+    // ln_local, the launcher's choice: an XCD then streams ALL of W, which cost the K = 5120 launch 3.5 us.)
+    if (p.ln_local) {
+      tile_m = wg / p.tiles_n;
+      tile_n = wg - tile_m * p.tiles_n;
+    }
+  }
   const int64_t m0 = (int64_t)tile_m * BM;
   const int n0 = tile_n * BN;
 
@@ -513,11 +560,13 @@ void igemm_kernel(MIXDQ_IGEMM_HEAD_PARAMS const IgemmParams p_in) {
   //      P_B0: bias0[n] (table mode: the full-window class row), P_SC: scale[n], P_BS: bias[n].
   bool has_bias = false, use_table = false;
   int full_cls = 0;
+  int ln_epoch = 0;        // LNQ: the workspace's launch counter (this launch's records carry ln_epoch + 1)
   v4f pre_b0, pre_sc;
   uint2 pre_bs;
   const bool pre_on = tid < BN / 4;
   const bool pre_in = n0 + tid * 4 < p.N;
   auto early_loads = [&]() {
+    if constexpr (LNQ) ln_epoch = __hip_atomic_load(p.ln_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     has_bias = p.bias != nullptr;
     use_table = p.table != nullptr;
     full_cls = (((p.R - 1)) * p.S) * p.S + (p.S - 1);   // rlo=0, rhi=R-1, slo=0, shi=S-1
@@ -1261,7 +1310,7 @@ void igemm_kernel(MIXDQ_IGEMM_HEAD_PARAMS const IgemmParams p_in) {
   //      fp16, product -> fp16, quantize) is kept: the INT8 tensor is the one mixdq_geglu_quantize
   //      produces from this GEMM's fp16 output.  ((8192, 10240, 1280) on the 256x256 tile: 117 us;
   //      142 with the fp16 tile staged through LDS and GELU computed, as round 2 did.)
-  if constexpr (BN % 32 == 0 && WTN % 32 == 0 && !CONV && !F16 && !ATT && !GROUPED && !AQ) {
+  if constexpr (BN % 32 == 0 && WTN % 32 == 0 && !CONV && !F16 && !ATT && !GROUPED && !AQ && !LNQ) {
     if (p.Dq != nullptr) {
       constexpr int QS = BN / 2 + 16;             // INT8 tile row stride (bytes)
       constexpr bool TAB = igemm_gelu_table_fits<BM, BN, BK, STAGES>();
@@ -1699,6 +1748,10 @@ void igemm_kernel(MIXDQ_IGEMM_HEAD_PARAMS const IgemmParams p_in) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) vw[e] = add_f16x2(vw[e], rw[e]);
     }
+    if constexpr (LNQ) {    // the FINAL value (residual added) back into the tile: the LayerNorm's input; the
+      *reinterpret_cast<uint4*>(Cs + row * CS_STRIDE + cc * 16) = v;   // rows leave for D behind the records
+      return;
+    }
     __half* dst = p.D + drow * p.N + n;
 #if MIXDQ_ABLATE == 4
     if (v.x == 0x12345678u && v.y == 0x9abcdef0u)      // never true in practice: stores elided
@@ -1739,6 +1792,216 @@ void igemm_kernel(MIXDQ_IGEMM_HEAD_PARAMS const IgemmParams p_in) {
     for (int idx = tid; idx < BM * CPRO; idx += NTHREADS) store_chunk(std::integral_constant<int, 0>{}, idx);
   }
   MIXDQ_STAMP_AT(7);
+  if constexpr (LNQ) {
+    // ---- LayerNorm + quantize of the rows this launch just produced (round 5).  A row's statistics need all
+    //      N columns and a tile holds BN of them -- exactly one UNIT of the LayerNorm specification
+    //      (oracle/mixdq_oracle.c: BN / 16 groups folded left to right; N / BN <= 16 units combined by a balanced
+    //      tree), so every tile publishes ONE 16-byte record per row: {sum, centred sum of squares, launch tag},
+    //      and every tile reads the N / BN records of each of its rows, combines them itself and normalises +
+    //      quantizes the BN columns it still holds in LDS.  No counter and no barrier between the tiles: a record
+    //      is valid when its tag is this launch's (the workspace's epoch + 1; the last workgroup to leave bumps
+    //      the epoch), the reader simply polls the record.  Visibility across CUs / XCDs: records are written
+    //      and read with 16-byte sc1 (write-through / L1-bypassing) accesses, one granule each (observed
+    //      untorn on gfx950, MI355X_MICROARCH.md "R2's granule needs no ordering at all").  All tiles of a row
+    //      block are resident at once (the launcher: one workgroup per CU, one round).  A first form -- per-group
+    //      8-byte partials, an arrival counter per row block -- cost three trips through the memory side and 5 K
+    //      8-byte loads per workgroup: the step got 1.1 ms SLOWER than with a LayerNorm launch of its own
+    //      (profiles/r05_ln_in_gemm.txt).  Replaces one ln_quant_kernel launch per LayerNorm of the fused graph.
+    constexpr int GPT = BN / 16;                     // 16-column groups per tile row = groups per unit
+    static_assert(GPT <= 8, "one 8-lane group computes a row's unit record");
+    const int U = p.tiles_n;                         // units per row (the launcher: N == U * BN, U <= 16)
+    const float n_u = (float)BN;
+    const int tag = ln_epoch + 1;
+    float* ln_mr = reinterpret_cast<float*>(smem + BM * CS_STRIDE);     // [BM][2]: mean, rstd (behind the tile)
+    static_assert(BM * CS_STRIDE + BM * 8 <= igemm_main_bytes<BM, BN, BK, STAGES>(), "row table fits");
+    // Two copies of every record: A, written with a PLAIN store -- it stays in the writer's XCD L2, where the
+    // other tiles of the row block find it with L1-bypassing (sc1) loads after one L2 round trip IF they run on
+    // the same XCD (the tile map above makes that the usual case: workgroups b and b + 8 share an XCD -- an
+    // observation, not a promise of the runtime); and B, written through to the memory side (sc1), which every
+    // reader on every XCD sees.  A reader polls A a few times, then B: never wrong, fast when placed as expected.
+    uint4* recs = reinterpret_cast<uint4*>(p.ln_part);
+    uint4* recs_b = recs + p.M * 16;
+    __syncthreads();                                 // the final fp16 tile is complete in Cs
+    MIXDQ_STAMP_AT(6);
+    auto halves = [](const uint4& w, float (&f)[8]) {
+      const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        __half_raw r;
+        r.x = (unsigned short)((j & 1) ? (ww[j >> 1] >> 16) : (ww[j >> 1] & 0xffffu));
+        f[j] = __half2float(__half(r));
+      }
+    };
+    {
+      const int j = tid & 7, base = lane & ~7;
+      for (int row = tid >> 3; row < BM; row += NTHREADS / 8) {
+        float s1 = 0.f, m2 = 0.f, mg = 0.f;
+        if (j < GPT) {
+          float lo[8], hi[8];
+          halves(*reinterpret_cast<const uint4*>(Cs + row * CS_STRIDE + j * 32), lo);
+          halves(*reinterpret_cast<const uint4*>(Cs + row * CS_STRIDE + j * 32 + 16), hi);
+          float sl = lo[0], sh_ = hi[0];
+#pragma unroll
+          for (int e = 1; e < 8; ++e) { sl = __fadd_rn(sl, lo[e]); sh_ = __fadd_rn(sh_, hi[e]); }
+          s1 = __fadd_rn(sl, sh_);
+          mg = __fmul_rn(s1, 0.0625f);
+          float ql = 0.f, qh = 0.f;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float dl = __fsub_rn(lo[e], mg), dh = __fsub_rn(hi[e], mg);
+            ql = __builtin_fmaf(dl, dl, ql);
+            qh = __builtin_fmaf(dh, dh, qh);
+          }
+          m2 = __fadd_rn(ql, qh);
+        }
+        float s1u = __shfl(s1, base, 64);
+#pragma unroll
+        for (int g = 1; g < GPT; ++g) s1u = __fadd_rn(s1u, __shfl(s1, base + g, 64));
+        const float mu = s1u / n_u;
+        const float e = __fsub_rn(mg, mu);
+        const float c = __builtin_fmaf(__fmul_rn(e, 16.0f), e, m2);
+        float m2u = __shfl(c, base, 64);
+#pragma unroll
+        for (int g = 1; g < GPT; ++g) m2u = __fadd_rn(m2u, __shfl(c, base + g, 64));
+        if (j == 0 && m0 + row < p.M) {
+          const v4i rec = {(int)__float_as_uint(s1u), (int)__float_as_uint(m2u), tag, 0};
+          const uint4* dst = recs + ((m0 + row) * U + tile_n);
+          const uint4* dst_b = recs_b + ((m0 + row) * U + tile_n);
+          asm volatile("global_store_dwordx4 %0, %2, off\n\tglobal_store_dwordx4 %1, %2, off sc1\n\ts_nop 1"
+                       ::"v"(dst), "v"(dst_b), "v"(rec) : "memory");
+        }
+      }
+    }
+    // the output rows leave now, under the records' way to the other tiles (in front of them they put ~1 us of
+    // store traffic between the last MFMA and the first record)
+    for (int idx2 = tid; idx2 < BM * CPRO; idx2 += NTHREADS) {
+      const int row = idx2 / CPRO, cc = idx2 - row * CPRO;
+      if (m0 + row >= p.M) continue;
+      const uint4 v = *reinterpret_cast<const uint4*>(Cs + row * CS_STRIDE + cc * 16);
+      const v4i vv = {(int)v.x, (int)v.y, (int)v.z, (int)v.w};
+      __builtin_nontemporal_store(vv, reinterpret_cast<v4i*>(p.D + (m0 + row) * p.N + n0 + cc * 8));
+    }
+    MIXDQ_STAMP_AT(10);
+    // gamma / beta of this thread's chunks and the quantizers' scalars: requested now, they land during the exchange
+    uint4 gmv[ST_ITERS], btv[ST_ITERS];
+#pragma unroll
+    for (int it = 0; it < ST_ITERS; ++it) {
+      const int idx2 = min(tid + it * NTHREADS, BM * CPRO - 1);
+      const int cc = idx2 % CPRO;
+      gmv[it] = *reinterpret_cast<const uint4*>(p.ln_gamma + n0 + cc * 8);
+      btv[it] = *reinterpret_cast<const uint4*>(p.ln_beta + n0 + cc * 8);
+    }
+    float qs[3] = {0.f, 0.f, 0.f}, qz[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if (k < p.ln_nq) { qs[k] = *p.ln_sinv[k]; qz[k] = *p.ln_zp[k]; }
+    // ---- the rows' U records: 16 lanes per row, lane u polls unit u's record until it carries this launch's
+    //      tag.  A thread's RPT rows are requested together (one trip through the memory side, not RPT).
+    {
+      constexpr int RPT = BM / (NTHREADS / 16);      // rows per thread: 2 (64-row tiles), 4 (128-row tiles)
+      static_assert(RPT == 2 || RPT == 4, "poll loads are written for 2 or 4 rows per thread");
+      const int u = tid & 15;
+      bool live[RPT], ok[RPT];
+      const uint4* src[RPT];
+      v4i rec[RPT];
+      const int kTryLocal = p.ln_local ? 12 : 0;     // polls of the L2-resident copy before the written-through one
+      int64_t rec_i[RPT];
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        const int row = (tid >> 4) + r * (NTHREADS / 16);
+        live[r] = u < U && m0 + row < p.M;
+        rec_i[r] = (m0 + (m0 + row < p.M ? row : 0)) * U + (u < U ? u : 0);
+        src[r] = recs + rec_i[r];
+        ok[r] = !live[r];
+      }
+      for (int spins = 0; spins < (1 << 18); ++spins) {
+        if (spins == kTryLocal) {
+#pragma unroll
+          for (int r = 0; r < RPT; ++r) src[r] = recs_b + rec_i[r];
+        }
+        if constexpr (RPT == 2)
+          asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                       : "=&v"(rec[0]), "=&v"(rec[1]) : "v"(src[0]), "v"(src[1]) : "memory");
+        else
+          asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
+                       "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                       : "=&v"(rec[0]), "=&v"(rec[1]), "=&v"(rec[2]), "=&v"(rec[3])
+                       : "v"(src[0]), "v"(src[1]), "v"(src[2]), "v"(src[3]) : "memory");
+        bool all_ok = true;
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) {
+          ok[r] = !live[r] || rec[r][2] == tag;
+          all_ok = all_ok && ok[r];
+        }
+        if (__builtin_amdgcn_ballot_w64(!all_ok) == 0) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+      MIXDQ_STAMP_AT(11);
+#pragma unroll
+      for (int r = 0; r < RPT; ++r) {
+        const int row = (tid >> 4) + r * (NTHREADS / 16);
+        // (a record that never arrived -- a lost workgroup; bounded, not a hang -- poisons the row: NaN out)
+        const float s1u = live[r] ? (ok[r] ? __uint_as_float((unsigned)rec[r][0]) : __uint_as_float(0x7fc00000u)) : 0.f;
+        const float m2u = live[r] ? __uint_as_float((unsigned)rec[r][1]) : 0.f;
+        const float mean = ln_row_tree(s1u, U) / (float)p.N;
+        const float e = __fsub_rn(s1u / n_u, mean);
+        const float t2 = ln_row_tree(__builtin_fmaf(__fmul_rn(e, n_u), e, m2u), U);
+        const float rstd = 1.0f / sqrtf(__fadd_rn(t2 / (float)p.N, p.ln_eps));
+        if (u == 0) { ln_mr[2 * row] = mean; ln_mr[2 * row + 1] = rstd; }
+      }
+    }
+    __syncthreads();
+    MIXDQ_STAMP_AT(14);
+    // ---- normalise + quantize the tile's own columns, whole 8-column chunks per thread
+    const bool unf = p.unfused != 0;
+    igemm_unrolled<ST_ITERS>([&](auto it_c) {
+      constexpr int it = decltype(it_c)::value;
+      const int idx2 = tid + it * NTHREADS;
+      if (idx2 >= BM * CPRO) return;
+      const int row = idx2 / CPRO, cc = idx2 - row * CPRO;
+      const int64_t m = m0 + row;
+      if (m >= p.M) return;
+      float x[8], gm[8], bt[8];
+      halves(*reinterpret_cast<const uint4*>(Cs + row * CS_STRIDE + cc * 16), x);
+      halves(gmv[it], gm);
+      halves(btv[it], bt);
+      const float mean = ln_mr[2 * row], rstd = ln_mr[2 * row + 1];
+      float y[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float nrm = __fmul_rn(__fsub_rn(x[j], mean), rstd);
+        y[j] = __half2float(f32_to_f16_rn(__builtin_fmaf(nrm, gm[j], bt[j])));
+      }
+      const int64_t off = m * p.N + n0 + cc * 8;
+      if (p.ln_h != nullptr) {
+        uint32_t hw[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          hw[j] = (uint32_t)__half_as_ushort(f32_to_f16_rn(y[2 * j])) |
+                  ((uint32_t)__half_as_ushort(f32_to_f16_rn(y[2 * j + 1])) << 16);
+        *reinterpret_cast<uint4*>(p.ln_h + off) = make_uint4(hw[0], hw[1], hw[2], hw[3]);
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        if (k >= p.ln_nq) break;
+        uint32_t pk[2] = {0u, 0u};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int qv = unf ? quantize_one<true>(y[j], qs[k], qz[k]) : quantize_one<false>(y[j], qs[k], qz[k]);
+          pk[j >> 2] |= (uint32_t)(qv & 0xff) << (8 * (j & 3));
+        }
+        *reinterpret_cast<uint2*>(p.ln_q[k] + off) = make_uint2(pk[0], pk[1]);
+      }
+    });
+    MIXDQ_STAMP_AT(15);
+    // ---- departures: the last workgroup of the launch to get here bumps the epoch (the next launch's tag)
+    if (tid == 0) {
+      if (__hip_atomic_fetch_add(p.ln_cnt + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nwg - 1) {
+        __hip_atomic_store(p.ln_cnt + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(p.ln_cnt, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
 }
 
 // m-tiles per super-row of the blockIdx -> tile map: 8 (super-rows of 1, 2, 4, 16 measured equal or worse
@@ -1753,9 +2016,12 @@ inline int tile_map_gm() {
 }
 
 template <int BM, int BN, int BK, int STAGES, int WM, int WN, bool CONV, bool FAST, bool W4, int KSPLIT,
-          int MT, bool F16 = false, bool PHASED = false, bool GROUPED = false, bool AQ = false>
+          int MT, bool F16 = false, bool PHASED = false, bool GROUPED = false, bool AQ = false, bool LNQ = false>
 int launch_kernel(IgemmParams& p, hipStream_t stream) {
-  constexpr int SMEM = igemm_smem_bytes<BM, BN, BK, STAGES>();
+  // (LNQ: the LDS request is padded past half a CU's LDS, so that no two workgroups share a CU: the tiles of a
+  //  row block wait for each other, and the cross-CU hand-off form they use is the one-workgroup-per-CU one)
+  constexpr int SMEM = LNQ && igemm_smem_bytes<BM, BN, BK, STAGES>() < 82 * 1024
+                           ? 82 * 1024 : igemm_smem_bytes<BM, BN, BK, STAGES>();
   static_assert(SMEM <= 160 * 1024, "LDS is 160 KiB per CU");
   if (p.Dq != nullptr && (BN % 32 != 0 || (BN / WN) % 32 != 0))        // whole value|gate groups per tile, per wave
     return MIXDQ_ERR_GEGLU_SHAPE;
@@ -1763,7 +2029,7 @@ int launch_kernel(IgemmParams& p, hipStream_t stream) {
     static bool seen[64] = {};
     if (const int st = lds_opt_in(
             reinterpret_cast<const void*>(
-                &igemm_kernel<BM, BN, BK, STAGES, WM, WN, CONV, FAST, W4, KSPLIT, MT, F16, false, PHASED, GROUPED, AQ>),
+                &igemm_kernel<BM, BN, BK, STAGES, WM, WN, CONV, FAST, W4, KSPLIT, MT, F16, false, PHASED, GROUPED, AQ, LNQ>),
             SMEM, seen))
       return st;
   }
@@ -1774,7 +2040,13 @@ int launch_kernel(IgemmParams& p, hipStream_t stream) {
   if (grid <= 0 || grid > 0x7fffffff || p.tiles_m >= (1 << 24)) return MIXDQ_ERR_INVALID_ARG;
   const int ny = GROUPED ? p.ngroups_launch : 1;
   if (GROUPED != (p.groups != nullptr)) return MIXDQ_ERR_INVALID_ARG;
-  igemm_kernel<BM, BN, BK, STAGES, WM, WN, CONV, FAST, W4, KSPLIT, MT, F16, false, PHASED, GROUPED, AQ>
+  if constexpr (LNQ) {   // every tile of a row block must be resident at once: one workgroup per CU, one round
+    // ... and a column tile must be exactly one unit of the LayerNorm's reduction order
+    int units = 1;
+    while (units < 16 && (p.N / 16) % (2 * units) == 0) units *= 2;
+    if (grid > kNumCU || p.N % BN != 0 || p.N / BN != units) return MIXDQ_ERR_SHAPE;
+  }
+  igemm_kernel<BM, BN, BK, STAGES, WM, WN, CONV, FAST, W4, KSPLIT, MT, F16, false, PHASED, GROUPED, AQ, LNQ>
       <<<dim3((unsigned)grid, (unsigned)ny), 64 * WM * WN * KSPLIT, SMEM, stream>>>(MIXDQ_IGEMM_HEAD_ARGS(p) p);
   return launch_status();
 }
@@ -1810,6 +2082,15 @@ int launch_tile_aq(IgemmParams& p, hipStream_t stream) {
                       (uint64_t)p.N * (uint64_t)p.Ktot < (1ull << 32);
   if (p.Ktot % BK != 0 || !fits32) return MIXDQ_ERR_SHAPE;
   return launch_kernel<BM, BN, BK, STAGES, WM, WN, false, true, W4, KSPLIT, MT, false, false, false, true>(p, stream);
+}
+
+// LNQ launches (GEMM + residual + LayerNorm + quantize): the Linear fast path on an exact-fit tile.
+template <int BM, int BN, int BK, int STAGES, int WM, int WN, int KSPLIT, int MT>
+int launch_tile_ln(IgemmParams& p, hipStream_t stream) {
+  const bool fits32 = (uint64_t)p.M * (uint64_t)p.Ktot < (1ull << 32) &&
+                      (uint64_t)p.N * (uint64_t)p.Ktot < (1ull << 32);
+  if (p.Ktot % BK != 0 || !fits32) return MIXDQ_ERR_SHAPE;
+  return launch_kernel<BM, BN, BK, STAGES, WM, WN, false, true, false, KSPLIT, MT, false, false, false, false, true>(p, stream);
 }
 
 }  // namespace

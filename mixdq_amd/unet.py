@@ -250,9 +250,18 @@ def _ln_feed(norm: nn.LayerNorm, x, consumers):
     Returns a list of (tensor, quantized?) aligned with `consumers`."""
     from mixdq_amd import _C
     C = x.shape[-1]
-    if not (_fusable_f16(x) and x.is_contiguous() and C % 8 == 0 and C <= 2048):
+    if not (_fusable_f16(x) and x.is_contiguous() and C % 16 == 0 and C <= 2048):
         h = norm(x)
         return [(h, False)] * len(consumers)
+    groups, slot = _ln_plan(norm, consumers)
+    want_f16 = any(s < 0 for s in slot)
+    outs, h = _C.layernorm_quantize(x, norm.weight, norm.bias, norm.eps, groups, want_f16=want_f16)
+    return [((outs[s], True) if s >= 0 else (h, False)) for s in slot]
+
+
+def _ln_plan(norm, consumers):
+    """(distinct (scale_inv, zero_point) pairs among the accelerated consumers, slot of each consumer in that
+    list or -1 for one that takes the FP16 tensor) -- cached on the norm, re-derived when the layers change."""
     acc = [c for c in consumers if _accel(c)]
     ids = _quantizer_groups(_memo(norm), "ln", acc)
     plan = norm.__dict__.get("_mixdq_plan")
@@ -270,10 +279,45 @@ def _ln_feed(norm: nn.LayerNorm, x, consumers):
         # weights) alive until the next forward
         plan = norm.__dict__["_mixdq_plan"] = (tuple(weakref.ref(c) for c in consumers),
                                                [_qp(groups[g]) for g in sorted(groups)], slot, ids)
-    _, groups, slot, _ = plan
-    want_f16 = any(s < 0 for s in slot)
-    outs, h = _C.layernorm_quantize(x, norm.weight, norm.bias, norm.eps, groups, want_f16=want_f16)
-    return [((outs[s], True) if s >= 0 else (h, False)) for s in slot]
+    return plan[1], plan[2]
+
+
+def _ln_workspace(owner, M, N, device):
+    """The exchange buffer of the GEMM + LayerNorm launches of one network (zeroed once; every launch leaves
+    its counters at zero): kept on `owner` (the SDXLUNet, whose launches run one at a time on one stream),
+    per device, grown when a larger problem comes along."""
+    from mixdq_amd import _C
+    store = owner.__dict__.setdefault("_ln_ws", {})
+    need = int(_C._lib.mixdq_qlinear_ln_workspace_bytes(int(M), int(N)))
+    ws = store.get(device)
+    if ws is None or ws.numel() < need:
+        ws = store[device] = _C.qlinear_ln_workspace(M, N, device)
+    return ws
+
+
+def _gemm_res_ln(layer, x_int, residual, next_ln):
+    """residual + layer(x_int) for an already quantized operand, AND -- when `next_ln` = (norm, consumers,
+    owner) names the LayerNorm that reads the result -- that LayerNorm's feeds (as `_ln_feed` returns them):
+    ONE launch where the GEMM + LayerNorm kernel takes the shape (mixdq_qlinear_w8a8_ln: the column tiles of
+    a row block exchange their partial statistics), else the GEMM followed by the LayerNorm launch.  The
+    bits are the same either way.  Returns (y, feeds or None)."""
+    from mixdq_amd import _C
+    if next_ln is None:
+        return layer.forward_quantized(x_int, residual=residual), None
+    norm, consumers, owner = next_ln
+    N, K = layer.out_features, layer.in_features
+    M = x_int.numel() // K
+    if (not DEFUSE and _accel(layer) and not layer.w_packed4 and x_int.dtype == torch.int8
+            and (residual is None or residual.is_contiguous())
+            and norm.weight.dtype == torch.float16 and _C.qlinear_ln_supported(M, N, K)):
+        groups, slot = _ln_plan(norm, consumers)
+        want_f16 = any(s_ < 0 for s_ in slot)
+        y, outs, h = _C.qlinear_ln(x_int, layer.weight_int, layer.scale, layer.bias0, layer.bias, residual,
+                                   norm.weight, norm.bias, norm.eps, groups,
+                                   _ln_workspace(owner, M, N, x_int.device), want_f16=want_f16)
+        return y, [((outs[s_], True) if s_ >= 0 else (h, False)) for s_ in slot]
+    y = layer.forward_quantized(x_int, residual=residual)
+    return y, _ln_feed(norm, y, consumers)
 
 
 def _run(layer, feed, residual=None):
@@ -464,7 +508,7 @@ class Attention(nn.Module):
         o = F.scaled_dot_product_attention(q, k, v)   # FP16, as in the reference
         return o.transpose(1, 2).reshape(B, T, C)
 
-    def cross_attend_out(self, feed_q, k, v, residual):
+    def cross_attend_out(self, feed_q, k, v, residual, next_ln=None):
         """residual + to_out[0](attention(to_q(feed_q), k, v)) for the cross-attention, whose keys /
         values (77 text tokens) fit one workgroup's LDS: to_q's INT8 GEMM, the attention core and
         to_out.0's quantizer are ONE launch; q never exists in memory.  Bit-identical to the
@@ -474,10 +518,10 @@ class Attention(nn.Module):
             q, out = self.to_q, self.to_out[0]
             o_int = _C.qlinear_attention(feed_q[0], q.weight_int4 if q.w_packed4 else q.weight_int,
                                          q.scale, q.bias0, k, v, *_qp(out), _w4=q.w_packed4)
-            return out.forward_quantized(o_int, residual=residual)
-        return self.attend_out(_run(self.to_q, feed_q), k, v, residual)
+            return _gemm_res_ln(out, o_int, residual, next_ln)
+        return self.attend_out(_run(self.to_q, feed_q), k, v, residual, next_ln=next_ln)
 
-    def attend_out(self, q, k, v, residual, prefetch=None):
+    def attend_out(self, q, k, v, residual, prefetch=None, next_ln=None):
         """residual + to_out[0](attention(q, k, v)) on the fused path: the HIP FP16 attention core
         reads q/k/v in place (column slices of the fused projection included) and, when to_out[0]
         is W8A8, emits its INT8 operand directly; the residual add rides in the GEMM epilogue."""
@@ -487,15 +531,20 @@ class Attention(nn.Module):
         ok = (C == self.heads * 64 and all(_fusable_f16(t) and t.dim() == 3 and t.stride(-1) == 1
                                            and t.stride(0) % 8 == 0 and t.stride(1) % 8 == 0
                                            and t.data_ptr() % 16 == 0 for t in (q, k, v)))
+        def plain(y):          # (y, feeds of the LayerNorm that reads y) by two launches
+            return y, (None if next_ln is None else _ln_feed(next_ln[0], y, next_ln[1]))
         if not ok:
-            return _linear_res(out, self.attend(q, k, v), residual)
+            return plain(_linear_res(out, self.attend(q, k, v), residual))
         if _accel(out) and residual.is_contiguous():
             o_int = _C.attention_f16(q, k, v, self.heads, *_qp(out), _prefetch=prefetch)
-            return out.forward_quantized(o_int, residual=residual)
-        return _linear_res(out, _C.attention_f16(q, k, v, self.heads, _prefetch=prefetch), residual)
+            return _gemm_res_ln(out, o_int, residual, next_ln)
+        return plain(_linear_res(out, _C.attention_f16(q, k, v, self.heads, _prefetch=prefetch), residual))
 
 
 CROSS_FUSE_MAX_ROWS = int(__import__("os").environ.get("MIXDQ_CROSS_FUSE_MAX_ROWS", "4096"))
+# LayerNorms in the epilogue of the GEMM that produces their input (csrc/igemm_ln.hip); 0: every LayerNorm a
+# launch of its own, as in round 4 (A/B runs)
+LN_CHAIN = __import__("os").environ.get("MIXDQ_LN_CHAIN", "1") != "0"
 # weight prefetch from the self-attention launch: on for launches of up to this many rows
 PREFETCH = __import__("os").environ.get("MIXDQ_PREFETCH", "1") != "0"
 PREFETCH_MAX_ROWS = int(__import__("os").environ.get("MIXDQ_PREFETCH_MAX_ROWS", "0"))      # 0: no limit (see _build_prefetch_plan)
@@ -632,11 +681,20 @@ class FeedForward(nn.Module):
         proj.permute_output_rows_(perm)
         self.__dict__["_interleaved"] = on
 
-    def forward_fused(self, feed, residual):
+    def forward_fused(self, feed, residual, next_ln=None):
         """residual + net2(geglu(proj(feed))): GEGLU fused with net.2's quantizer, the residual add
-        folded into net.2's epilogue."""
+        folded into net.2's epilogue.  With `next_ln` (the LayerNorm that reads the result: the next
+        block's norm1) returns (y, that LayerNorm's feeds), the LayerNorm riding in net.2's launch where
+        the GEMM + LayerNorm kernel takes the shape (`_gemm_res_ln`)."""
         from mixdq_amd import _C
         out_layer = self.net[2]
+        if next_ln is not None:
+            y = self.forward_fused(feed, residual) if (DEFUSE or not self.__dict__.get("_interleaved")) else None
+            if y is not None:
+                return y, _ln_feed(next_ln[0], y, next_ln[1])
+            assert feed[1], "interleaved rows need the quantized feed"
+            q = self.net[0].proj.forward_quantized_geglu(feed[0], out_layer)
+            return _gemm_res_ln(out_layer, q, residual, next_ln)
         if self.__dict__.get("_interleaved") and not DEFUSE:
             assert feed[1], "interleaved rows need the quantized feed"
             q = self.net[0].proj.forward_quantized_geglu(feed[0], out_layer)
@@ -696,23 +754,33 @@ class BasicTransformerBlock(nn.Module):
             pack = self.__dict__["_qkv"] = _pack_rows(layers)
         return pack
 
-    def forward_fused(self, x, context):
+    def ln1_consumers(self):
+        a = self.attn1
+        return [a.to_q, a.to_k, a.to_v]
+
+    def forward_fused(self, x, context, feeds1=None, next_ln=None, owner=None):
+        """`feeds1`: norm1's feeds when the GEMM that produced x already computed them (`_gemm_res_ln`);
+        `next_ln`: the LayerNorm that reads this block's output (the next block's norm1) -- then returns
+        (x, its feeds); `owner`: the module that keeps the GEMM + LayerNorm exchange buffer (None: the
+        LayerNorms of this block run as launches of their own)."""
         x = x.contiguous()
         a = self.attn1
         pack = self._qkv_fused()
-        feeds = _ln_feed(self.norm1, x, [a.to_q, a.to_k, a.to_v])
+        feeds = feeds1 if feeds1 is not None else _ln_feed(self.norm1, x, self.ln1_consumers())
+        ln2 = None if owner is None else (self.norm2, [self.attn2.to_q], owner)
+        ln3 = None if owner is None else (self.norm3, [self.ff.net[0].proj], owner)
         if pack is not None and feeds[0][1]:
             from mixdq_amd.op.qlinear import qlinear
             q0 = a.to_q
             qkv = qlinear(feeds[0][0], pack["w"], pack["wscale"], q0.act_scales, q0.act_zero_points,
                           pack["wsum"], pack["scale"], pack["bias0"], None, _w4=pack["w4"])
             C = pack["C"]
-            x = a.attend_out(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], x)
+            x, f2 = a.attend_out(qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:], x, next_ln=ln2)
         else:
             fq, fk, fv = feeds                                      # x + attn1(norm1(x))
-            x = a.attend_out(_run(a.to_q, fq), _run(a.to_k, fk), _run(a.to_v, fv), x)
+            x, f2 = a.attend_out(_run(a.to_q, fq), _run(a.to_k, fk), _run(a.to_v, fv), x, next_ln=ln2)
         a = self.attn2
-        (fq,) = _ln_feed(self.norm2, x, [a.to_q])
+        (fq,) = f2 if f2 is not None else _ln_feed(self.norm2, x, [a.to_q])
         kv = self.__dict__.pop("_kv", None)
         if kv is not None:          # projected ahead of time (SDXLUNet._project_context_ahead)
             k, v, ready = kv
@@ -722,9 +790,11 @@ class BasicTransformerBlock(nn.Module):
                 v.record_stream(torch.cuda.current_stream())
         else:
             k, v = a.to_k(context), a.to_v(context)                 # K/V: BOS path
-        x = a.cross_attend_out(fq, k, v, x)                         # x + attn2(norm2(x), ctx)
-        (ff,) = _ln_feed(self.norm3, x, [self.ff.net[0].proj])
-        return self.ff.forward_fused(ff, x)                         # x + ff(norm3(x))
+        x, f3 = a.cross_attend_out(fq, k, v, x, next_ln=ln3)        # x + attn2(norm2(x), ctx)
+        (ff,) = f3 if f3 is not None else _ln_feed(self.norm3, x, [self.ff.net[0].proj])
+        if next_ln is None:
+            return self.ff.forward_fused(ff, x)                     # x + ff(norm3(x))
+        return self.ff.forward_fused(ff, x, next_ln=next_ln)        # ... and the next block's norm1 feeds
 
 
 class Transformer2DModel(nn.Module):
@@ -744,9 +814,29 @@ class Transformer2DModel(nn.Module):
         if self.fused and _fusable_f16(x) and x.is_contiguous(memory_format=torch.channels_last):
             feed, q = _gn_feed(self.norm, x, self.proj_in, silu=False)
             feed = feed.permute(0, 2, 3, 1).reshape(B, H * W, C)    # NHWC memory == [B, HW, C]
-            h = _run(self.proj_in, (feed, q))
-            for blk in self.transformer_blocks:
-                h = blk(h, context)
+            blocks = list(self.transformer_blocks)
+            owner = self.__dict__.get("_ln_owner")
+            chain = (LN_CHAIN and owner is not None and not DEFUSE and blocks
+                     and all(getattr(b, "fused", False) for b in blocks))
+            if chain:
+                # every LayerNorm rides in the launch of the GEMM that produces its input (round 5):
+                # proj_in -> block 0's norm1, attn1.to_out.0 -> norm2, attn2.to_out.0 -> norm3,
+                # ff.net.2 -> the next block's norm1
+                first = (blocks[0].norm1, blocks[0].ln1_consumers(), owner)
+                if q and _accel(self.proj_in):
+                    h, feeds = _gemm_res_ln(self.proj_in, feed, None, first)
+                else:
+                    h = _run(self.proj_in, (feed, q))
+                    feeds = None
+                for i, blk in enumerate(blocks):
+                    nxt = blocks[i + 1] if i + 1 < len(blocks) else None
+                    nl = None if nxt is None else (nxt.norm1, nxt.ln1_consumers(), owner)
+                    out = blk.forward_fused(h, context, feeds1=feeds, next_ln=nl, owner=owner)
+                    h, feeds = out if nl is not None else (out, None)
+            else:
+                h = _run(self.proj_in, (feed, q))
+                for blk in blocks:
+                    h = blk(h, context)
             res_rows = res.permute(0, 2, 3, 1).reshape(B, H * W, C)
             h = _linear_res(self.proj_out, h, res_rows)             # proj_out(h) + res
             return h.reshape(B, H, W, C).permute(0, 3, 1, 2)
@@ -1111,6 +1201,9 @@ class SDXLUNet(nn.Module):
                     and len(set(_quantizer_groups(_memo(blk), "kv", kv))) == 1
                     and unify_packed_storage_(kv)):
                 self._kv_pack(blk)
+        for m in self.modules():            # the network that keeps the GEMM + LayerNorm exchange buffer
+            if isinstance(m, Transformer2DModel):
+                m.__dict__["_ln_owner"] = self
         # the GELU table of the GEMM+GEGLU launches is built here, eagerly: a first use inside a stream
         # capture could only RECORD its init kernel into that graph (csrc/igemm_kernel.h ensure_gelu_table)
         dev = next((b.device for b in self.buffers() if b.is_cuda), None)

@@ -372,28 +372,86 @@ int mixdq_oracle_groupnorm_silu_quantize(const uint16_t* x, const uint16_t* gamm
 
 /* ln_quant_kernel: one 64-lane wave per row, lane l owns chunks l, l+64, ...; xor butterfly. */
 
+/* LayerNorm + quantize.  The row statistics follow a reduction order that does not depend on how a kernel
+ * tiles the row (round 5): csrc/fused_norm.hip's one-wave-per-row kernel and the GEMM epilogue of
+ * csrc/igemm_ln.hip -- where the 16 column tiles of a row block each hold 80 of the 1280 columns and
+ * exchange ONE record per row and tile -- produce the same bits.
+ *   group g = columns 16g .. 16g+15 (C % 16 == 0):
+ *     S1_g = (x0 + .. + x7) + (x8 + .. + x15)      each half summed left to right, FP32
+ *     m_g  = S1_g / 16                              (exact)
+ *     M2_g = (sum_{j<8} d_j^2) + (sum_{j>=8} d_j^2),  d_j = x_j - m_g, each half an fmaf chain from 0
+ *   unit u = `per` consecutive groups, U = (largest power of two <= 16 dividing G = C / 16) units per row
+ *   (C = 1280: 16 units of 5 groups = 80 columns, the GEMM's column tile; C = 640: 8 such units):
+ *     S1_u = S1_g summed left to right;   m_u = S1_u / (16 per)
+ *     M2_u = sum, left to right, of fmaf(16 (m_g - m_u), m_g - m_u, M2_g)        (Chan's combination)
+ *   row: the U unit values combined by a balanced binary tree (pairs at distance 1, 2, 4, 8):
+ *     mean = tree(S1_u) / C
+ *     var  = tree( fmaf(16 per (m_u - mean), m_u - mean, M2_u) ) / C
+ *     rstd = 1 / sqrtf(var + eps)
+ *   y = f16( fmaf((x - mean) * rstd, gamma, beta) ), each quantizer applied to y. */
+static int ln_units(int G) {
+  int u = 1;
+  while (u < 16 && G % (2 * u) == 0) u *= 2;
+  return u;
+}
+
+static float ln_tree(float* a, int U) {
+  for (int off = 1; off < U; off *= 2) {
+    float b[16];
+    for (int i = 0; i < U; i++) b[i] = a[i] + a[i ^ off];
+    for (int i = 0; i < U; i++) a[i] = b[i];
+  }
+  return a[0];
+}
+
 void mixdq_oracle_layernorm_quantize(const uint16_t* x, const uint16_t* gamma, const uint16_t* beta,
                                      float eps, int64_t M, int C, int n_out, const float* s_inv,
                                      const float* zp, int8_t** out_q, uint16_t* out_h,
                                      int variant) {
-  const int nch = C / 8;
+  const int G = C / 16, U = ln_units(G > 0 ? G : 1), per = (G > 0 ? G : 1) / U;
+  const float n_u = (float)(16 * per);
   for (int64_t r = 0; r < M; r++) {
     const uint16_t* xr = x + r * C;
-    float part[64];
-    for (int l = 0; l < 64; l++) {
-      float s = 0;
-      for (int c = l; c < nch; c += 64)
-        for (int j = 0; j < 8; j++) s = s + h2f(xr[8 * c + j]);
-      part[l] = s;
+    float s1u[16], m2u[16], mu[16];
+    for (int u = 0; u < U; u++) {
+      float s1g[128], m2g[128];           /* per <= 128 (C <= 2048 in the kernels; any C here up to 32768) */
+      for (int k = 0; k < per; k++) {
+        const uint16_t* xg = xr + 16 * (u * per + k);
+        float half[2];
+        for (int h = 0; h < 2; h++) {
+          float t = h2f(xg[8 * h]);
+          for (int j = 1; j < 8; j++) t = t + h2f(xg[8 * h + j]);
+          half[h] = t;
+        }
+        s1g[k] = half[0] + half[1];
+        const float mg = s1g[k] * 0.0625f;
+        for (int h = 0; h < 2; h++) {
+          float t = 0;
+          for (int j = 0; j < 8; j++) { float d = h2f(xg[8 * h + j]) - mg; t = fmaf(d, d, t); }
+          half[h] = t;
+        }
+        m2g[k] = half[0] + half[1];
+      }
+      float t = s1g[0];
+      for (int k = 1; k < per; k++) t = t + s1g[k];
+      s1u[u] = t;
+      mu[u] = t / n_u;
+      float q = 0;
+      for (int k = 0; k < per; k++) {
+        const float e = s1g[k] * 0.0625f - mu[u];
+        const float c = fmaf(e * 16.0f, e, m2g[k]);
+        q = k == 0 ? c : q + c;
+      }
+      m2u[u] = q;
     }
-    const float mean = wave_sum64(part) / (float)C;
-    for (int l = 0; l < 64; l++) {
-      float v = 0;
-      for (int c = l; c < nch; c += 64)
-        for (int j = 0; j < 8; j++) { float d = h2f(xr[8 * c + j]) - mean; v = fmaf(d, d, v); }
-      part[l] = v;
+    float a[16];
+    for (int u = 0; u < U; u++) a[u] = s1u[u];
+    const float mean = ln_tree(a, U) / (float)C;
+    for (int u = 0; u < U; u++) {
+      const float e = mu[u] - mean;
+      a[u] = fmaf(e * n_u, e, m2u[u]);
     }
-    const float rstd = 1.0f / sqrtf(wave_sum64(part) / (float)C + eps);
+    const float rstd = 1.0f / sqrtf(ln_tree(a, U) / (float)C + eps);
     for (int c = 0; c < C; c++) {
       volatile float nrm = (h2f(xr[c]) - mean) * rstd;
       float y = rh(fmaf(nrm, h2f(gamma[c]), h2f(beta[c])));

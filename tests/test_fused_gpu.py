@@ -441,3 +441,102 @@ def test_split_shortcut_on_unconcatenated_halves(C, modules_golden):
     assert torch.equal(y, yp) and torch.equal(y, ypq)
     want = modules_golden["conv_split.out"]
     assert np.array_equal(yp.contiguous().cpu().numpy().view(np.uint16), want.view(np.uint16))
+
+
+# --------------------------------------------------------- GEMM + residual + LayerNorm + quantize (round 5)
+LN_GEMM_CASES = [  # M, N, K, residual, bias, nq, want_f16, expected tile id
+    (1024, 1280, 1280, True, True, 1, False, 56),      # attn.to_out.0 -> norm2 / norm3
+    (1024, 1280, 1280, True, True, 3, True, 56),       # ff.net.2 -> the next block's norm1 (q, k, v quantizers)
+    (1024, 1280, 5120, True, True, 1, False, 45),      # ff.net.2 at 1280 channels
+    (1024, 1280, 1280, False, True, 2, False, 56),     # proj_in -> norm1 (no residual)
+    (4096, 640, 640, True, True, 1, False, 44),
+    (4096, 640, 2560, True, False, 3, False, 44),
+    (2048, 1280, 1280, True, True, 1, True, 44),       # batch 2 at 1280 channels: 128-row tiles
+    (1000, 1280, 1280, True, True, 2, False, 56),      # ragged last row tile
+    (77, 640, 640, True, True, 0, True, 56),           # FP16 copy only
+    (1024, 1280, 1280, True, False, 2, True, 56),
+]
+
+
+@pytest.mark.parametrize("M,N,K,res,bias,nq,want_h,cfg", LN_GEMM_CASES)
+def test_qlinear_ln_equals_gemm_then_layernorm_quantize(C, oracle, M, N, K, res, bias, nq, want_h, cfg):
+    """mixdq_qlinear_w8a8_ln (csrc/igemm_ln.hip): ONE launch == mixdq_qlinear_w8a8_rows (+ residual) followed by
+    mixdq_layernorm_quantize, bit for bit -- the FP16 rows, every INT8 tensor, the FP16 LayerNorm copy -- and
+    == the oracle's chain.  The launch runs twice on one exchange buffer (records are told apart by the launch
+    tag the buffer counts up), and once more after a launch of another shape."""
+    assert C._lib.mixdq_qlinear_ln_select_id(M, N, K) == (cfg if K <= 1280 else -1)   # long K: two launches by rule
+    a, w = dd.int8(701, (M, K)), dd.int8(702, (N, K))
+    b0, sc = dd.f32(703, (N,), -500, 500), dd.f32(704, (N,), 2e-5, 6e-5)
+    bs = dd.f16(705, (N,), -1, 1) if bias else None
+    r = dd.normal_f16(706, (M, N), 1.5) if res else None
+    gamma = (dd.normal_f16(707, (N,), 0.3).astype(np.float32) + 1).astype(np.float16)
+    beta = dd.normal_f16(708, (N,), 0.2)
+    qp = [(float(np.float32(1) / np.float32(0.02 + 0.01 * i)), float(-7 + 11 * i)) for i in range(nq)]
+    qpd = [(scal(x), scal(y)) for x, y in qp]
+    ws = C.qlinear_ln_workspace(max(M, 2048), N, DEV)
+    args = (t(a), t(w), t(sc), t(b0), None if bs is None else t(bs), None if r is None else t(r), t(gamma),
+            t(beta), 1e-5, qpd, ws)
+    y, outs, h = C.qlinear_ln(*args, want_f16=want_h, _cfg=cfg)
+    # the two launches it stands for
+    y2 = C.qlinear_w8_a8_ohalf(t(a), t(w), t(sc), scal(1), scal(0), t(b0), t(sc), t(b0),
+                               None if bs is None else t(bs), _residual=None if r is None else t(r))
+    o2, h2 = C.layernorm_quantize(y2, t(gamma), t(beta), 1e-5, qpd, want_f16=want_h)
+    assert torch.equal(y.view(torch.int16), y2.view(torch.int16))
+    assert len(outs) == nq and all(torch.equal(p, q) for p, q in zip(outs, o2))
+    if want_h:
+        assert torch.equal(h.view(torch.int16), h2.view(torch.int16))
+    # the oracle's chain
+    v = C.FLAGS & 1
+    y_ref = oracle.qlinear(a, w, b0, sc, bs, v)
+    if r is not None:
+        y_ref = oracle.add_f16(y_ref, r)
+    assert np.array_equal(y.cpu().numpy().view(np.uint16), y_ref.view(np.uint16))
+    o_ref, h_ref = oracle.layernorm_quantize(y_ref, gamma, beta, 1e-5, qp, v)
+    for p, q in zip(outs, o_ref):
+        assert np.array_equal(p.cpu().numpy(), q)
+    if want_h:
+        assert np.array_equal(h.cpu().numpy().view(np.uint16), h_ref.view(np.uint16))
+    # the exchange buffer is clean again: same launch, another shape, same launch
+    hdr = ws[:8].view(torch.int32).tolist()                        # (epoch, departures): one launch, all gone
+    assert hdr == [1, 0], hdr
+    y3, outs3, _ = C.qlinear_ln(*args, want_f16=want_h, _cfg=cfg)
+    other = C.qlinear_ln(t(dd.int8(711, (128, 640))), t(dd.int8(712, (640, 640))), t(sc[:640].copy()),
+                         t(b0[:640].copy()), None, None, t(gamma[:640].copy()), t(beta[:640].copy()), 1e-5,
+                         qpd[:1] or [(scal(30), scal(0))], ws)
+    assert other[0].shape == (128, 640)
+    y4, outs4, _ = C.qlinear_ln(*args, want_f16=want_h, _cfg=cfg)
+    for yy, oo in ((y3, outs3), (y4, outs4)):
+        assert torch.equal(yy.view(torch.int16), y2.view(torch.int16))
+        assert all(torch.equal(p, q) for p, q in zip(oo, o2))
+
+
+def test_qlinear_ln_range_and_graph_capture(C):
+    """Outside its range the launch says so (the caller then issues the two launches); inside a captured graph
+    it replays (no host synchronisation, the counters reset themselves)."""
+    assert not C.qlinear_ln_supported(8192, 1280, 1280)        # more tiles than CUs: not all resident at once
+    assert not C.qlinear_ln_supported(1024, 1280, 200)
+    assert not C.qlinear_ln_supported(1024, 1920, 1280)        # a column tile must be one unit of the LayerNorm
+    assert C.qlinear_ln_supported(1024, 320, 1280)             # (N = 320, 640, 1280: 4, 8, 16 units of 80)
+    assert C.qlinear_ln_supported(1024, 1280, 1280) and C.qlinear_ln_supported(4096, 640, 640)
+    assert not C.qlinear_ln_supported(4096, 640, 2560)         # long K: the cost rule keeps two launches
+    M, N, K = 1024, 1280, 1280
+    a, w = t(dd.int8(721, (M, K))), t(dd.int8(722, (N, K)))
+    sc, b0 = t(dd.f32(723, (N,), 2e-5, 6e-5)), t(dd.f32(724, (N,), -50, 50))
+    r = t(dd.normal_f16(725, (M, N), 1.0))
+    g, b = t(dd.normal_f16(726, (N,), 1.0)), t(dd.normal_f16(727, (N,), 0.2))
+    qp = [(scal(40), scal(3))]
+    ws = C.qlinear_ln_workspace(M, N, DEV)
+    with pytest.raises(RuntimeError, match="shape outside"):
+        C.qlinear_ln(t(dd.int8(728, (8192, K))), w, sc, b0, None, None, g, b, 1e-5, qp,
+                     C.qlinear_ln_workspace(8192, N, DEV))
+    ref = C.qlinear_ln(a, w, sc, b0, None, r, g, b, 1e-5, qp, ws)
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        got = C.qlinear_ln(a, w, sc, b0, None, r, g, b, 1e-5, qp, ws)
+    for _ in range(3):
+        got[0].zero_()
+        got[1][0].zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(got[0].view(torch.int16), ref[0].view(torch.int16))
+        assert torch.equal(got[1][0], ref[1][0])

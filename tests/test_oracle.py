@@ -241,6 +241,24 @@ def test_layernorm_restatement_matches_torch_fp32_reference(oracle):
         assert np.array_equal(q, oracle.quantize(h, si, zp))
 
 
+@pytest.mark.parametrize("C", [64, 96, 128, 640, 1280, 2048])
+def test_layernorm_reduction_order_is_stable_for_shifted_rows(oracle, C):
+    """The row statistics are per-16-column (sum, centred sum of squares) partials folded in a fixed order
+    (oracle/mixdq_oracle.c: the order the GEMM epilogue of csrc/igemm_ln.hip can follow from its column tiles)
+    and combined with Chan's formula, so the variance does not suffer E[x^2] - mean^2 cancellation: rows whose
+    mean is 12 standard deviations away from zero (mean^2 / var = 144) stay within one FP16 ulp (+ the FP32
+    noise of the mean itself, 4e-6) of PyTorch's FP64 LayerNorm of the same FP16 input.  Widths cover every
+    segment count (C / 16 = 4, 6, 8, 40, 80, 128)."""
+    x = (dd.normal_f16(305, (19, C), 0.5).astype(np.float32) + 6.0).astype(np.float16)
+    gamma = (dd.normal_f16(307, (C,), 0.3).astype(np.float32) + 1).astype(np.float16)
+    beta = dd.normal_f16(308, (C,), 0.2)
+    _, h = oracle.layernorm_quantize(x, gamma, beta, 1e-5, [])
+    ref = torch.nn.functional.layer_norm(torch.from_numpy(x).double(), (C,), torch.from_numpy(gamma).double(),
+                                         torch.from_numpy(beta).double(), 1e-5).float()
+    got = torch.from_numpy(h).float()
+    assert bool(((got - ref).abs() <= 1.001 * _ulp16(ref) + 4e-6).all())
+
+
 def test_groupnorm_silu_restatement_matches_torch_fp32_reference(oracle):
     x = (dd.normal_f16(311, (2, 6, 5, 64), 1.5).astype(np.float32) +
          dd.normal_f16(312, (1, 1, 1, 64), 0.7).astype(np.float32)).astype(np.float16)   # NHWC

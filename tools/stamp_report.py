@@ -30,6 +30,8 @@ def main():
     ap.add_argument("K", type=int)
     ap.add_argument("--geglu", action="store_true")
     ap.add_argument("--res", action="store_true")
+    ap.add_argument("--ln", action="store_true", help="the GEMM + residual + LayerNorm + quantize launch (slots 6: tile "
+                    "final | 10: records + output rows issued | 11: all records in | 14: row statistics done | 15: end)")
     ap.add_argument("--cfg", type=int, default=0)
     ap.add_argument("--cold", action="store_true", help="stream 512 MB between launches")
     ap.add_argument("--conv", type=int, default=0, metavar="HW",
@@ -38,6 +40,12 @@ def main():
     lib = C._lib
     assert hasattr(lib, "mixdq_debug_stamps"), "not a stamped build (tools/stamp_build.sh)"
     lib.mixdq_debug_stamps.argtypes = [ctypes.c_void_p]
+    set_stamps = lib.mixdq_debug_stamps
+    if a.ln:
+        lib.mixdq_debug_stamps_ln.argtypes = [ctypes.c_void_p]
+        set_stamps = lib.mixdq_debug_stamps_ln
+        gm, bt = torch.ones(a.N, device=DEV).half(), torch.zeros(a.N, device=DEV).half()
+        lnws = C.qlinear_ln_workspace(a.M, a.N, DEV)
     g = torch.Generator().manual_seed(0)
     x = torch.randint(-128, 128, (a.M, a.K), generator=g, dtype=torch.int8).to(DEV)
     w = torch.randint(-128, 128, (a.N, a.K), generator=g, dtype=torch.int8).to(DEV)
@@ -59,6 +67,8 @@ def main():
         if a.conv:
             C.qconv2d_w8_a8_ohalf(xc, wc, sc, z, one, sc, wsum, None, None, 1, 1, 1, _table=table,
                                   _cfg=a.cfg, _residual=resc)
+        elif a.ln:
+            C.qlinear_ln(x, w, sc, sc, None, res, gm, bt, 1e-5, [(one, z)], lnws, _cfg=a.cfg)
         elif a.geglu:
             C.qlinear_geglu(x, w, sc, sc, None, one, z, _cfg=a.cfg)
         else:
@@ -72,10 +82,10 @@ def main():
             flush.zero_()
         stamps.zero_()
         torch.cuda.synchronize()
-        lib.mixdq_debug_stamps(ctypes.c_void_p(stamps.data_ptr()))
+        set_stamps(ctypes.c_void_p(stamps.data_ptr()))
         launch()
         torch.cuda.synchronize()
-        lib.mixdq_debug_stamps(None)
+        set_stamps(None)
         s = stamps.cpu().numpy().astype(np.int64)
         wg = np.nonzero((s[:, :, 0] != 0).any(axis=1))[0]
         s = s[wg]
@@ -87,7 +97,8 @@ def main():
         ok = dt_rt > 0
         ghz = float(np.median(dt_clk[ok] / dt_rt[ok])) * 0.1 if ok.any() else 2.0
         parts = []
-        for slot in (12, 13, 1, 2, 3, 4, 5, 6, 10, 11, 7):
+        end = 15 if a.ln else 7
+        for slot in (12, 13, 1, 2, 3, 4, 5, 7, 6, 10, 11, 14, 15) if a.ln else (12, 13, 1, 2, 3, 4, 5, 6, 10, 11, 7):
             v = s[:, :, slot]
             have = used & (v != 0)
             if not have.any():
@@ -96,7 +107,7 @@ def main():
             last = np.where(have, v, 0).max(axis=1) - t0
             sel = have.any(axis=1)
             parts.append(f"s{slot}: {np.median(first[sel]) / (ghz * 1e3):5.2f}..{np.median(last[sel]) / (ghz * 1e3):5.2f}")
-        span = (np.where(used, s[:, :, 7], 0).max(axis=1) - t0) / (ghz * 1e3)
+        span = (np.where(used, s[:, :, end], 0).max(axis=1) - t0) / (ghz * 1e3)
         print(f"clock {ghz:.2f} GHz, {len(wg)} workgroups, workgroup life med {np.median(span):.2f} max {span.max():.2f} us | "
               + " | ".join(parts))
 
