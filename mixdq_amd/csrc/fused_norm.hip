@@ -321,6 +321,7 @@ __global__ __launch_bounds__(256) void ln_quant_kernel(
   while (U < 16 && G % (2 * U) == 0) U *= 2;
   const int per = G / U;
   const float n_u = (float)(16 * per);
+  const float inv_nu = 1.0f / n_u, inv_c = 1.0f / (float)C;     // the specification multiplies by these
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) {
     float mg[kLnMaxChunks], m2[kLnMaxChunks];
@@ -350,10 +351,10 @@ __global__ __launch_bounds__(256) void ln_quant_kernel(
     if (lane < U) {                                                  // one lane per unit: its groups, left to right
       s1u = sh[lane * per];
       for (int g = 1; g < per; ++g) s1u = __fadd_rn(s1u, sh[lane * per + g]);
-      mu = s1u / n_u;
+      mu = __fmul_rn(s1u, inv_nu);
       sh[kLnMaxGroups + lane] = mu;
     }
-    mean[r] = ln_tree(s1u, U) / (float)C;
+    mean[r] = __fmul_rn(ln_tree(s1u, U), inv_c);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
     for (int i = 0; i < kLnMaxChunks; ++i) {
@@ -371,7 +372,7 @@ __global__ __launch_bounds__(256) void ln_quant_kernel(
       const float e = __fsub_rn(mu, mean[r]);
       du = __builtin_fmaf(__fmul_rn(e, n_u), e, m2u);
     }
-    rstd[r] = 1.0f / sqrtf(__fadd_rn(ln_tree(du, U) / (float)C, eps));
+    rstd[r] = 1.0f / sqrtf(__fadd_rn(__fmul_rn(ln_tree(du, U), inv_c), eps));
   }
 #pragma unroll
   for (int r = 0; r < ROWS; ++r) {

@@ -491,6 +491,10 @@ void igemm_kernel(MIXDQ_IGEMM_HEAD_PARAMS const IgemmParams p_in) {
   constexpr int PB = B_STAGE / 1024;
   constexpr int B_LO = PB / NWAVES, B_REM = PB % NWAVES, B_NI = B_LO + (B_REM ? 1 : 0);
   constexpr int CS_STRIDE = BN * 2 + 16;          // epilogue tile row stride (bytes)
+  // LNQ: behind the fp16 tile -- [BM][2] row statistics (mean, rstd), then [BM][BN / 16][2] group statistics
+  constexpr int LN_GRP_OFF = BM * CS_STRIDE + BM * 8;
+  static_assert(!LNQ || LN_GRP_OFF + BM * (BN / 16) * 8 <= igemm_main_bytes<BM, BN, BK, STAGES>(),
+                "the LayerNorm tables fit behind the tile");
   constexpr int PRE = STAGES - 1;                 // K-tiles in flight ahead of the one computed
   static_assert(A_NI >= 1 && A_NI * 1024 * NWAVES == A_STAGE && PB >= 1 && PB * 1024 == B_STAGE,
                 "whole 1-KiB DMA pieces; the activation pieces divide evenly over the waves");
@@ -1750,6 +1754,32 @@ void igemm_kernel(MIXDQ_IGEMM_HEAD_PARAMS const IgemmParams p_in) {
     }
     if constexpr (LNQ) {    // the FINAL value (residual added) back into the tile: the LayerNorm's input; the
       *reinterpret_cast<uint4*>(Cs + row * CS_STRIDE + cc * 16) = v;   // rows leave for D behind the records
+      // ... and the 16-column group's statistics while the chunk is in registers: a chunk is half a group, its
+      // other half sits in the neighbouring lane (chunks run along the lanes; a pair never straddles a wave)
+      float f[8];
+      {
+        const uint32_t ww[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          __half_raw r;
+          r.x = (unsigned short)((j & 1) ? (ww[j >> 1] >> 16) : (ww[j >> 1] & 0xffffu));
+          f[j] = __half2float(__half(r));
+        }
+      }
+      float s8 = f[0];
+#pragma unroll
+      for (int j = 1; j < 8; ++j) s8 = __fadd_rn(s8, f[j]);
+      const float s1 = __fadd_rn(s8, ln_dpp<0xB1>(s8));
+      const float mg = __fmul_rn(s1, 0.0625f);
+      float q8 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float d = __fsub_rn(f[j], mg);
+        q8 = __builtin_fmaf(d, d, q8);
+      }
+      const float m2 = __fadd_rn(q8, ln_dpp<0xB1>(q8));
+      if ((cc & 1) == 0)
+        *reinterpret_cast<float2*>(smem + LN_GRP_OFF + (row * (BN / 16) + (cc >> 1)) * 8) = make_float2(s1, m2);
       return;
     }
     __half* dst = p.D + drow * p.N + n;
@@ -1811,6 +1841,7 @@ void igemm_kernel(MIXDQ_IGEMM_HEAD_PARAMS const IgemmParams p_in) {
     static_assert(GPT <= 8, "one 8-lane group computes a row's unit record");
     const int U = p.tiles_n;                         // units per row (the launcher: N == U * BN, U <= 16)
     const float n_u = (float)BN;
+    const float inv_nu = 1.0f / n_u, inv_c = 1.0f / (float)p.N;    // (the specification multiplies by these)
     const int tag = ln_epoch + 1;
     float* ln_mr = reinterpret_cast<float*>(smem + BM * CS_STRIDE);     // [BM][2]: mean, rstd (behind the tile)
     static_assert(BM * CS_STRIDE + BM * 8 <= igemm_main_bytes<BM, BN, BK, STAGES>(), "row table fits");
@@ -1832,44 +1863,30 @@ void igemm_kernel(MIXDQ_IGEMM_HEAD_PARAMS const IgemmParams p_in) {
         f[j] = __half2float(__half(r));
       }
     };
-    {
-      const int j = tid & 7, base = lane & ~7;
-      for (int row = tid >> 3; row < BM; row += NTHREADS / 8) {
-        float s1 = 0.f, m2 = 0.f, mg = 0.f;
-        if (j < GPT) {
-          float lo[8], hi[8];
-          halves(*reinterpret_cast<const uint4*>(Cs + row * CS_STRIDE + j * 32), lo);
-          halves(*reinterpret_cast<const uint4*>(Cs + row * CS_STRIDE + j * 32 + 16), hi);
-          float sl = lo[0], sh_ = hi[0];
+    // the row's unit record from its GPT group statistics (computed from registers in the pass above): one
+    // thread per row, groups left to right, Chan's combination about the unit mean
+    for (int row = tid; row < BM; row += NTHREADS) {
+      const float2* gs = reinterpret_cast<const float2*>(smem + LN_GRP_OFF) + row * GPT;
+      float2 g[GPT];
 #pragma unroll
-          for (int e = 1; e < 8; ++e) { sl = __fadd_rn(sl, lo[e]); sh_ = __fadd_rn(sh_, hi[e]); }
-          s1 = __fadd_rn(sl, sh_);
-          mg = __fmul_rn(s1, 0.0625f);
-          float ql = 0.f, qh = 0.f;
+      for (int k = 0; k < GPT; ++k) g[k] = gs[k];
+      float s1u = g[0].x;
 #pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            const float dl = __fsub_rn(lo[e], mg), dh = __fsub_rn(hi[e], mg);
-            ql = __builtin_fmaf(dl, dl, ql);
-            qh = __builtin_fmaf(dh, dh, qh);
-          }
-          m2 = __fadd_rn(ql, qh);
-        }
-        float s1u = __shfl(s1, base, 64);
+      for (int k = 1; k < GPT; ++k) s1u = __fadd_rn(s1u, g[k].x);
+      const float mu = __fmul_rn(s1u, inv_nu);
+      float m2u = 0.f;
 #pragma unroll
-        for (int g = 1; g < GPT; ++g) s1u = __fadd_rn(s1u, __shfl(s1, base + g, 64));
-        const float mu = s1u / n_u;
-        const float e = __fsub_rn(mg, mu);
-        const float c = __builtin_fmaf(__fmul_rn(e, 16.0f), e, m2);
-        float m2u = __shfl(c, base, 64);
-#pragma unroll
-        for (int g = 1; g < GPT; ++g) m2u = __fadd_rn(m2u, __shfl(c, base + g, 64));
-        if (j == 0 && m0 + row < p.M) {
-          const v4i rec = {(int)__float_as_uint(s1u), (int)__float_as_uint(m2u), tag, 0};
-          const uint4* dst = recs + ((m0 + row) * U + tile_n);
-          const uint4* dst_b = recs_b + ((m0 + row) * U + tile_n);
-          asm volatile("global_store_dwordx4 %0, %2, off\n\tglobal_store_dwordx4 %1, %2, off sc1\n\ts_nop 1"
-                       ::"v"(dst), "v"(dst_b), "v"(rec) : "memory");
-        }
+      for (int k = 0; k < GPT; ++k) {
+        const float e = __fsub_rn(__fmul_rn(g[k].x, 0.0625f), mu);
+        const float c = __builtin_fmaf(__fmul_rn(e, 16.0f), e, g[k].y);
+        m2u = k == 0 ? c : __fadd_rn(m2u, c);
+      }
+      if (m0 + row < p.M) {
+        const v4i rec = {(int)__float_as_uint(s1u), (int)__float_as_uint(m2u), tag, 0};
+        const uint4* dst = recs + ((m0 + row) * U + tile_n);
+        const uint4* dst_b = recs_b + ((m0 + row) * U + tile_n);
+        asm volatile("global_store_dwordx4 %0, %2, off\n\tglobal_store_dwordx4 %1, %2, off sc1\n\ts_nop 1"
+                     ::"v"(dst), "v"(dst_b), "v"(rec) : "memory");
       }
     }
     // the output rows leave now, under the records' way to the other tiles (in front of them they put ~1 us of
@@ -1943,10 +1960,10 @@ void igemm_kernel(MIXDQ_IGEMM_HEAD_PARAMS const IgemmParams p_in) {
         // (a record that never arrived -- a lost workgroup; bounded, not a hang -- poisons the row: NaN out)
         const float s1u = live[r] ? (ok[r] ? __uint_as_float((unsigned)rec[r][0]) : __uint_as_float(0x7fc00000u)) : 0.f;
         const float m2u = live[r] ? __uint_as_float((unsigned)rec[r][1]) : 0.f;
-        const float mean = ln_row_tree(s1u, U) / (float)p.N;
-        const float e = __fsub_rn(s1u / n_u, mean);
+        const float mean = __fmul_rn(ln_row_tree(s1u, U), inv_c);
+        const float e = __fsub_rn(__fmul_rn(s1u, inv_nu), mean);
         const float t2 = ln_row_tree(__builtin_fmaf(__fmul_rn(e, n_u), e, m2u), U);
-        const float rstd = 1.0f / sqrtf(__fadd_rn(t2 / (float)p.N, p.ln_eps));
+        const float rstd = 1.0f / sqrtf(__fadd_rn(__fmul_rn(t2, inv_c), p.ln_eps));
         if (u == 0) { ln_mr[2 * row] = mean; ln_mr[2 * row + 1] = rstd; }
       }
     }

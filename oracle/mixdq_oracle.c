@@ -382,11 +382,11 @@ int mixdq_oracle_groupnorm_silu_quantize(const uint16_t* x, const uint16_t* gamm
  *     M2_g = (sum_{j<8} d_j^2) + (sum_{j>=8} d_j^2),  d_j = x_j - m_g, each half an fmaf chain from 0
  *   unit u = `per` consecutive groups, U = (largest power of two <= 16 dividing G = C / 16) units per row
  *   (C = 1280: 16 units of 5 groups = 80 columns, the GEMM's column tile; C = 640: 8 such units):
- *     S1_u = S1_g summed left to right;   m_u = S1_u / (16 per)
+ *     S1_u = S1_g summed left to right;   m_u = S1_u * rn(1 / (16 per))          (rn: the FP32 reciprocal, one multiply)
  *     M2_u = sum, left to right, of fmaf(16 (m_g - m_u), m_g - m_u, M2_g)        (Chan's combination)
  *   row: the U unit values combined by a balanced binary tree (pairs at distance 1, 2, 4, 8):
- *     mean = tree(S1_u) / C
- *     var  = tree( fmaf(16 per (m_u - mean), m_u - mean, M2_u) ) / C
+ *     mean = tree(S1_u) * rn(1 / C)
+ *     var  = tree( fmaf(16 per (m_u - mean), m_u - mean, M2_u) ) * rn(1 / C)
  *     rstd = 1 / sqrtf(var + eps)
  *   y = f16( fmaf((x - mean) * rstd, gamma, beta) ), each quantizer applied to y. */
 static int ln_units(int G) {
@@ -410,6 +410,7 @@ void mixdq_oracle_layernorm_quantize(const uint16_t* x, const uint16_t* gamma, c
                                      int variant) {
   const int G = C / 16, U = ln_units(G > 0 ? G : 1), per = (G > 0 ? G : 1) / U;
   const float n_u = (float)(16 * per);
+  const float inv_nu = 1.0f / n_u, inv_c = 1.0f / (float)C;
   for (int64_t r = 0; r < M; r++) {
     const uint16_t* xr = x + r * C;
     float s1u[16], m2u[16], mu[16];
@@ -435,7 +436,7 @@ void mixdq_oracle_layernorm_quantize(const uint16_t* x, const uint16_t* gamma, c
       float t = s1g[0];
       for (int k = 1; k < per; k++) t = t + s1g[k];
       s1u[u] = t;
-      mu[u] = t / n_u;
+      mu[u] = t * inv_nu;
       float q = 0;
       for (int k = 0; k < per; k++) {
         const float e = s1g[k] * 0.0625f - mu[u];
@@ -446,12 +447,12 @@ void mixdq_oracle_layernorm_quantize(const uint16_t* x, const uint16_t* gamma, c
     }
     float a[16];
     for (int u = 0; u < U; u++) a[u] = s1u[u];
-    const float mean = ln_tree(a, U) / (float)C;
+    const float mean = ln_tree(a, U) * inv_c;
     for (int u = 0; u < U; u++) {
       const float e = mu[u] - mean;
       a[u] = fmaf(e * n_u, e, m2u[u]);
     }
-    const float rstd = 1.0f / sqrtf(ln_tree(a, U) / (float)C + eps);
+    const float rstd = 1.0f / sqrtf(ln_tree(a, U) * inv_c + eps);
     for (int c = 0; c < C; c++) {
       volatile float nrm = (h2f(xr[c]) - mean) * rstd;
       float y = rh(fmaf(nrm, h2f(gamma[c]), h2f(beta[c])));
