@@ -5,6 +5,8 @@ import glob
 import os
 import re
 
+import pytest
+
 from tests.conftest import ROOT
 
 
@@ -97,3 +99,20 @@ def test_tile_choice_is_a_host_function_of_the_shape():
     assert lib.mixdq_igemm_select_id_w4(1024, 1280, 1280, 1280) == 41
     assert lib.mixdq_igemm_select_id_w4(1024, 1280, 1281, 1281) == -1             # K % 32 != 0
     assert sel(64, 8, 20, 20) == 0 and sel(64, 6, 16, 16) == -1                   # generic / invalid
+
+
+def test_aq_kernels_never_touch_a_register_whose_load_is_in_flight():
+    """csrc/igemm_aq.hip requests its FP16 operand with inline-asm loads that the compiler cannot see in flight
+    (its own wait-count pass serialised the prefetch pipeline); tools/check_aq_isa.py proves on the generated ISA
+    of every AQ kernel that between a request and its counted wait nothing else mentions those registers (no
+    copy, no spill), that prologue and loop use the same physical registers, and that the loop tail is drained."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else shutil.which("hipcc")
+    if not hipcc:
+        pytest.skip("no hipcc on this box (the check runs where the library is built)")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_aq_isa.py")], capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert "20 AQ kernels checked, 0 failed" in r.stdout
