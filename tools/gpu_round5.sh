@@ -1,12 +1,12 @@
 #!/bin/bash
 # One lease for the round's record, on the FINAL tree: the GPU suite, the benchmark lines of the named
 # configurations, the rocprofv3 kernel traces of the benchmarked graphs (batch 1 and 8), the counter passes.
-#   bash tools/gpu_round4.sh <tag>     -> gpurun_out/<tag>/...   (copy what is to be judged into profiles/)
-tag=${1:-r04_final}
+#   bash tools/gpu_round5.sh <tag>     -> gpurun_out/<tag>/...   (copy what is to be judged into profiles/)
+tag=${1:-r05_final}
 out=gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
-( time timeout 1800 python -m pytest tests -q -m gpu 2>&1 | tail -8 ) > $out/pytest_gpu.txt 2>&1
+( time timeout 2400 python -m pytest tests -q -m gpu 2>&1 | tail -8 ) > $out/pytest_gpu.txt 2>&1
 timeout 1500 python bench.py > $out/bench_default.json 2> $out/bench_default.err
 timeout 900 python bench.py --batch 8 --steps 10 --no-cpu-baseline > $out/bench_bs8.json 2> $out/bench_bs8.err
 timeout 900 python bench.py --baseline-config 4 --forwards-per-image 20 --steps 20 --warmup 2 --no-fp16 --no-cpu-baseline > $out/bench_bs16_cfg4_20steps.json 2> $out/bench_cfg4.err
@@ -19,14 +19,18 @@ for bs in 1 8; do
   cp $(ls $out/prof$bs/*/*kernel_stats.csv $out/prof$bs/*kernel_stats.csv 2>/dev/null | head -1) $out/bench_kernel_stats_bs$bs.csv 2>/dev/null
   rm -rf $out/prof$bs
 done
-timeout 1800 bash tools/pmc_r04.sh > $out/pmc.txt 2>&1
+timeout 2400 bash tools/pmc_r05.sh > $out/pmc.txt 2>&1
 python - <<PY
 import json, glob
 for f in sorted(glob.glob("$out/bench_*.json")):
     try:
         d = json.loads(open(f).read().strip().splitlines()[-1])
-        print(f.split('/')[-1], 'n_gpus', d['n_gpus'], 'ms_per_step %.3f' % d['ms_per_step'], 'value %.2f' % d['value'], d.get('speedup_vs_fp16'), (d.get('roofline') or {}).get('frac'), (d.get('batch8') or {}).get('ms_per_step'), d.get('dropin_unfused_ms_per_step'))
+        r = d.get('roofline') or {}
+        print(f.split('/')[-1], 'n_gpus', d['n_gpus'], 'ms_per_step %.3f' % d['ms_per_step'], 'value %.2f' % d['value'],
+              'vs fp16', d.get('speedup_vs_fp16'), 'like-for-like', d.get('speedup_vs_fp16_like_for_like'), 'dropin', d.get('speedup_vs_fp16_dropin'),
+              'frac', r.get('frac'), 'in-step', r.get('frac_in_step'), 'batch8', (d.get('batch8') or {}).get('ms_per_step'),
+              'dropin ms', d.get('dropin_unfused_ms_per_step'), 'kernels', d.get('kernels_per_step'))
     except Exception as e:
         print(f, 'ERR', e)
 PY
-cat $out/pytest_gpu.txt; tail -16 $out/pmc.txt; head -12 $out/step_breakdown_bs1.txt
+cat $out/pytest_gpu.txt; tail -22 $out/pmc.txt; head -14 $out/step_breakdown_bs1.txt

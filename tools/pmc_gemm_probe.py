@@ -4,6 +4,9 @@
                                                               ... python3 tools/pmc_gemm_probe.py geglu M N K [cfg]
                                                               ... python3 tools/pmc_gemm_probe.py conv  IMG HW CIN COUT [cfg]
                                                               ... python3 tools/pmc_gemm_probe.py attn  B T C   (self-attention, heads = C / 64)
+                                                              ... python3 tools/pmc_gemm_probe.py linattn B T C  (to_q + cross-attention, 77 keys)
+                                                              ... python3 tools/pmc_gemm_probe.py ln    M N K   (GEMM + residual + LayerNorm + quantize)
+                                                              ... python3 tools/pmc_gemm_probe.py f16in M N K   (quantize-in-prologue GEMM)
 Inputs are made on the CPU and copied; no PyTorch GPU kernel is launched (rocprofv3 --pmc segfaults
 inside some torch reduction launches on this image)."""
 import os
@@ -33,6 +36,34 @@ if kind in ("lin", "geglu"):
             C.qlinear_geglu(a, w, sc, sc, None, one, zero, _cfg=cfg)
         else:
             C.qlinear_w8_a8_ohalf(a, w, sc, zero, zero, sc, sc, sc, None, _cfg=cfg)
+elif kind == "linattn":
+    B, T, Cc = a1, a2, a3
+    x = torch.randint(-128, 128, (B, T, Cc), generator=g, dtype=torch.int8).to("cuda")
+    w = torch.randint(-128, 128, (Cc, Cc), generator=g, dtype=torch.int8).to("cuda")
+    sc = (torch.rand(Cc, generator=g) * 2e-5).to("cuda")
+    kv = torch.randn(B, 77, 2 * Cc, generator=g).half().to("cuda")
+    s_inv = torch.full((), 20.0).to("cuda")
+    for _ in range(REPS):
+        C.qlinear_attention(x, w, sc, sc, kv[..., :Cc], kv[..., Cc:], s_inv, zero)
+elif kind == "ln":
+    M, N, K = a1, a2, a3
+    a = torch.randint(-128, 128, (M, K), generator=g, dtype=torch.int8).to("cuda")
+    w = torch.randint(-128, 128, (N, K), generator=g, dtype=torch.int8).to("cuda")
+    sc = (torch.rand(N, generator=g) * 4e-5).to("cuda")
+    res = torch.randn(M, N, generator=g).half().to("cuda")
+    gm, bt = torch.ones(N).half().to("cuda"), torch.zeros(N).half().to("cuda")
+    ws = torch.zeros(int(C._lib.mixdq_qlinear_ln_workspace_bytes(M, N)), dtype=torch.uint8).to("cuda")
+    s_inv = torch.full((), 30.0).to("cuda")
+    for _ in range(REPS):
+        C.qlinear_ln(a, w, sc, sc, None, res, gm, bt, 1e-5, [(s_inv, zero)], ws)
+elif kind == "f16in":
+    M, N, K = a1, a2, a3
+    x = torch.randn(M, K, generator=g).half().to("cuda")
+    w = torch.randint(-128, 128, (N, K), generator=g, dtype=torch.int8).to("cuda")
+    sc = (torch.rand(N, generator=g) * 1e-4).to("cuda")
+    s_inv = torch.full((), 30.0).to("cuda")
+    for _ in range(REPS):
+        C.qlinear_f16in(x, s_inv, zero, w, sc, sc, None)
 elif kind == "attn":
     B, T, Cc = a1, a2, a3
     qkv = (torch.randn(B, T, 3 * Cc, generator=g) * 1.0).half().to("cuda")     # the fused q|k|v projection's layout

@@ -26,9 +26,18 @@ for line in open(out + "/shapes.txt"):
         M, N, K = NI * HW * HW, COUT, 9 * CIN
         alg = NI * HW * HW * CIN + N * K + 2 * M * N
         shape = f"conv3x3 {NI}x{HW}x{HW}x{CIN}->{COUT}"
+    elif kind == "linattn":
+        B, T, Cc = v[:3]
+        M, N, K = B * T, Cc, Cc                               # the to_q GEMM (the 77-key attention adds ~12 % FLOPs)
+        alg = M * K + N * K + M * N + 2 * 2 * B * 77 * Cc     # int8 in, int8 out, k / v fp16
+        shape = f"linattn M{M} N{N} K{K}"
     else:
         M, N, K = v[:3]
         alg = M * K + N * K + (M * N // 2 if kind == "geglu" else 2 * M * N)
+        if kind == "ln":
+            alg += 2 * M * N + M * N                          # residual read, one INT8 LayerNorm output written
+        if kind == "f16in":
+            alg += M * K                                      # the operand arrives as FP16
         shape = f"{kind} M{M} N{N} K{K}"
     entry = {}
     for p in ("FETCH_SIZE", "WRITE_SIZE", "SQ", "SQ2"):

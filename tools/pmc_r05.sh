@@ -1,11 +1,11 @@
 #!/bin/bash
-# Round-4 counter passes of the launches that dominate the benchmarked graphs (batch 1 and 8), the
+# Round-5 counter passes of the launches that dominate the benchmarked graphs (batch 1 and 8), the
 # self-attention launches included: FETCH_SIZE and WRITE_SIZE in separate passes (MI355X_MICROARCH.md, HBM
 # section: FETCH_SIZE x2 on gfx950), one SQ pass (MFMA-busy, CU-busy, wait / issue-stall split) and a second
 # SQ pass for the vector-ALU share.  Run on the GPU box from the repo root:
-#   bash tools/pmc_r04.sh        -> gpurun_out/r04_pmc/{summary.json, *_counter_collection.csv}
+#   bash tools/pmc_r05.sh        -> gpurun_out/r05_pmc/{summary.json, *_counter_collection.csv}
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:?}"
-out=gpurun_out/r04_pmc
+out=gpurun_out/r05_pmc
 rm -rf $out; mkdir -p $out
 SQ="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES"
 SQ2="SQ_BUSY_CU_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_MFMA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"
@@ -27,6 +27,10 @@ conv 1 64 640 640
 conv 1 32 1280 1280
 attn 1 4096 640
 attn 1 1024 1280
+linattn 1 1024 1280
+ln 1024 1280 1280
+ln 4096 640 640
+f16in 1024 1280 640
 geglu 8192 10240 1280
 lin 8192 1280 5120
 lin 8192 3840 1280

@@ -8,13 +8,25 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r04_pmc_summary.json")
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r05_pmc_summary.json")
+lease = sys.argv[2] if len(sys.argv) > 2 else "unknown"
 tag = os.path.basename(src)
 out = {"_comment": "HBM-side bytes per launch and MFMA-busy fraction from the rocprofv3 --pmc passes of "
-                   "tools/pmc_r04.sh (profiles/r04_pmc_*): FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, "
+                   "tools/pmc_r05.sh (profiles/r05_pmc_*): FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, "
                    "KiB -> bytes, separate passes; mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (4 x "
                    "SQ_BUSY_CU_CYCLES).  Sections = batch size of the benchmarked graph, keys = bench.py "
                    "kernel names; each entry was measured on that very instantiation and launch kind."}
+import hashlib   # noqa: E402
+h = hashlib.sha256()
+d = os.path.join(ROOT, "mixdq_amd", "csrc")
+for name in sorted(os.listdir(d)):          # = bench.py csrc_sha16(): the kernel sources the counters were taken on
+    if name.endswith((".hip", ".h")):
+        with open(os.path.join(d, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+out["_provenance"] = {"summary": f"profiles/{tag}", "script": "tools/pmc_r05.sh", "lease": lease,
+                      "csrc_sha16": h.hexdigest()[:16],
+                      "note": "collected by the builder's rocprofv3 --pmc passes; bench.py re-prints these columns and "
+                              "drops them when csrc_sha16 differs from the running tree's"}
 for key, e in json.load(open(src)).items():
     kern, shape = key.split(" @ ")
     args = [a.strip() for a in re.search(r"<(.*)>", kern).group(1).split(",")]
@@ -25,18 +37,24 @@ for key, e in json.load(open(src)).items():
         name = f"conv3x3_halo_kernel<{args[0]},{args[1]},{args[2]}>"
         bs = int(re.search(r"conv3x3 (\d+)x", shape).group(1))
     else:
-        kind = "linear_geglu" if shape.startswith("geglu") else "linear"
+        kind = {"geglu": "linear_geglu", "linattn": "linear_attn", "ln": "linear_ln", "f16in": "linear_f16in"}.get(
+            shape.split()[0], "linear")
         name = f"igemm_kernel<{args[0]},{args[1]},{args[2]},{args[3]},{kind}>"
+        if kind in ("linear_attn", "linear_ln", "linear_f16in"):
+            name += "#cfg" + {("64", "128"): "41", ("64", "80"): "56" if args[3] == "6" else "45", ("128", "80"): "44"}.get(
+                (args[0], args[1]), "0")
         if args[:4] == ["128", "320", "128", "2"]:      # one tile, three wave layouts: keep them apart
             name += {("4", "2"): "#cfg25", ("8", "2"): "#cfg27", ("4", "4"): "#cfg28"}.get((args[4], args[5]), "")
-        bs = max(1, int(re.search(r"M(\d+)", shape).group(1)) // 1024)
+        rows = int(re.search(r"M(\d+)", shape).group(1))
+        ncols = int(re.search(r"N(\d+)", shape).group(1))
+        bs = max(1, rows // (4096 if ncols in (640, 5120) and rows % 4096 == 0 else 1024))   # rows per image: 4096 at 640 channels
     out.setdefault(f"bs{bs}", {})[name] = {
         "shape": shape, "hbm_bytes_per_launch": e["hbm_bytes_per_launch"],
         "algorithmic_bytes": e["algorithmic_bytes"],
         "traffic_over_algorithmic": round(e["traffic_over_algorithmic"], 3),
         "mfma_util": round(e.get("mfma_util", 0.0), 4),
         "us_under_pmc": round(e.get("SQ:_dur_ns", 0) / 1e3, 1),
-        "source": f"profiles/{tag} (tools/pmc_r04.sh)"}
+        "source": f"profiles/{tag} (tools/pmc_r05.sh)"}
     if "valu_util" in e:
         out[f"bs{bs}"][name]["valu_util"] = round(e["valu_util"], 4)
 dst = os.path.join(ROOT, "profiles", "pmc_traffic.json")
