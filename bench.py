@@ -69,6 +69,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-batch8", action="store_true", help="skip the batch-8 object of the default line")
+    ap.add_argument("--no-lnchain", action="store_true",
+                    help="skip the extra leg that times the fused graph with LayerNorm in the producer GEMM's launch")
     ap.add_argument("--no-dropin", action="store_true",
                     help="skip the module-swap-only (unfused) leg of the default line")
     ap.add_argument("--cpu-seconds", type=float, default=60.0,
@@ -751,6 +753,29 @@ def main():
         n_fused = count_kernels(lambda: eager_forward(**inputs), device)
         dropin = {"dropin_unfused_ms_per_step": 1e3 * dtd / kd, "dropin_unfused_kernels_per_step": n_unfused,
                   "kernels_per_step": n_fused}
+    # ---- the same fused graph with every eligible LayerNorm riding in its producer GEMM's launch (DESIGN.md 3.13:
+    #      off by default because it is time-neutral): its step time and kernel count beside the headline's
+    ln_in_gemm = None
+    if default_line and not args.no_lnchain and not args.no_fuse:
+        import mixdq_amd.unet as U_
+        saved_chain = U_.LN_CHAIN
+        try:
+            U_.LN_CHAIN = not saved_chain
+            unet.forward = eager_forward
+            with torch.no_grad():
+                eager_forward(**inputs)
+            torch.cuda.synchronize(device)
+            n_alt = count_kernels(lambda: eager_forward(**inputs), device)
+            hip_graph_opt(unet)
+            kl = max(5, args.steps // 2)
+            dtl = time_steps(run_once, kl, 2, device)
+            ln_in_gemm = {"enabled_in_headline": bool(saved_chain), "alternative_ms_per_step": 1e3 * dtl / kl,
+                          "alternative_kernels_per_step": n_alt,
+                          "alternative": "LayerNorm + quantize in the producer GEMM's launch" if not saved_chain
+                                         else "every LayerNorm a launch of its own"}
+        finally:
+            U_.LN_CHAIN = saved_chain
+            unet.forward = eager_forward
     if args.profile_ranges and rank == 0:
         unet.forward = eager_forward
         layers_roctx_annotate(unet)
@@ -831,6 +856,8 @@ def main():
         out.update(dropin)
         if fp16:
             out["speedup_vs_fp16_dropin"] = fp16["ms_per_step"] / dropin["dropin_unfused_ms_per_step"]
+    if ln_in_gemm:
+        out["ln_in_gemm"] = ln_in_gemm
     if world == 1:
         out["multi_gpu"] = ("unmeasured: no multi-GPU node was available to this build; RCCL has run under this "
                             "code at world size 1 only (tests/test_dist_gpu.py)")

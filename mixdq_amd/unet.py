@@ -542,9 +542,11 @@ class Attention(nn.Module):
 
 
 CROSS_FUSE_MAX_ROWS = int(__import__("os").environ.get("MIXDQ_CROSS_FUSE_MAX_ROWS", "4096"))
-# LayerNorms in the epilogue of the GEMM that produces their input (csrc/igemm_ln.hip); 0: every LayerNorm a
-# launch of its own, as in round 4 (A/B runs)
-LN_CHAIN = __import__("os").environ.get("MIXDQ_LN_CHAIN", "1") != "0"
+# LayerNorms in the epilogue of the GEMM that produces their input (csrc/igemm_ln.hip).  Off by default: the step
+# time is EQUAL either way (10.975 / 10.986 ms with, 10.965 / 10.945 without, same box: DESIGN.md section 3.13) -- 151
+# launches fewer, paid for by a cross-workgroup exchange per launch -- and the plain form keeps every launch free of
+# inter-workgroup waits.  MIXDQ_LN_CHAIN=1 (or `mixdq_amd.unet.LN_CHAIN = True`) turns it on; bench.py times both.
+LN_CHAIN = __import__("os").environ.get("MIXDQ_LN_CHAIN", "0") == "1"
 # weight prefetch from the self-attention launch: on for launches of up to this many rows
 PREFETCH = __import__("os").environ.get("MIXDQ_PREFETCH", "1") != "0"
 PREFETCH_MAX_ROWS = int(__import__("os").environ.get("MIXDQ_PREFETCH_MAX_ROWS", "0"))      # 0: no limit (see _build_prefetch_plan)

@@ -51,6 +51,16 @@ def _check_graph(unet, inputs2, expect_accel, expect_w4=None):
         with U.defused():
             ref2 = unet(**inputs2)[0].clone()
         fused1 = unet(**inputs1)[0].clone()
+        # ... and with every eligible LayerNorm riding in its producer GEMM's launch (mixdq_qlinear_w8a8_ln,
+        # DESIGN.md 3.13; off by default): the same bits, 151 launches fewer at batch 1
+        saved_chain = U.LN_CHAIN
+        try:
+            U.LN_CHAIN = True
+            chain2 = unet(**inputs2)[0].clone()
+            chain1 = unet(**inputs1)[0].clone()
+        finally:
+            U.LN_CHAIN = saved_chain
+    assert torch.equal(chain2, fused2) and torch.equal(chain1, fused1), "LayerNorm-in-GEMM graph != the plain fused graph"
     assert torch.isfinite(fused2).all()
     assert torch.equal(fused2, again2), "fused graph is not deterministic"
     diff = (fused2.float() - ref2.float()).abs()

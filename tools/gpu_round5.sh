@@ -14,7 +14,7 @@ timeout 900 python bench.py --baseline-config 2 --no-fp16 --no-cpu-baseline > $o
 timeout 1500 python bench.py --baseline-config 3 --gpus 1 --steps 4 --warmup 1 --no-fp16 --no-cpu-baseline --no-roofline > $out/bench_bs64_cfg3_1gpu.json 2> $out/bench_cfg3.err
 MIXDQ_SHARE_DEVICE=1 MIXDQ_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 2 --tiny --no-fp16 --no-cpu-baseline --no-roofline > $out/bench_gpus2_tiny_shared_device.json 2> $out/bench_gpus2.err
 for bs in 1 8; do
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof$bs -o bench -- python3 bench.py --no-fp16 --no-cpu-baseline --no-roofline --no-batch8 --no-dropin --steps 20 --batch $bs > $out/bench_prof_bs$bs.json 2> $out/bench_prof_bs$bs.err
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof$bs -o bench -- python3 bench.py --no-fp16 --no-cpu-baseline --no-roofline --no-batch8 --no-dropin --no-lnchain --steps 20 --batch $bs > $out/bench_prof_bs$bs.json 2> $out/bench_prof_bs$bs.err
   python3 tools/step_breakdown.py $(ls $out/prof$bs/*/*kernel_trace.csv $out/prof$bs/*kernel_trace.csv 2>/dev/null | head -1) 45 > $out/step_breakdown_bs$bs.txt 2>&1
   cp $(ls $out/prof$bs/*/*kernel_stats.csv $out/prof$bs/*kernel_stats.csv 2>/dev/null | head -1) $out/bench_kernel_stats_bs$bs.csv 2>/dev/null
   rm -rf $out/prof$bs
