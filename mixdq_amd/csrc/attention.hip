@@ -31,6 +31,32 @@ namespace {
 
 typedef short v4s16 __attribute__((__vector_size__(4 * sizeof(short))));
 
+// MIXDQ_STAMP (diagnostic builds only, tools/stamp_build.sh): every wave of every attention workgroup records the
+// shader clock at the phase boundaries of attn_fwd_kernel into a buffer registered with mixdq_debug_stamps_attn();
+// tools/stamp_report.py --attn turns them into a time line (where the 1024-token launch spends the
+// ~7 us outside its 16-tile loop).
+#ifndef MIXDQ_STAMP
+#define MIXDQ_STAMP 0
+#endif
+#if MIXDQ_STAMP
+__device__ unsigned long long g_attn_stamps;      // address of [workgroup][wave 0..3][16] uint64, or 0
+#define MIXDQ_ATTN_STAMP(slot)                                                                    \
+  do {                                                                                            \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();                                   \
+    const unsigned long long r_ = __builtin_amdgcn_s_memrealtime();                               \
+    const unsigned long long a_ = g_attn_stamps;                                                  \
+    if (a_ != 0 && (threadIdx.x & 63) == 0) {                                                     \
+      auto sp_ = (__attribute__((address_space(1))) unsigned long long*)a_ +                      \
+                 ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;                              \
+      sp_[slot] = t_;                                                                             \
+      if ((slot) == 0) sp_[8] = r_;                                                               \
+      if ((slot) == 7) sp_[9] = r_;                                                               \
+    }                                                                                             \
+  } while (0)
+#else
+#define MIXDQ_ATTN_STAMP(slot) do {} while (0)
+#endif
+
 struct AttnParams {
   const __half* q; const __half* k; const __half* v;
   void* out;                       // f16 rows or int8 rows
@@ -254,6 +280,15 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2
     attn_prefetch_role(p);
     return;
   }
+  MIXDQ_ATTN_STAMP(0);
+  // the output quantizer's scalars: requested at entry, as SCALAR loads (constant address space: they do not
+  // change while the kernel runs).  Read where they are used -- behind the last barrier -- they were a
+  // dependent trip to memory at the very end of every launch: stores phase 1.5 us (tools/stamp_attn.py).
+  float s_inv = 0.f, zp = 0.f;
+  if constexpr (QUANT) {
+    s_inv = *(const __attribute__((address_space(4))) float*)p.s_inv;
+    zp = *(const __attribute__((address_space(4))) float*)p.zp;
+  }
   constexpr int NI = 16 / WAVES;                 // LDS-DMA wave-instructions per wave per tile
   constexpr int PRE = STAGES - 1;                // tiles staged ahead of the one whose V is consumed
   static_assert(STAGES >= 3, "tiles t (V) and t+1 (K) are read while t+2.. are in flight");
@@ -372,10 +407,13 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
   for (int s = 0; s < PRE; ++s)
     if (!short_k || s < ntiles) stage(s, s);     // long: tiles past the end re-stage the last key
+  MIXDQ_ATTN_STAMP(1);                           // Q requested, the prologue's K/V tiles requested
   if (short_k) asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
   else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((PRE - 1) * NI) : "memory");
+  MIXDQ_ATTN_STAMP(2);                           // the first K/V tile has landed (every wave's pieces)
   v16f S[2][2];                                  // scores: S[t & 1] softmaxed now, S[~t & 1] next
   qk(0, 0, S[0]);
+  MIXDQ_ATTN_STAMP(3);                           // Q in registers, scores of tile 0
   v8h P[2][2][2];                                // P[t & 1]: probabilities of tile t, FP16, B operand
 #pragma unroll
   for (int kb = 0; kb < 2; ++kb)
@@ -402,6 +440,7 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2
                              t + 1 == ntiles - 1, p.tkv - (t + 1) * kKeys - 4 * hh);
     }
   }
+  MIXDQ_ATTN_STAMP(4);                           // the tile loop is done
   // ---- the last tile's product ----
   s_waitcnt_lgkm0();
   if ((ntiles - 1) & 1) attn_pv_tile(st, P[1], ones); else attn_pv_tile(st, P[0], ones);
@@ -423,9 +462,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2
       for (int j = 0; j < 4; ++j) w[j] = (_Float16)(o[db][4 * g + j] * inv);
       *reinterpret_cast<v4h*>(Os + l32 * kORow + (32 * db + 8 * g + 4 * hh) * 2) = w;
     }
-  __syncthreads();
-  float s_inv = 0.f, zp = 0.f;
-  if constexpr (QUANT) { s_inv = *p.s_inv; zp = *p.zp; }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private staging (a wave reads back its own 32 rows): no block barrier
+  MIXDQ_ATTN_STAMP(5);                           // O normalised and staged in LDS
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int id = lane + 64 * i, row = id >> 3, ch = id & 7;
@@ -436,16 +474,14 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2
       *reinterpret_cast<uint4*>(reinterpret_cast<__half*>(p.out) + off) = w;
     } else {
       const __half* hv = reinterpret_cast<const __half*>(&w);
-      uint32_t pk[2] = {0u, 0u};
+      float x[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float x = __half2float(hv[j]);
-        const int qv = p.unfused ? quantize_one<true>(x, s_inv, zp) : quantize_one<false>(x, s_inv, zp);
-        pk[j >> 2] |= (uint32_t)(qv & 0xff) << (8 * (j & 3));
-      }
-      *reinterpret_cast<uint2*>(reinterpret_cast<int8_t*>(p.out) + off) = make_uint2(pk[0], pk[1]);
+      for (int j = 0; j < 8; ++j) x[j] = __half2float(hv[j]);
+      *reinterpret_cast<uint2*>(reinterpret_cast<int8_t*>(p.out) + off) =
+          p.unfused ? quantize_pack8<true>(x, s_inv, zp) : quantize_pack8<false>(x, s_inv, zp);
     }
   }
+  MIXDQ_ATTN_STAMP(7);                           // rows stored (issued)
 }
 
 // SHORT key sequences (tkv <= 128: the UNet's cross-attention, 77 keys): a workgroup's life is one
@@ -461,6 +497,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   MIXDQ_ARGS_NOW(p.q, p.k, p.v, p.out, p.q_bs, p.q_rs, p.k_bs, p.k_rs, p.v_bs, p.v_rs, p.o_bs, p.o_rs,
                  p.tq, p.tkv, p.heads, p.qblocks);
   MIXDQ_ARGS_NOW(p.scale_log2, p.s_inv, p.zp, p.unfused);
+  float s_inv = 0.f, zp = 0.f;                   // (scalar loads at entry: see attn_fwd_kernel)
+  if constexpr (QUANT) {
+    s_inv = *(const __attribute__((address_space(4))) float*)p.s_inv;
+    zp = *(const __attribute__((address_space(4))) float*)p.zp;
+  }
   constexpr int WAVES = 4, NI = 16 / WAVES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -606,8 +647,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       *reinterpret_cast<v4h*>(Os + l32 * kORow + (32 * db + 8 * g + 4 * hh) * 2) = w;
     }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private staging: no block barrier
-  float s_inv = 0.f, zp = 0.f;
-  if constexpr (QUANT) { s_inv = *p.s_inv; zp = *p.zp; }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int id = lane + 64 * i, row = id >> 3, ch = id & 7;
@@ -618,14 +657,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       *reinterpret_cast<uint4*>(reinterpret_cast<__half*>(p.out) + off) = w;
     } else {
       const __half* hv = reinterpret_cast<const __half*>(&w);
-      uint32_t pk[2] = {0u, 0u};
+      float x[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float x = __half2float(hv[j]);
-        const int qv = p.unfused ? quantize_one<true>(x, s_inv, zp) : quantize_one<false>(x, s_inv, zp);
-        pk[j >> 2] |= (uint32_t)(qv & 0xff) << (8 * (j & 3));
-      }
-      *reinterpret_cast<uint2*>(reinterpret_cast<int8_t*>(p.out) + off) = make_uint2(pk[0], pk[1]);
+      for (int j = 0; j < 8; ++j) x[j] = __half2float(hv[j]);
+      *reinterpret_cast<uint2*>(reinterpret_cast<int8_t*>(p.out) + off) =
+          p.unfused ? quantize_pack8<true>(x, s_inv, zp) : quantize_pack8<false>(x, s_inv, zp);
     }
   }
 }
@@ -774,3 +810,11 @@ extern "C" int mixdq_attention_f16_prefetch(const void* q, const void* k, const 
                             out_row_stride, softmax_scale, out_scale_inv, out_zero_point, prefetch_ptrs,
                             prefetch_bytes, n_prefetch, flags, stream);
 }
+
+#if MIXDQ_STAMP
+// diagnostic builds only: register (or clear, with null) the attention stamp buffer, [grid][4 waves][16] uint64
+extern "C" int mixdq_debug_stamps_attn(void* buffer) {
+  unsigned long long b = (unsigned long long)(uintptr_t)buffer;
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_attn_stamps), &b, sizeof(b)) == hipSuccess ? MIXDQ_OK : MIXDQ_ERR_LAUNCH;
+}
+#endif

@@ -212,20 +212,21 @@ __global__ void gn_apply_kernel(const __half* __restrict__ x, const __half* __re
   for (int64_t p = p_begin + pp; p < p_end; p += g.PP) {
     const Half8 h = *reinterpret_cast<const Half8*>(src + p * xs);
     Half8 oh;
-    Char8 oq, rq;
-    oq.w[0] = oq.w[1] = rq.w[0] = rq.w[1] = 0;
     oh.w[0] = oh.w[1] = oh.w[2] = oh.w[3] = 0;
+    float y8[8], h8[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      float y = round_f16(__builtin_fmaf(half_at(h, j), a[j], b[j]));   // GroupNorm -> fp16
+      h8[j] = half_at(h, j);
+      float y = round_f16(__builtin_fmaf(h8[j], a[j], b[j]));           // GroupNorm -> fp16
       if (SILU) y = round_f16(mixdq_siluf(y));                          // SiLU -> fp16
+      y8[j] = y;
       put_half(oh, j, y);
-      put_q(oq, j, quantize_one<UNFUSED>(y, s_inv, zp));
-      put_q(rq, j, quantize_one<UNFUSED>(half_at(h, j), raw_si, raw_zp));
     }
-    if (want_q) *reinterpret_cast<Char8*>(out_q + img + p * g.C) = oq;
+    // (the quantizers only where their output exists -- kernel-uniform branches -- and with the packed helper:
+    //  the pass is VALU-bound, and the raw-input quantizer ran for every element whether or not it was wanted)
+    if (want_q) *reinterpret_cast<uint2*>(out_q + img + p * g.C) = quantize_pack8<UNFUSED>(y8, s_inv, zp);
     if (out_h) *reinterpret_cast<Half8*>(out_h + img + p * g.C) = oh;
-    if (raw_q) *reinterpret_cast<Char8*>(raw_q + p * xs) = rq;
+    if (raw_q) *reinterpret_cast<uint2*>(raw_q + p * xs) = quantize_pack8<UNFUSED>(h8, raw_si, raw_zp);
   }
 }
 
@@ -383,22 +384,18 @@ __global__ __launch_bounds__(256) void ln_quant_kernel(
       if (c < nch) {
         const Half8 gm = gmv[i], bt = btv[i];
         Half8 oh;
-        Char8 a, b, d;
-        a.w[0] = a.w[1] = b.w[0] = b.w[1] = d.w[0] = d.w[1] = 0;
         oh.w[0] = oh.w[1] = oh.w[2] = oh.w[3] = 0;
+        float y[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float nrm = __fmul_rn(__fsub_rn(half_at(h[r][i], j), mean[r]), rstd[r]);
-          const float y = round_f16(__builtin_fmaf(nrm, half_at(gm, j), half_at(bt, j)));
-          if constexpr (WANT_H) put_half(oh, j, y);
-          if constexpr (NQ > 0) put_q(a, j, quantize_one<UNFUSED>(y, si0, z0));
-          if constexpr (NQ > 1) put_q(b, j, quantize_one<UNFUSED>(y, si1, z1));
-          if constexpr (NQ > 2) put_q(d, j, quantize_one<UNFUSED>(y, si2, z2));
+          y[j] = round_f16(__builtin_fmaf(nrm, half_at(gm, j), half_at(bt, j)));
+          if constexpr (WANT_H) put_half(oh, j, y[j]);
         }
-        const int64_t off = (row0 + r) * C + 8 * c;
-        if constexpr (NQ > 0) *reinterpret_cast<Char8*>(q0 + off) = a;
-        if constexpr (NQ > 1) *reinterpret_cast<Char8*>(q1 + off) = b;
-        if constexpr (NQ > 2) *reinterpret_cast<Char8*>(q2 + off) = d;
+        const int64_t off = (row0 + r) * C + 8 * c;     // (quantize_pack8: clamp and packing in 3 instructions per pair)
+        if constexpr (NQ > 0) *reinterpret_cast<uint2*>(q0 + off) = quantize_pack8<UNFUSED>(y, si0, z0);
+        if constexpr (NQ > 1) *reinterpret_cast<uint2*>(q1 + off) = quantize_pack8<UNFUSED>(y, si1, z1);
+        if constexpr (NQ > 2) *reinterpret_cast<uint2*>(q2 + off) = quantize_pack8<UNFUSED>(y, si2, z2);
         if constexpr (WANT_H) *reinterpret_cast<Half8*>(out_h + off) = oh;
       }
     }
@@ -422,9 +419,8 @@ __global__ __launch_bounds__(256) void geglu_quant_kernel(
     const Half8 xv = *reinterpret_cast<const Half8*>(h + m * 2 * D + 8 * c);
     const Half8 gv = *reinterpret_cast<const Half8*>(h + m * 2 * D + D + 8 * c);
     Half8 oh;
-    Char8 oq;
-    oq.w[0] = oq.w[1] = 0;
     oh.w[0] = oh.w[1] = oh.w[2] = oh.w[3] = 0;
+    float y8[8];
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {       // two gate values at a time (packed FP32: geluf2)
       const v2f g2 = geluf2(v2f{half_at(gv, j), half_at(gv, j + 1)});
@@ -433,10 +429,10 @@ __global__ __launch_bounds__(256) void geglu_quant_kernel(
         const float ge = round_f16(g2[e]);
         const float y = round_f16(__fmul_rn(half_at(xv, j + e), ge));
         put_half(oh, j + e, y);
-        put_q(oq, j + e, quantize_one<UNFUSED>(y, s_inv, zp));
+        y8[j + e] = y;
       }
     }
-    if (want_q) *reinterpret_cast<Char8*>(out_q + m * D + 8 * c) = oq;
+    if (want_q) *reinterpret_cast<uint2*>(out_q + m * D + 8 * c) = quantize_pack8<UNFUSED>(y8, s_inv, zp);
     if (out_h) *reinterpret_cast<Half8*>(out_h + m * D + 8 * c) = oh;
   }
 }

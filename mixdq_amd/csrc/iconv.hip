@@ -95,6 +95,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloConvArgs
   constexpr int CS_STRIDE = G::CS_STRIDE;
   MIXDQ_ARGS_NOW(p.X, p.Wt, p.scale, p.bias, p.table, p.zp, p.D, p.res, p.res_div, p.NI, p.H, p.W, p.C,
                  p.K, p.unfused, p.ups);
+  // the activation zero point: a SCALAR load at entry (constant address space: it does not change while the
+  // kernel runs) -- read in front of the accumulator pass it was a dependent trip to memory in every launch
+  const float zpv = *(const __attribute__((address_space(4))) float*)p.zp;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -318,7 +321,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_halo_kernel(const HaloConvArgs
     }
   }
   char* Cs = smem;
-  const float zpv = *p.zp;
   auto to_tile = [&](auto mode_c) {
     constexpr int MODE = decltype(mode_c)::value;    // 0: no bias, 1: bias (FMA), 2: bias, mul then add
 #pragma unroll

@@ -227,9 +227,11 @@ __device__ __forceinline__ uint32_t geglu_pair(uint32_t xw, uint32_t gw, const c
   }
   v2h y = __builtin_bit_cast(v2h, xw) * ge;
   asm("" : "+v"(y));
-  const int q0 = quantize_one<UNFUSED>((float)y[0], s_inv, zpq);
-  const int q1 = quantize_one<UNFUSED>((float)y[1], s_inv, zpq);
-  return __builtin_amdgcn_perm((uint32_t)q1, (uint32_t)q0, 0x0c0c0400u);
+  // (clamp and packing of the pair in ONE instruction, v_ashr_pk_i8_i32: the pass is VALU-bound)
+  const float x0 = (float)y[0], x1 = (float)y[1];
+  const float t0 = UNFUSED ? __fadd_rn(__fmul_rn(x0, s_inv), zpq) : __builtin_fmaf(x0, s_inv, zpq);
+  const float t1 = UNFUSED ? __fadd_rn(__fmul_rn(x1, s_inv), zpq) : __builtin_fmaf(x1, s_inv, zpq);
+  return __builtin_amdgcn_ashr_pk_i8_i32((int)__builtin_rintf(t0), (int)__builtin_rintf(t1), 0);
 }
 // four outputs: the bytes of one dword
 template <int HOW, bool UNFUSED>
@@ -453,6 +455,21 @@ void igemm_kernel(MIXDQ_IGEMM_HEAD_PARAMS const IgemmParams p_in) {
   }
   IgemmParams p = p_in;
   MIXDQ_IGEMM_HEAD_TAKE(p);
+  // padded convs (table mode): the activation zero point, as a scalar load at entry (it was a dependent trip
+  // to memory in front of the accumulator pass)
+  float zpv_early = 0.f;
+  if constexpr (CONV) {
+    if (p_in.table != nullptr) zpv_early = *(const __attribute__((address_space(4))) float*)p_in.zp;
+  }
+  // ATT: the output quantizer's scalars, as scalar loads at entry -- read behind the attention epilogue they
+  // were a dependent trip to memory at the very end of every to_q + cross-attention launch
+  float att_sinv_early = 0.f, att_zp_early = 0.f;
+  if constexpr (ATT) {
+    if (p_in.att_sinv != nullptr) {
+      att_sinv_early = *(const __attribute__((address_space(4))) float*)p_in.att_sinv;
+      att_zp_early = *(const __attribute__((address_space(4))) float*)p_in.att_zp;
+    }
+  }
   float aq_sinv = 0.f, aq_zp = 0.f;
   bool aq_unfused = false;
   if constexpr (AQ) {
@@ -1295,7 +1312,7 @@ void igemm_kernel(MIXDQ_IGEMM_HEAD_PARAMS const IgemmParams p_in) {
   }
   char* Cs = smem;
   const bool unfused = p.unfused != 0;
-  const float zpv = use_table ? *p.zp : 0.f;
+  const float zpv = zpv_early;                     // (padded convs: read at kernel entry, see there)
   // The accumulator -> fp16 pass is straight-line code per wave: the uniform choices (bias or not,
   // fused multiply-add or not) are taken ONCE, outside (MODE), the per-channel vectors come from LDS
   // (zero-filled past N, so there is no column test: a quad past N computes zeros into a part of the
@@ -1686,7 +1703,7 @@ void igemm_kernel(MIXDQ_IGEMM_HEAD_PARAMS const IgemmParams p_in) {
       }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // wave-private staging: no block barrier
     const bool quant = p.att_sinv != nullptr;
-    const float s_inv = quant ? *p.att_sinv : 0.f, zpq = quant ? *p.att_zp : 0.f;
+    const float s_inv = att_sinv_early, zpq = att_zp_early;    // (read at kernel entry: see below)
     const bool unf = p.unfused != 0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -1699,14 +1716,11 @@ void igemm_kernel(MIXDQ_IGEMM_HEAD_PARAMS const IgemmParams p_in) {
         *reinterpret_cast<uint4*>(reinterpret_cast<__half*>(p.att_out) + off) = w;
       } else {
         const __half* hv = reinterpret_cast<const __half*>(&w);
-        uint32_t pk[2] = {0u, 0u};
+        float x[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float x = __half2float(hv[j]);
-          const int qv = unf ? quantize_one<true>(x, s_inv, zpq) : quantize_one<false>(x, s_inv, zpq);
-          pk[j >> 2] |= (uint32_t)(qv & 0xff) << (8 * (j & 3));
-        }
-        *reinterpret_cast<uint2*>(reinterpret_cast<int8_t*>(p.att_out) + off) = make_uint2(pk[0], pk[1]);
+        for (int j = 0; j < 8; ++j) x[j] = __half2float(hv[j]);
+        *reinterpret_cast<uint2*>(reinterpret_cast<int8_t*>(p.att_out) + off) =
+            unf ? quantize_pack8<true>(x, s_inv, zpq) : quantize_pack8<false>(x, s_inv, zpq);
       }
     }
     return;
@@ -2001,13 +2015,8 @@ void igemm_kernel(MIXDQ_IGEMM_HEAD_PARAMS const IgemmParams p_in) {
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
         if (k >= p.ln_nq) break;
-        uint32_t pk[2] = {0u, 0u};
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int qv = unf ? quantize_one<true>(y[j], qs[k], qz[k]) : quantize_one<false>(y[j], qs[k], qz[k]);
-          pk[j >> 2] |= (uint32_t)(qv & 0xff) << (8 * (j & 3));
-        }
-        *reinterpret_cast<uint2*>(p.ln_q[k] + off) = make_uint2(pk[0], pk[1]);
+        *reinterpret_cast<uint2*>(p.ln_q[k] + off) =
+            unf ? quantize_pack8<true>(y, qs[k], qz[k]) : quantize_pack8<false>(y, qs[k], qz[k]);
       }
     });
     MIXDQ_STAMP_AT(15);

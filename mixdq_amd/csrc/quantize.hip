@@ -16,21 +16,18 @@ struct alignas(8) Char8 { uint32_t w[2]; };
 
 template <bool UNFUSED>
 __device__ __forceinline__ Char8 quantize8(const Half8& h, float s_inv, float zp) {
-  Char8 out;
+  float x[8];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    uint32_t packed = 0;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      uint32_t w = h.w[j * 2 + (e >> 1)];
-      __half_raw hr;
-      hr.x = (unsigned short)((e & 1) ? (w >> 16) : (w & 0xffffu));
-      float x = __half2float(__half(hr));
-      int q = quantize_one<UNFUSED>(x, s_inv, zp);
-      packed |= (uint32_t)(q & 0xff) << (8 * e);
-    }
-    out.w[j] = packed;
+  for (int j = 0; j < 8; ++j) {
+    const uint32_t w = h.w[j >> 1];
+    __half_raw hr;
+    hr.x = (unsigned short)((j & 1) ? (w >> 16) : (w & 0xffffu));
+    x[j] = __half2float(__half(hr));
   }
+  const uint2 q = quantize_pack8<UNFUSED>(x, s_inv, zp);     // common.h: clamp + packing by v_ashr_pk_i8_i32 / v_perm_b32
+  Char8 out;
+  out.w[0] = q.x;
+  out.w[1] = q.y;
   return out;
 }
 
