@@ -68,6 +68,7 @@ struct AttnParams {
   // prefetch payload (mixdq_attention_f16_prefetch): workgroups attn_blocks .. attn_blocks + pf_blocks - 1
   // read these byte ranges and do nothing else
   int attn_blocks, pf_blocks, n_pf, pf_nt;
+  int pf_delay;                    // payload workgroups sleep pf_delay x 127 x 64 clocks (~3.9 us each) before their first load
   const char* pf_ptr[16];
   long pf_bytes[16];
 };
@@ -76,6 +77,11 @@ struct AttnParams {
 // together a contiguous stripe; eight loads in flight per lane.  The values are folded into a register the
 // compiler must keep (an empty asm consumes it): nothing is written.
 __device__ __forceinline__ void attn_prefetch_role(const AttnParams& p) {
+  // The payload starts LATE: its workgroups are dispatched within a microsecond of the attention's, and 24 MB of
+  // loads in flight at that moment sit in front of the attention's own first requests (Q, the first K/V tiles:
+  // entry -> prologue issued 2.4 -> 5.6 us, tools/stamp_attn.py --payload 24); the attention needs the memory
+  // side for ~4 us and then runs out of L2 / LDS, which is when the payload should stream.
+  for (int i = 0; i < p.pf_delay; ++i) __builtin_amdgcn_s_sleep(127);
   const long first = ((long)(blockIdx.x - p.attn_blocks) * blockDim.x + threadIdx.x) * 16;
   const long stride = (long)p.pf_blocks * blockDim.x * 16;
   v4i acc = {0, 0, 0, 0};
@@ -740,7 +746,7 @@ static int attention_f16_impl(const void* q, const void* k, const void* v, void*
   p.scale_log2 = softmax_scale * 1.4426950408889634f;
   p.s_inv = out_scale_inv; p.zp = out_zero_point;
   p.unfused = (flags & MIXDQ_FLAG_UNFUSED) ? 1 : 0;
-  p.attn_blocks = 0; p.pf_blocks = 0; p.n_pf = 0; p.pf_nt = 0;
+  p.attn_blocks = 0; p.pf_blocks = 0; p.n_pf = 0; p.pf_nt = 0; p.pf_delay = 0;
   for (int i = 0; i < 16; ++i) { p.pf_ptr[i] = nullptr; p.pf_bytes[i] = 0; }
   for (int i = 0; i < n_pf; ++i) {
     if (!pf_ptrs[i] || pf_bytes[i] < 16) continue;
@@ -755,8 +761,10 @@ static int attention_f16_impl(const void* q, const void* k, const void* v, void*
   if (p.n_pf) {   // one payload workgroup per CU by default (MIXDQ_PREFETCH_BLOCKS / MIXDQ_PREFETCH_NT: A/B runs)
     static const int blocks = [] { const char* e = getenv("MIXDQ_PREFETCH_BLOCKS"); return e ? atoi(e) : kNumCU; }();
     static const int nt = [] { const char* e = getenv("MIXDQ_PREFETCH_NT"); return e ? atoi(e) : 0; }();
+    static const int delay = [] { const char* e = getenv("MIXDQ_PREFETCH_DELAY"); return e ? atoi(e) : 0; }();
     p.pf_blocks = blocks > 0 ? blocks : 0;
     p.pf_nt = nt;
+    p.pf_delay = delay >= 0 && delay <= 16 ? delay : 0;
     if (p.pf_blocks == 0) p.n_pf = 0;
   }
 
