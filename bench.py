@@ -303,6 +303,13 @@ def roofline_object(roof_stats, B, reps, px, tiny):
     }
 
 
+def under_rocprof() -> bool:
+    """Is this process running under rocprofv3?  (Then torch.profiler -- a second tracer in the process -- is not
+    started: the legs that count kernels with it are skipped, whatever the flags say.  ADVICE r4.)"""
+    return bool(os.environ.get("ROCP_TOOL_LIBRARIES") or os.environ.get("ROCPROFILER_REGISTER_FORCE_LOAD")
+                or "rocprofiler" in os.environ.get("LD_PRELOAD", ""))
+
+
 def csrc_sha16():
     """sha256 (first 16 hex digits) over the kernel sources the running library was built from."""
     import hashlib
@@ -704,7 +711,7 @@ def main():
     in_step = None
     if not args.no_roofline and rank == 0:
         roof_stats = roofline_sweep(lambda: eager_forward(**inputs), device, args.sweep_reps)
-        if not os.environ.get("ROCP_TOOL_LIBRARIES") and not os.environ.get("ROCPROFILER_REGISTER_FORCE_LOAD"):
+        if not under_rocprof():
             # (an EAGER forward of the timed graph's launches -- tracing a hipGraph replay through torch.profiler
             #  crashed the process on ROCm 7.2; and not under rocprofv3: two tracers in one process)
             in_step = in_step_kernel_times(lambda: eager_forward(**inputs), device)
@@ -738,7 +745,7 @@ def main():
     #      an unchanged graph): the same quantized network with this repo's producer fusions off --
     #      one quantize launch per layer, torch GroupNorm / LayerNorm / GELU / SDPA glue -- in a hipGraph.
     dropin = None
-    if default_line and not args.no_dropin and not args.no_fuse:
+    if default_line and not args.no_dropin and not args.no_fuse and not under_rocprof():
         unet.forward = eager_forward
         unet.set_fused(False)
         with torch.no_grad():
@@ -756,7 +763,7 @@ def main():
     # ---- the same fused graph with every eligible LayerNorm riding in its producer GEMM's launch (DESIGN.md 3.13:
     #      off by default because it is time-neutral): its step time and kernel count beside the headline's
     ln_in_gemm = None
-    if default_line and not args.no_lnchain and not args.no_fuse:
+    if default_line and not args.no_lnchain and not args.no_fuse and not under_rocprof():
         import mixdq_amd.unet as U_
         saved_chain = U_.LN_CHAIN
         try:
