@@ -654,3 +654,24 @@ def test_prefetch_state_is_per_forward_and_per_thread():
     with ctx_m:
         _C._trace_w(wa)
         assert ctx_m.trace == [] and ctx_m.payload() == []
+
+
+def test_f16in_rows_view_accepts_exactly_the_operands_the_kernel_can_read_in_place():
+    """mixdq_amd._C._rows_view (host logic of the quantize-in-prologue GEMM): an FP16 operand is read in place when
+    its rows of K contiguous values are a CONSTANT stride apart -- a dense tensor with any leading shape, a
+    last-dimension slice of one (the split shortcut's halves over NHWC rows) -- and nothing else: the BOS slice
+    x[:, 1:, :] at batch > 1 (two strides) goes through the row map, a transposed operand through two launches."""
+    from mixdq_amd._C import _rows_view
+    x = torch.zeros(2, 77, 64, dtype=torch.float16)
+    assert _rows_view(x, 64) == (154, 64, [2, 77])
+    assert _rows_view(x[..., :32], 32) == (154, 64, [2, 77])                  # column slice: lda = all columns
+    assert _rows_view(x[..., 32:], 32) == (154, 64, [2, 77])
+    assert _rows_view(x[:1, 1:, :], 64) == (76, 64, [1, 76])                  # batch 1: one stride
+    assert _rows_view(x[:, 1:, :], 64) is None                                # batch 2: rows are not equidistant
+    assert _rows_view(x.transpose(1, 2), 77) is None                          # last dimension not contiguous
+    assert _rows_view(x, 32) is None                                          # K must be the last dimension
+    nhwc = torch.zeros(2, 96, 6, 6, dtype=torch.float16).contiguous(memory_format=torch.channels_last)
+    rows = nhwc[:, :64].permute(0, 2, 3, 1)                                   # the first half of a split shortcut
+    assert _rows_view(rows, 64) == (72, 96, [2, 6, 6])
+    assert _rows_view(torch.zeros(0, 64, dtype=torch.float16), 64) is None
+    assert _rows_view(torch.zeros(1, 64, dtype=torch.float16), 64) == (1, 64, [1])
