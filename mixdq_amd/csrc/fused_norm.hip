@@ -54,6 +54,8 @@ struct GnGeom {
   int ppb;      // pixels per block (multiple of PP)
   int nchunk;   // blocks per image
   int ppb_apply, nchunk_apply;   // apply pass split (elementwise: order-free; = the statistics')
+  int OCs, PPa, GS;              // apply pass: octets per channel slice (blockIdx.z), its pixel lanes, groups per
+                                 // slice (OC, PP, G when the pass is not sliced)
   int C1;       // two-source input (a skip connection never concatenated in memory): channels
                 // 0 .. C1-1 come from x [N, HW, C1], the rest from x2 [N, HW, C - C1]; C1 == C: one
 };
@@ -128,15 +130,8 @@ __device__ __forceinline__ float wave_sum_gn(float v) {
 
 // mean / rstd of group `grp` of image n from the chunk partials, by one 64-lane wave; the result
 // goes to out[grp] (the apply kernel's LDS table).
-__device__ __forceinline__ void gn_finalize_group(const float2* __restrict__ partial, float2* out,
-                                                  const GnGeom& g, float eps, int grp, int n,
-                                                  int lane) {
-  float s = 0.f, q = 0.f;
-  for (int c = lane; c < g.nchunk; c += 64) {
-    const float2 v = partial[((int64_t)n * g.nchunk + c) * g.G + grp];
-    s = __fadd_rn(s, v.x);
-    q = __fadd_rn(q, v.y);
-  }
+__device__ __forceinline__ void gn_finalize_tail(float s, float q, float2* out, const GnGeom& g, float eps,
+                                                 int grp, int lane) {
   s = wave_sum_gn(s);
   q = wave_sum_gn(q);
   if (lane == 0) {
@@ -149,6 +144,45 @@ __device__ __forceinline__ void gn_finalize_group(const float2* __restrict__ par
   }
 }
 
+__device__ __forceinline__ void gn_finalize_group(const float2* __restrict__ partial, float2* out,
+                                                  const GnGeom& g, float eps, int grp, int n,
+                                                  int lane) {
+  float s = 0.f, q = 0.f;
+  for (int c = lane; c < g.nchunk; c += 64) {
+    const float2 v = partial[((int64_t)n * g.nchunk + c) * g.G + grp];
+    s = __fadd_rn(s, v.x);
+    q = __fadd_rn(q, v.y);
+  }
+  gn_finalize_tail(s, q, out, g, eps, grp, lane);
+}
+
+// The same, for TWO groups at once and with every partial requested before the first is used (at most
+// 512 partials per group: 8 per lane): the apply blocks of the sliced pass run this in their prologue, where
+// the loads' latency -- the partials come from other XCDs' statistics blocks, i.e. from the memory side --
+// is the whole cost.  Same order of additions as gn_finalize_group (lane l: partials l, l + 64, ... ascending).
+__device__ __forceinline__ void gn_finalize_pair(const float2* __restrict__ partial, float2* out,
+                                                 const GnGeom& g, float eps, int ga, int gb, bool has_b,
+                                                 int n, int lane) {
+  constexpr int R = 8;
+  float2 va[R], vb[R];
+  const float2* base = partial + (int64_t)n * g.nchunk * g.G;
+#pragma unroll
+  for (int k = 0; k < R; ++k) {   // unconditional (a branch per round made the compiler drain the loads round by
+    const int c = min(lane + 64 * k, g.nchunk - 1);   // round); clamped: an address that exists, an L2 hit
+    va[k] = base[(int64_t)c * g.G + ga];
+    vb[k] = base[(int64_t)c * g.G + gb];
+  }
+  float sa = 0.f, qa = 0.f, sb = 0.f, qb = 0.f;
+#pragma unroll
+  for (int k = 0; k < R; ++k)
+    if (lane + 64 * k < g.nchunk) {
+      sa = __fadd_rn(sa, va[k].x); qa = __fadd_rn(qa, va[k].y);
+      sb = __fadd_rn(sb, vb[k].x); qb = __fadd_rn(qb, vb[k].y);
+    }
+  gn_finalize_tail(sa, qa, out, g, eps, ga, lane);
+  if (has_b) gn_finalize_tail(sb, qb, out, g, eps, gb, lane);
+}
+
 __global__ __launch_bounds__(64) void gn_finalize_kernel(const float2* __restrict__ partial,
                                                          float2* __restrict__ stats, GnGeom g,
                                                          float eps) {
@@ -156,7 +190,9 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float2* __restric
                     threadIdx.x);
 }
 
-template <bool SILU, bool UNFUSED>
+// SELF: the blocks reduce their groups' partials themselves (stats == nullptr); a template parameter because as a
+// run-time branch the two forms shared registers and the compiler drained every load where they met.
+template <bool SILU, bool UNFUSED, bool SELF>
 __global__ void gn_apply_kernel(const __half* __restrict__ x, const __half* __restrict__ x2,
                                 const float2* __restrict__ partial,
                                 const float2* __restrict__ stats, float eps,
@@ -166,24 +202,46 @@ __global__ void gn_apply_kernel(const __half* __restrict__ x, const __half* __re
                                 int8_t* __restrict__ out_q, __half* __restrict__ out_h, GnGeom g,
                                 GnRaw raw) {
   MIXDQ_ARGS_NOW(x, x2, partial, stats, eps, gamma, beta, s_inv_p, zp_p, out_q, out_h);
-  MIXDQ_ARGS_NOW(g.C, g.G, g.cg, g.OC, g.PP, g.HW, g.ppb_apply, g.nchunk, g.C1, raw.s_inv[0],
+  MIXDQ_ARGS_NOW(g.C, g.G, g.cg, g.OCs, g.PPa, g.GS, g.HW, g.ppb_apply, g.nchunk, g.C1, raw.s_inv[0],
                  raw.s_inv[1], raw.zp[0], raw.zp[1], raw.q[0], raw.q[1]);
   __shared__ float2 s_stats[1024];   // G <= OC * PP <= 1024
+  // the quantizers' scalars as scalar loads at kernel entry (kernel-uniform addresses; as plain loads they were
+  // vector loads issued after the statistics, the raw pair behind a pointer fetched from the argument block)
+  using cf32 = const __attribute__((address_space(4))) float;
+  const bool want_q = out_q != nullptr;
+  const float s_inv = want_q ? *(cf32*)s_inv_p : 0.f, zp = want_q ? *(cf32*)zp_p : 0.f;
+  const float raw_si0 = raw.q[0] ? *(cf32*)raw.s_inv[0] : 0.f, raw_zp0 = raw.q[0] ? *(cf32*)raw.zp[0] : 0.f;
+  const float raw_si1 = raw.q[1] ? *(cf32*)raw.s_inv[1] : 0.f, raw_zp1 = raw.q[1] ? *(cf32*)raw.zp[1] : 0.f;
   const int t = threadIdx.x;
-  const int o = t % g.OC, pp = t / g.OC;
+  // channel slice blockIdx.z: octets [z * OCs, (z + 1) * OCs) = groups [z * GS, (z + 1) * GS) -- a slice ends
+  // on a group boundary; one slice (OCs = OC, PPa = PP, GS = G) unless the launch sliced the pass
+  const int o = (int)blockIdx.z * g.OCs + t % g.OCs, pp = t / g.OCs;
   const int n = blockIdx.y, chunk = blockIdx.x;
   const int g0 = (8 * o) / g.cg;
   const int jb = min(8, (g0 + 1) * g.cg - 8 * o);
   const Half8 gm = *reinterpret_cast<const Half8*>(gamma + 8 * o);
   const Half8 bt = *reinterpret_cast<const Half8*>(beta + 8 * o);
   float2 st0, st1;
-  if (stats == nullptr) {
-    // at most 64 partials per group (small images): every block reduces its image's partials itself
-    // (one per lane, then the fixed butterfly) -- cheaper than the kernel boundary of a separate
-    // finalize launch; with more partials per group the finalize kernel ran first (stats != null)
+  if constexpr (SELF) {
+    // Every block reduces the partials of ITS groups itself (lane l: partials l, l + 64, ...; then the fixed
+    // butterfly) -- cheaper than the kernel boundary of a separate finalize launch: all G groups where an
+    // image has at most 64 partials per group, and in the sliced pass (round 5) the GS <= 8 groups of the
+    // block's channel slice whatever their count; otherwise the finalize kernel ran first (stats != null)
     const int nfull = (int)blockDim.x >> 6, wave = t >> 6;   // complete waves only
-    if (wave < nfull)
-      for (int grp = wave; grp < g.G; grp += nfull) gn_finalize_group(partial, s_stats, g, eps, grp, n, t & 63);
+    const int gfirst = (int)blockIdx.z * g.GS;
+    if (g.GS <= 2 * nfull) {   // the sliced pass: one pair per wave, straight-line (in a loop the compiler drains
+      if (wave < nfull && wave < g.GS) {   // the gamma / beta loads before the first partial is requested)
+        const bool has_b = wave + nfull < g.GS;
+        gn_finalize_pair(partial, s_stats, g, eps, gfirst + wave, gfirst + (has_b ? wave + nfull : wave), has_b,
+                         n, t & 63);
+      }
+    } else if (wave < nfull) {
+      for (int r = wave; r < g.GS; r += 2 * nfull) {
+        const bool has_b = r + nfull < g.GS;
+        gn_finalize_pair(partial, s_stats, g, eps, gfirst + r, gfirst + (has_b ? r + nfull : r), has_b, n,
+                         t & 63);
+      }
+    }
     __syncthreads();
     st0 = s_stats[g0];
     st1 = s_stats[min(g0 + 1, g.G - 1)];
@@ -198,18 +256,16 @@ __global__ void gn_apply_kernel(const __half* __restrict__ x, const __half* __re
     a[j] = __fmul_rn(rstd, half_at(gm, j));
     b[j] = __builtin_fmaf(-mean, a[j], half_at(bt, j));
   }
-  const bool want_q = out_q != nullptr;
-  const float s_inv = want_q ? *s_inv_p : 0.f, zp = want_q ? *zp_p : 0.f;
   const int64_t p_begin = (int64_t)chunk * g.ppb_apply;
   const int64_t p_end = min(g.HW, p_begin + g.ppb_apply);
   const int64_t img = ((int64_t)n * g.HW) * g.C + 8 * o;
   int xs;
   const __half* src = gn_src(x, x2, g, n, o, xs);
   const int which = 8 * o < g.C1 ? 0 : 1;
-  int8_t* raw_q = raw.q[which];
-  const float raw_si = raw_q ? *raw.s_inv[which] : 0.f, raw_zp = raw_q ? *raw.zp[which] : 0.f;
+  int8_t* raw_q = which ? raw.q[1] : raw.q[0];
+  const float raw_si = which ? raw_si1 : raw_si0, raw_zp = which ? raw_zp1 : raw_zp0;
   if (raw_q) raw_q += ((int64_t)n * g.HW) * xs + (8 * o - (which ? g.C1 : 0));
-  for (int64_t p = p_begin + pp; p < p_end; p += g.PP) {
+  for (int64_t p = p_begin + pp; p < p_end; p += g.PPa) {
     const Half8 h = *reinterpret_cast<const Half8*>(src + p * xs);
     Half8 oh;
     oh.w[0] = oh.w[1] = oh.w[2] = oh.w[3] = 0;
@@ -249,6 +305,7 @@ inline bool make_gn_geom(int N, int64_t HW, int C, int G, GnGeom& g) {
   g.nchunk = (int)((HW + ppb - 1) / ppb);
   g.ppb_apply = g.ppb;
   g.nchunk_apply = g.nchunk;
+  g.OCs = g.OC; g.PPa = g.PP; g.GS = G;
   g.C1 = C;
   return true;
 }
@@ -526,8 +583,19 @@ extern "C" int mixdq_groupnorm_silu_quantize3(const void* x_nhwc, int C1, const 
   const int threads = g.OC * g.PP;
   gn_stats_kernel<<<dim3(g.nchunk, N), threads, threads * 4 * sizeof(float), stream>>>(
       (const __half*)x_nhwc, (const __half*)x2_nhwc, partial, g);
-  float2* stats = nullptr;          // null: the apply blocks finalize themselves (<= 64 partials)
-  if (g.nchunk > 64) {
+  // MIXDQ_GN_SLICED=1 (measured, off): with more than 64 partials per group the apply pass is cut into channel
+  // slices (blockIdx.z) of whole groups, at most 8 groups each, so that a block needs -- and reduces in its
+  // prologue -- only its slice's statistics (4 x 342 x 8 B at C = 640) and the finalize launch disappears (46 per
+  // batch-1 step).  Bit-exact, and slower: slices are 160-320 contiguous bytes per pixel (80-byte INT8 rows), the
+  // prologue's strided partial reads are one cache line per lane: batch 1 11.08 -> 11.24 ms, batch 8 47.5 -> 48.9
+  // (profiles/r05_gn_finalize_ab.txt).
+  static const bool sliced_on = [] { const char* e = getenv("MIXDQ_GN_SLICED"); return e && e[0] == '1'; }();
+  int nslice = 1;
+  if (g.nchunk > 64 && sliced_on)
+    for (int s = 8; s >= 2 && nslice == 1; s >>= 1)
+      if (g.OC % s == 0 && G % s == 0 && G / s <= 8 && g.OC / s >= 10) nslice = s;
+  float2* stats = nullptr;          // null: the apply blocks finalize themselves
+  if (g.nchunk > 64 && nslice == 1) {
     stats = partial + (size_t)N * g.nchunk * G;
     gn_finalize_kernel<<<dim3(G, N), 64, 0, stream>>>(partial, stats, g, eps);
   }
@@ -542,10 +610,19 @@ extern "C" int mixdq_groupnorm_silu_quantize3(const void* x_nhwc, int C1, const 
     g.ppb_apply = (g.ppb / 2 / g.PP) * g.PP;
     g.nchunk_apply = (int)((HW + g.ppb_apply - 1) / g.ppb_apply);
   }
-  const dim3 grid(g.nchunk_apply, N);
+  int threads_apply = threads;
+  if (nslice > 1) {   // the same number of pixels per THREAD as the unsliced pass would take
+    const int iters = g.ppb_apply / g.PP;
+    g.OCs = g.OC / nslice; g.GS = G / nslice;
+    g.PPa = (256 + g.OCs - 1) / g.OCs;          // >= 256 threads: four complete waves for the prologue
+    g.ppb_apply = iters * g.PPa;
+    g.nchunk_apply = (int)((HW + g.ppb_apply - 1) / g.ppb_apply);
+    threads_apply = g.OCs * g.PPa;
+  }
+  const dim3 grid(g.nchunk_apply, N, nslice);
   const bool unfused = flags & MIXDQ_FLAG_UNFUSED;
 #define GN_APPLY(S, U)                                                                          \
-  gn_apply_kernel<S, U><<<grid, threads, 0, stream>>>(                                          \
+  (stats ? gn_apply_kernel<S, U, false> : gn_apply_kernel<S, U, true>)<<<grid, threads_apply, 0, stream>>>( \
       (const __half*)x_nhwc, (const __half*)x2_nhwc, partial, stats, eps, (const __half*)gamma, \
       (const __half*)beta,                                                                      \
       scale_inv, zero_point, out_q_or_null, (__half*)out_f16_or_null, g, raw)

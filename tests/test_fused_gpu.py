@@ -32,6 +32,10 @@ GN_CASES = [  # N, H, W, C, G, silu
     (1, 12, 12, 960, 32, True), (1, 4, 4, 1920, 32, True), (1, 4, 4, 2560, 32, True),
     (3, 5, 7, 64, 8, True), (2, 16, 16, 32, 8, False), (1, 1, 1, 128, 8, True),
     (1, 128, 128, 320, 32, True),
+    # more than 64 partials per group: the sliced apply pass reduces its slice's groups itself (8 slices of 4
+    # groups; 4 slices of 8 at C = 320 above) -- and a shape it cannot slice, which keeps the finalize launch
+    (1, 32, 32, 640, 32, True), (2, 16, 16, 1280, 32, True), (1, 32, 32, 1920, 32, False),
+    (1, 64, 64, 64, 8, True),
 ]
 
 
