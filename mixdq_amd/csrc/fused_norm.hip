@@ -221,6 +221,15 @@ __global__ void gn_apply_kernel(const __half* __restrict__ x, const __half* __re
   const int jb = min(8, (g0 + 1) * g.cg - 8 * o);
   const Half8 gm = *reinterpret_cast<const Half8*>(gamma + 8 * o);
   const Half8 bt = *reinterpret_cast<const Half8*>(beta + 8 * o);
+  // the block's first pixel is requested here, beside gamma / beta / the statistics, not behind them: at batch 1
+  // a thread has one or two pixels, and the pass was two memory round trips in a row (statistics, then pixels)
+  const int64_t p_begin = (int64_t)chunk * g.ppb_apply;
+  const int64_t p_end = min(g.HW, p_begin + g.ppb_apply);
+  int xs;
+  const __half* src = gn_src(x, x2, g, n, o, xs);
+  Half8 h_next;
+  h_next.w[0] = h_next.w[1] = h_next.w[2] = h_next.w[3] = 0;
+  if (p_begin + pp < p_end) h_next = *reinterpret_cast<const Half8*>(src + (p_begin + pp) * xs);
   float2 st0, st1;
   if constexpr (SELF) {
     // Every block reduces the partials of ITS groups itself (lane l: partials l, l + 64, ...; then the fixed
@@ -256,17 +265,14 @@ __global__ void gn_apply_kernel(const __half* __restrict__ x, const __half* __re
     a[j] = __fmul_rn(rstd, half_at(gm, j));
     b[j] = __builtin_fmaf(-mean, a[j], half_at(bt, j));
   }
-  const int64_t p_begin = (int64_t)chunk * g.ppb_apply;
-  const int64_t p_end = min(g.HW, p_begin + g.ppb_apply);
   const int64_t img = ((int64_t)n * g.HW) * g.C + 8 * o;
-  int xs;
-  const __half* src = gn_src(x, x2, g, n, o, xs);
   const int which = 8 * o < g.C1 ? 0 : 1;
   int8_t* raw_q = which ? raw.q[1] : raw.q[0];
   const float raw_si = which ? raw_si1 : raw_si0, raw_zp = which ? raw_zp1 : raw_zp0;
   if (raw_q) raw_q += ((int64_t)n * g.HW) * xs + (8 * o - (which ? g.C1 : 0));
   for (int64_t p = p_begin + pp; p < p_end; p += g.PPa) {
-    const Half8 h = *reinterpret_cast<const Half8*>(src + p * xs);
+    const Half8 h = h_next;
+    if (p + g.PPa < p_end) h_next = *reinterpret_cast<const Half8*>(src + (p + g.PPa) * xs);
     Half8 oh;
     oh.w[0] = oh.w[1] = oh.w[2] = oh.w[3] = 0;
     float y8[8], h8[8];
