@@ -327,10 +327,21 @@ inline bool make_gn_geom(int N, int64_t HW, int C, int G, GnGeom& g) {
 constexpr int kLnMaxChunks = 4;   // C <= 2048
 constexpr int kLnMaxGroups = 64 * kLnMaxChunks / 2;
 
-// balanced tree over the values of lanes 0 .. U-1 (U a power of two <= 16); every lane returns the total
+// balanced tree over the values of lanes 0 .. U-1 (U a power of two <= 16): pairs at distance 1, 2, 4, 8 by DPP
+// (quad permutes, then the half-row and row mirrors: after two levels a quad holds one value, after three a
+// half-row does, so a mirror reads the value the xor partner holds) -- the pairs, hence the bits, of the xor
+// butterfly this replaces (__shfl_xor is ds_bpermute, the LDS crossbar: twelve of them were on the row's critical
+// path); every lane returns the total.
+template <int CTRL>
+__device__ __forceinline__ float ln_dpp_f(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float ln_tree(float t, int U) {
-  for (int off = 1; off < U; off <<= 1) t = __fadd_rn(t, __shfl_xor(t, off, 64));
-  return __shfl(t, 0, 64);
+  if (U > 1) t = __fadd_rn(t, ln_dpp_f<0xB1>(t));    // quad_perm [1,0,3,2]
+  if (U > 2) t = __fadd_rn(t, ln_dpp_f<0x4E>(t));    // quad_perm [2,3,0,1]
+  if (U > 4) t = __fadd_rn(t, ln_dpp_f<0x141>(t));   // row_half_mirror
+  if (U > 8) t = __fadd_rn(t, ln_dpp_f<0x140>(t));   // row_mirror
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, t)));
 }
 // NQ: quantizers in use (0..3), WANT_H: the FP16 copy is written -- compile-time, so a launch with one
 // consumer does not run the other two quantizers' arithmetic on its one-wave-per-SIMD critical path.
@@ -398,7 +409,7 @@ __global__ __launch_bounds__(256) void ln_quant_kernel(
         float s8 = half_at(h[r][i], 0);
 #pragma unroll
         for (int j = 1; j < 8; ++j) s8 = __fadd_rn(s8, half_at(h[r][i], j));
-        const float s1 = __fadd_rn(s8, __shfl_xor(s8, 1, 64));      // the group's two halves
+        const float s1 = __fadd_rn(s8, ln_dpp_f<0xB1>(s8));          // the group's two halves
         mg[i] = __fmul_rn(s1, 0.0625f);
         float q8 = 0.f;
 #pragma unroll
@@ -406,7 +417,7 @@ __global__ __launch_bounds__(256) void ln_quant_kernel(
           const float d = __fsub_rn(half_at(h[r][i], j), mg[i]);
           q8 = __builtin_fmaf(d, d, q8);
         }
-        m2[i] = __fadd_rn(q8, __shfl_xor(q8, 1, 64));
+        m2[i] = __fadd_rn(q8, ln_dpp_f<0xB1>(q8));
         if ((lane & 1) == 0) sh[c >> 1] = s1;
       }
     }
