@@ -85,6 +85,23 @@ def test_groupnorm_equals_unfused_pipeline_on_its_own_fp16(C):
     assert torch.equal(C.quantize_per_tensor_to_int8(h, s_inv, zp), q)
 
 
+def test_groupnorm_sliced_apply_pass_same_bits():
+    """MIXDQ_GN_SLICED=1 (the finalize launch folded into a channel-sliced apply pass: measured slower, off by
+    default) is read once per process: the GroupNorm parity cases -- oracle, two sources, raw
+    outputs -- again in a child process with the switch on."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MIXDQ_GN_SLICED="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_fused_gpu.py", "-m", "gpu", "-q", "-x",
+                        "-p", "no:cacheprovider", "-k",
+                        "test_groupnorm_silu_quantize or two_sources or raw_outputs"],
+                       cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-3000:]
+
+
 def test_groupnorm_unsupported_shapes_raise(C):
     x = torch.zeros(1, 36, 4, 4, dtype=torch.float16, device=DEV).contiguous(
         memory_format=torch.channels_last)
