@@ -266,7 +266,8 @@ def roofline_object(roof_stats, B, reps, px, tiny):
         prov = table.get("_provenance", {})
         traffic_source.update(prov)
         traffic_source["csrc_sha16_running"] = csrc_sha16()
-        traffic_source["stale"] = prov.get("csrc_sha16") != traffic_source["csrc_sha16_running"]
+        traffic_source["stale"] = (traffic_source["csrc_sha16_running"] is None
+                                   or prov.get("csrc_sha16") != traffic_source["csrc_sha16_running"])
         if not traffic_source["stale"]:
             pmc_all = table.get(f"bs{B}", {})
         entry = pmc_all.get(dom) or pmc_all.get(dom.split("#")[0], {})     # "...#cfgNN" where a tile has several wave layouts
@@ -311,15 +312,19 @@ def under_rocprof() -> bool:
 
 
 def csrc_sha16():
-    """sha256 (first 16 hex digits) over the kernel sources the running library was built from."""
-    import hashlib
-    h = hashlib.sha256()
-    d = os.path.join(ROOT, "mixdq_amd", "csrc")
-    for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".h")):
-            with open(os.path.join(d, name), "rb") as f:
-                h.update(name.encode() + b"\0" + f.read())
-    return h.hexdigest()[:16]
+    """sha256 (first 16 hex digits) of the kernel sources the LOADED library was built from: the hash
+    mixdq_amd/build.py embedded in it (mixdq_build_csrc_sha16), read back through the library -- not a hash of the
+    tree on disk, which says nothing about a stale .so or one named by MIXDQ_HIP_LIB.  None: a library that does
+    not carry one (a build of an older tree); provenance is then unknown and the counter columns are dropped."""
+    import ctypes
+    import mixdq_amd._C as C
+    try:
+        fn = C._lib.mixdq_build_csrc_sha16
+    except AttributeError:
+        return None
+    fn.restype = ctypes.c_char_p
+    v = fn()
+    return v.decode() if v else None
 
 
 def kernel_name_pattern(kname):

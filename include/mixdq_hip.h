@@ -83,6 +83,10 @@ enum mixdq_flags {
 
 const char* mixdq_status_string(int status);
 int mixdq_abi_version(void);
+/* sha256 (first 16 hex digits) over the kernel sources this library was built from (mixdq_amd/build.py writes it
+ * at build time): lets a run say which sources the LOADED library carries -- the provenance check of bench.py's
+ * counter columns -- whatever MIXDQ_HIP_LIB points at. */
+const char* mixdq_build_csrc_sha16(void);
 
 /* ---------------------------------------------------------------------------------------------
  * a1. FP16 -> INT8 per-tensor affine quantize.
@@ -299,10 +303,16 @@ int mixdq_layernorm_quantize(const void* x_f16, const void* gamma_f16, const voi
  * (mixdq_qlinear_ln_select_id() < 0; the caller then issues the two launches).
  * `workspace`: mixdq_qlinear_ln_workspace_bytes(M, N) bytes, 16-byte aligned, ZERO before the first use (its
  * first page holds a launch counter that tags the records: a launch of any shape may follow on the same
- * buffer).  One launch at a time per workspace (launches of one stream are).
+ * buffer).  One launch at a time per workspace (launches of one stream are) AND per device: the tiles of a row
+ * block wait for each other, so the whole grid must be resident at once -- the entry point checks the grid against
+ * the device's real CU count and the runtime's occupancy answer (MIXDQ_ERR_SHAPE if it does not fit), but two such
+ * launches on DIFFERENT streams of one device can each hold CUs the other needs: do not run them concurrently.  A
+ * workgroup that gives up waiting (bounded spin) writes its rows as NaN and sets a sticky error word in the
+ * workspace; mixdq_qlinear_ln_status() reads it (0 = every launch on this workspace found all its records).
  * No reference counterpart (stock nn.LayerNorm + quant_op, nn/Linear.py:162-164). */
 size_t mixdq_qlinear_ln_workspace_bytes(int64_t M, int N);
 int mixdq_qlinear_ln_select_id(int64_t M, int N, int K);   /* tile id (44, 45, 56) or -1 = not supported */
+int mixdq_qlinear_ln_status(const void* workspace, int* status, mixdq_stream_t stream);   /* blocking; not in a capture */
 int mixdq_qlinear_w8a8_ln(const int8_t* A, const int8_t* W, const float* bias0, const float* scale,
                           const void* bias_f16_or_null, void* D_f16, int64_t M, int N, int K,
                           const void* residual_f16_or_null, int64_t residual_row_div,

@@ -420,12 +420,15 @@ def qlinear_f16in_wanted(x: torch.Tensor, N: int, K: int, *, w4: bool = False, b
 
 
 def qlinear_f16in(input_f16, scale_inv, zero_point, weight_int8, scale, bias0, bias=None, *,
-                  _out=None, _bos=False, _cfg=0, _residual=None, _residual_div=1, _w4=False):
+                  _out=None, _bos=False, _cfg=0, _residual=None, _residual_div=1, _w4=False, _trace=None):
     """quantize_per_tensor_to_int8(input, scale_inv, zero_point) -> qlinear_w8_a8_ohalf(...) in ONE launch
     (bit-identical to the pair).  `input_f16`: fp16 [..., K] readable in place as rows a constant stride
     apart; `_bos`: input is [B, T, K] and tokens 1.. are the operand, written to rows 1.. of `_out`
-    [B, T, N] (QuantizedLinear's BOS path).  Raises where qlinear_f16in_supported() is False."""
-    _trace_w(weight_int8)
+    [B, T, N] (QuantizedLinear's BOS path).  Raises where qlinear_f16in_supported() is False.
+    `_trace`: the PERSISTENT tensor the weight operand is a view of (a 1x1 conv hands over a fresh
+    permute / reshape view of its buffer on every call: the prefetch planner keeps weak references, and a
+    reference to a temporary is dead on the next forward -- ADVICE r5)."""
+    _trace_w(weight_int8 if _trace is None else _trace)
     _check(input_f16.is_cuda and input_f16.dtype == torch.float16, "input should be fp16 on GPU")
     dev = input_f16.device
     for t, nm in ((scale_inv, "scale_inv"), (zero_point, "zero_point"), (weight_int8, "weight_int8"),
@@ -1051,10 +1054,26 @@ def qlinear_ln_supported(M: int, N: int, K: int) -> bool:
 
 
 def qlinear_ln_workspace(M: int, N: int, device) -> torch.Tensor:
-    """A zeroed exchange buffer for qlinear_ln launches of up to M rows x N columns (partials + counters; a
-    launch leaves the counters at zero).  Owned by the caller: one launch at a time per buffer."""
+    """A zeroed exchange buffer for qlinear_ln launches of up to M rows x N columns: its first page holds the
+    launch counter (the epoch: it only grows -- every launch tags its records with epoch + 1), the departure
+    counter (zero between launches) and a sticky error word (qlinear_ln_status); the records follow.  Owned by
+    the caller: one launch at a time per buffer AND per device (the tiles of a launch wait for each other)."""
     return torch.zeros(int(_lib.mixdq_qlinear_ln_workspace_bytes(int(M), int(N))), dtype=torch.uint8,
                        device=device)
+
+
+_lib.mixdq_qlinear_ln_status.restype = _i32
+_lib.mixdq_qlinear_ln_status.argtypes = [_vp, _vp, _vp]
+
+
+def qlinear_ln_status(workspace) -> int:
+    """The workspace's sticky error word: 0 while every launch on it found all its records, else the tag of the
+    last launch in which a workgroup gave up waiting (its rows were written as NaN).  Synchronises the stream."""
+    w = ctypes.c_int(0)
+    with torch.cuda.device(workspace.device):
+        code = _lib.mixdq_qlinear_ln_status(workspace.data_ptr(), ctypes.byref(w), _stream())
+    _status(code, "qlinear_ln_status")
+    return int(w.value)
 
 
 def qlinear_ln(input_int8, weight_int8, scale, bias0, bias, residual, ln_weight, ln_bias, eps, qparams,

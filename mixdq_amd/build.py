@@ -40,6 +40,55 @@ def _hipcc():
     return "hipcc"
 
 
+def csrc_sha16() -> str:
+    """sha256 (first 16 hex digits) over the kernel sources: embedded in the library at build time
+    (mixdq_build_csrc_sha16) so that a run can say which sources the LOADED library was built from --
+    hashing the tree on disk says nothing about a stale .so or one named by MIXDQ_HIP_LIB."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(CSRC)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(CSRC, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def _build_info_obj(force: bool) -> str:
+    """A host-only object that carries the hash of the sources being compiled (rebuilt whenever it changes)."""
+    src = os.path.join(OBJ, "build_info.cpp")
+    obj = os.path.join(OBJ, "build_info.o")
+    text = ('extern "C" __attribute__((visibility("default"))) const char* mixdq_build_csrc_sha16() '
+            '{ return "%s"; }\n' % csrc_sha16())
+    if force or not os.path.exists(src) or open(src).read() != text or not os.path.exists(obj):
+        with open(src, "w") as f:
+            f.write(text)
+        subprocess.check_call(["g++", "-O1", "-fPIC", "-c", "-o", obj, src])
+    return obj
+
+
+def _aq_asm_cmd(asm: str):
+    """The device assembly of igemm_aq.hip under EXACTLY the flags of its object (same compiler, same options,
+    -S instead of -c: the same code generation; `-save-temps`, which would hand over the object's own .s, is not an
+    option -- it switches hipcc to its non-integrated pipeline, which generates OTHER code: 48 bytes of scratch in
+    kernels that have none)."""
+    src = os.path.join(CSRC, "igemm_aq.hip")
+    return [_hipcc()] + FLAGS + EXTRA.get("igemm_aq.hip", []) + ["--cuda-device-only", "-S", "-o", asm, src]
+
+
+def _check_aq_isa(asm: str, obj: str) -> None:
+    """tools/check_aq_isa.py on that assembly: the quantize-in-prologue kernels park in-flight loads in registers
+    the compiler believes written, which is only sound if nothing touches them before their tied wait -- a
+    toolchain or flag change that breaks that must fail the BUILD, not ship."""
+    tool = os.path.join(os.path.dirname(PKG), "tools", "check_aq_isa.py")
+    if not os.path.exists(tool):          # (a source tree without tools/: nothing to run)
+        return
+    r = subprocess.run([sys.executable, tool, asm], capture_output=True, text=True)
+    if r.returncode != 0:
+        if os.path.exists(obj):
+            os.remove(obj)
+        raise RuntimeError("igemm_aq.hip: the AQ kernels touch a register whose load is in flight\n" + r.stdout[-4000:])
+
+
 def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
@@ -64,10 +113,17 @@ def build(force: bool = False, verbose: bool = False) -> str:
             cmd = [_hipcc()] + FLAGS + EXTRA.get(src, []) + ["-c", "-o", obj, path]
             if verbose:
                 print(" ".join(cmd))
-            procs.append((cmd, subprocess.Popen(cmd)))
-        for cmd, pr in procs:                      # the files compile in parallel
+            procs.append((cmd, subprocess.Popen(cmd), src, obj))
+            if src == "igemm_aq.hip":              # its assembly, beside it (see _aq_asm_cmd)
+                asm_cmd = _aq_asm_cmd(os.path.join(OBJ, "igemm_aq.s"))
+                procs.append((asm_cmd, subprocess.Popen(asm_cmd, stderr=subprocess.DEVNULL), "igemm_aq.s", obj))
+        for cmd, pr, src, obj in procs:            # the files compile in parallel
             if pr.wait() != 0:
                 raise subprocess.CalledProcessError(pr.returncode, cmd)
+        for cmd, pr, src, obj in procs:
+            if src == "igemm_aq.s":
+                _check_aq_isa(os.path.join(OBJ, "igemm_aq.s"), obj)
+        objs.append(_build_info_obj(force))
         cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd))

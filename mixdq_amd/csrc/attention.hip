@@ -62,6 +62,7 @@ struct AttnParams {
   void* out;                       // f16 rows or int8 rows
   long q_bs, q_rs, k_bs, k_rs, v_bs, v_rs, o_bs, o_rs;   // batch / row strides in elements
   int tq, tkv, heads, qblocks;
+  int xcd_map;                     // 1: workgroup -> (batch, head, query block) through attn_block_of()
   float scale_log2;                // softmax scale * log2(e)
   const float* s_inv; const float* zp;
   int unfused;
@@ -105,6 +106,18 @@ __device__ __forceinline__ void attn_prefetch_role(const AttnParams& p) {
     }
   }
   asm volatile("" ::"v"(acc));
+}
+
+// XCD-aware workgroup map (round 6).  Workgroups are dealt round-robin over the 8 XCDs (bid % 8), each with its own
+// 4 MiB L2, and all query blocks of one (batch, head) read the SAME K / V.  With block = bid the query blocks of a
+// head were spread over all 8 XCDs and every L2 fetched every head's K / V: 4.4x the algorithmic bytes on the
+// memory side at every shape (profiles/pmc_traffic.json, round 5: 8 x (K + V) + Q + O).  Here XCD x -- blocks
+// x, x + 8, ... -- gets a CONTIGUOUS run of the (batch, head, query block) sequence (bijective for any count, as
+// igemm's tile map), so a head's query blocks meet in one L2 (a head that straddles two runs: two).  Which XCD a
+// block lands on is an observation, not a promise: the map changes where a block runs, never what it computes.
+__device__ __forceinline__ int attn_block_of(int bid, int total) {
+  const int x = bid % kNumXCD, q8 = total / kNumXCD, r8 = total % kNumXCD;
+  return (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + bid / kNumXCD;
 }
 
 __device__ __forceinline__ float half_sum(float x) {
@@ -281,7 +294,7 @@ template <int WAVES, int STAGES, bool QUANT, bool RAGGED>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void attn_fwd_kernel(const AttnParams p) {
   MIXDQ_ARGS_NOW(p.q, p.k, p.v, p.out, p.q_bs, p.q_rs, p.k_bs, p.k_rs, p.v_bs, p.v_rs, p.o_bs, p.o_rs,
                  p.tq, p.tkv, p.heads, p.qblocks);
-  MIXDQ_ARGS_NOW(p.scale_log2, p.s_inv, p.zp, p.unfused);
+  MIXDQ_ARGS_NOW(p.scale_log2, p.s_inv, p.zp, p.unfused, p.xcd_map, p.attn_blocks);
   if ((int)blockIdx.x >= p.attn_blocks) {        // payload workgroups (dispatched after the attention ones)
     attn_prefetch_role(p);
     return;
@@ -303,9 +316,10 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keep it scalar
   const int l32 = lane & 31, hh = lane >> 5;
-  const int qb = blockIdx.x % p.qblocks;
-  const int head = (blockIdx.x / p.qblocks) % p.heads;
-  const int b = blockIdx.x / (p.qblocks * p.heads);
+  const int blk = p.xcd_map ? attn_block_of(blockIdx.x, p.attn_blocks) : (int)blockIdx.x;
+  const int qb = blk % p.qblocks;
+  const int head = (blk / p.qblocks) % p.heads;
+  const int b = blk / (p.qblocks * p.heads);
   const int q0 = qb * (WAVES * 32) + wave * 32;
 
   // Q^T fragments: lane's query row, d = 16 ks + 8 h .. + 7
@@ -502,7 +516,7 @@ template <bool QUANT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void attn_short_kernel(const AttnParams p) {
   MIXDQ_ARGS_NOW(p.q, p.k, p.v, p.out, p.q_bs, p.q_rs, p.k_bs, p.k_rs, p.v_bs, p.v_rs, p.o_bs, p.o_rs,
                  p.tq, p.tkv, p.heads, p.qblocks);
-  MIXDQ_ARGS_NOW(p.scale_log2, p.s_inv, p.zp, p.unfused);
+  MIXDQ_ARGS_NOW(p.scale_log2, p.s_inv, p.zp, p.unfused, p.xcd_map, p.attn_blocks);
   float s_inv = 0.f, zp = 0.f;                   // (scalar loads at entry: see attn_fwd_kernel)
   if constexpr (QUANT) {
     s_inv = *(const __attribute__((address_space(4))) float*)p.s_inv;
@@ -513,9 +527,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l32 = lane & 31, hh = lane >> 5;
-  const int qb = blockIdx.x % p.qblocks;
-  const int head = (blockIdx.x / p.qblocks) % p.heads;
-  const int b = blockIdx.x / (p.qblocks * p.heads);
+  const int blk = p.xcd_map ? attn_block_of(blockIdx.x, p.attn_blocks) : (int)blockIdx.x;
+  const int qb = blk % p.qblocks;
+  const int head = (blk / p.qblocks) % p.heads;
+  const int b = blk / (p.qblocks * p.heads);
   const int q0 = qb * (WAVES * 32) + wave * 32;
   const int ntiles = (p.tkv + kKeys - 1) / kKeys;      // 1 or 2
 
@@ -672,8 +687,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   }
 }
 
-int launch_attn_short(const AttnParams& p, int batch, bool quant, hipStream_t stream) {
+int launch_attn_short(AttnParams& p, int batch, bool quant, hipStream_t stream) {
+  if ((long)p.qblocks * p.heads * batch > 0x7fffffffl) return MIXDQ_ERR_INVALID_ARG;
   const int grid = p.qblocks * p.heads * batch;
+  p.attn_blocks = grid;
   const int smem = 2 * kStageBytes;                  // two K | V tiles; the output staging overlays them
   if (quant) hipLaunchKernelGGL((attn_short_kernel<true>), dim3(grid), dim3(256), smem, stream, p);
   else hipLaunchKernelGGL((attn_short_kernel<false>), dim3(grid), dim3(256), smem, stream, p);
@@ -747,6 +764,8 @@ static int attention_f16_impl(const void* q, const void* k, const void* v, void*
   p.s_inv = out_scale_inv; p.zp = out_zero_point;
   p.unfused = (flags & MIXDQ_FLAG_UNFUSED) ? 1 : 0;
   p.attn_blocks = 0; p.pf_blocks = 0; p.n_pf = 0; p.pf_nt = 0; p.pf_delay = 0;
+  static const int xcd_on = [] { const char* e = getenv("MIXDQ_ATTN_XCD"); return !(e && e[0] == '0'); }();   // A/B runs
+  p.xcd_map = xcd_on;
   for (int i = 0; i < 16; ++i) { p.pf_ptr[i] = nullptr; p.pf_bytes[i] = 0; }
   for (int i = 0; i < n_pf; ++i) {
     if (!pf_ptrs[i] || pf_bytes[i] < 16) continue;

@@ -108,7 +108,8 @@ struct IgemmParams {
   int8_t* ln_q[3];
   __half* ln_h;          // optional FP16 copy of the normalised rows
   float* ln_part;        // [M][N / BN] 16-byte records: {sum, centred sum of squares, launch tag, 0} of each unit
-  int* ln_cnt;           // [0]: epoch (launches completed on this workspace), [1]: departures of the running one
+  int* ln_cnt;           // [0]: epoch (launches completed on this workspace), [1]: departures of the running one,
+                         // [2]: sticky error word (the tag of a launch in which a record never arrived; 0 = none)
   int ln_local;          // 1: row blocks are laid out XCD by XCD and the records are first looked for in that L2
 };
 
@@ -1968,6 +1969,13 @@ void igemm_kernel(MIXDQ_IGEMM_HEAD_PARAMS const IgemmParams p_in) {
         __builtin_amdgcn_s_sleep(1);
       }
       MIXDQ_STAMP_AT(11);
+      {   // a record that never arrived: besides poisoning the row (below), leave a STICKY error word in the workspace
+        bool lost = false;      // (ln_cnt[2]: never cleared by a launch; mixdq_qlinear_ln_status reads it)
+#pragma unroll
+        for (int r = 0; r < RPT; ++r) lost = lost || (live[r] && !ok[r]);
+        if (__builtin_amdgcn_ballot_w64(lost) != 0 && lane == 0)
+          __hip_atomic_store(p.ln_cnt + 2, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
 #pragma unroll
       for (int r = 0; r < RPT; ++r) {
         const int row = (tid >> 4) + r * (NTHREADS / 16);
@@ -2071,6 +2079,22 @@ int launch_kernel(IgemmParams& p, hipStream_t stream) {
     int units = 1;
     while (units < 16 && (p.N / 16) % (2 * units) == 0) units *= 2;
     if (grid > kNumCU || p.N % BN != 0 || p.N / BN != units) return MIXDQ_ERR_SHAPE;
+    // ... on THIS device: its real CU count (a partitioned CPX / DPX mode or a smaller part has fewer than 256)
+    // and at least one workgroup of this kernel per CU by the runtime's own occupancy answer -- a grid that is not
+    // wholly resident would wait for records of workgroups that cannot start until a waiter leaves.
+    static int cus[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MIXDQ_ERR_LAUNCH;
+    if (cus[dev] == 0) {
+      int n = 0, per_cu = 0;
+      if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return MIXDQ_ERR_LAUNCH;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(
+              &per_cu, igemm_kernel<BM, BN, BK, STAGES, WM, WN, CONV, FAST, W4, KSPLIT, MT, F16, false, PHASED, GROUPED, AQ, LNQ>,
+              64 * WM * WN * KSPLIT, SMEM) != hipSuccess)
+        return MIXDQ_ERR_LAUNCH;
+      cus[dev] = per_cu >= 1 ? n : -1;
+    }
+    if (cus[dev] < 0 || grid > cus[dev]) return MIXDQ_ERR_SHAPE;
   }
   igemm_kernel<BM, BN, BK, STAGES, WM, WN, CONV, FAST, W4, KSPLIT, MT, F16, false, PHASED, GROUPED, AQ, LNQ>
       <<<dim3((unsigned)grid, (unsigned)ny), 64 * WM * WN * KSPLIT, SMEM, stream>>>(MIXDQ_IGEMM_HEAD_ARGS(p) p);

@@ -28,7 +28,7 @@ int select_ln(int64_t M, int N, int K) {
   return -1;
 }
 
-constexpr size_t kLnCounterBytes = 4096;      // epoch, departures (two ints; a page of their own)
+constexpr size_t kLnCounterBytes = 4096;      // epoch, departures, sticky error word (three ints; a page of their own)
 
 }  // namespace
 }  // namespace mixdq
@@ -47,6 +47,20 @@ extern "C" size_t mixdq_qlinear_ln_workspace_bytes(int64_t M, int N) {
   // of another shape on the same buffer finds them where the last one left them); then one 16-byte record per
   // row and column tile (at most 16 tiles per row)
   return kLnCounterBytes + 2 * (size_t)M * 16 * 16;      // (two copies of the records: csrc/igemm_kernel.h)
+}
+
+// The sticky error word of a workspace: 0 while every launch on it found all its records; otherwise the
+// tag of the last launch in which a workgroup gave up waiting for one (its rows were written as NaN).  Reads the
+// word with a blocking copy on `stream`: for tests and for hosts that check after a synchronisation point, never
+// inside a stream capture.  MIXDQ_OK / MIXDQ_ERR_LAUNCH; *status receives the word.
+extern "C" int mixdq_qlinear_ln_status(const void* workspace, int* status, mixdq_stream_t stream) {
+  if (!workspace || !status) return MIXDQ_ERR_INVALID_ARG;
+  int w = 0;
+  if (hipMemcpyAsync(&w, (const int*)workspace + 2, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess ||
+      hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
+    return MIXDQ_ERR_LAUNCH;
+  *status = w;
+  return MIXDQ_OK;
 }
 
 extern "C" int mixdq_qlinear_w8a8_ln(const int8_t* A, const int8_t* W, const float* bias0,

@@ -306,7 +306,8 @@ class QuantizedConv2d(nn.Module):
             res = residual.permute(0, 2, 3, 1)
         out = _C.qlinear_f16in(rows, getattr(self, "act_scales_inv" + sfx),
                                getattr(self, "act_zero_points" + sfx), w2, getattr(self, "scale" + sfx),
-                               getattr(self, "bias0" + sfx), bias, _residual=res, _w4=self.w_packed4)
+                               getattr(self, "bias0" + sfx), bias, _residual=res, _w4=self.w_packed4,
+                               _trace=w)      # (the module's buffer, not the per-call view of it)
         return out.permute(0, 3, 1, 2)                    # [N, K, H, W], channels-last in memory
 
     def _quant_conv(self, x, sfx, bias, residual=None):

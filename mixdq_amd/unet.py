@@ -282,16 +282,26 @@ def _ln_plan(norm, consumers):
     return plan[1], plan[2]
 
 
+# the largest problem a GEMM + LayerNorm launch takes (csrc/igemm_ln.hip select_ln: one 64 x 80 or 128 x 80 tile
+# per CU): M <= 4096 at N = 640, M <= 2048 at N = 1280 -- the workspace is sized for it ONCE
+_LN_WS_ROWS = 4096
+
+
 def _ln_workspace(owner, M, N, device):
-    """The exchange buffer of the GEMM + LayerNorm launches of one network (zeroed once; every launch leaves
-    its counters at zero): kept on `owner` (the SDXLUNet, whose launches run one at a time on one stream),
-    per device, grown when a larger problem comes along."""
+    """The exchange buffer of the GEMM + LayerNorm launches of one network: kept on `owner` (the SDXLUNet, whose
+    launches run one at a time on one stream), per device, allocated ONCE for the largest problem the launch form
+    takes (2.1 MB) and never replaced -- a hipGraph captured through hip_graph_opt holds its raw pointer, so a
+    buffer that grew by reallocation would leave every earlier graph writing records and counters into memory the
+    allocator has handed to someone else.  The epoch in its first page only grows (launch tags); the
+    departure counter is zero between launches; the third word is the sticky error word (_C.qlinear_ln_status)."""
     from mixdq_amd import _C
     store = owner.__dict__.setdefault("_ln_ws", {})
-    need = int(_C._lib.mixdq_qlinear_ln_workspace_bytes(int(M), int(N)))
     ws = store.get(device)
-    if ws is None or ws.numel() < need:
-        ws = store[device] = _C.qlinear_ln_workspace(M, N, device)
+    if ws is None:
+        ws = store[device] = _C.qlinear_ln_workspace(max(int(M), _LN_WS_ROWS), max(int(N), 1280), device)
+    need = int(_C._lib.mixdq_qlinear_ln_workspace_bytes(int(M), int(N)))
+    if ws.numel() < need:      # (cannot happen for a shape the launch form takes; never silently reallocate)
+        raise RuntimeError(f"GEMM + LayerNorm workspace of {ws.numel()} bytes is too small for M={M}, N={N}")
     return ws
 
 

@@ -256,3 +256,36 @@ def test_modules_take_the_one_launch_path_and_keep_their_bits(C, monkeypatch):
         assert len(calls) == (4 if mode == "0" else 0), (mode, len(calls))
     for a, b in zip(outs["0"], outs["1"]):
         assert a.shape == b.shape and torch.equal(a.contiguous().view(torch.int16), b.contiguous().view(torch.int16))
+
+
+def test_f16in_conv_traces_its_persistent_buffer(C, monkeypatch):
+    """The 1x1 conv hands mixdq_qlinear_f16in_w8a8 a fresh permute / reshape VIEW of its weight buffer on every
+    call; the prefetch planner keeps weak references to what the entry points trace, and a reference to a
+    temporary is dead on the next forward (the plan was dropped, silently: ADVICE r5).  What is traced is the
+    module's buffer itself: alive, at the same address, on a second forward."""
+    import weakref
+    from mixdq_amd.nn import QuantizedConv2d
+    from tests.cases import make_float_module
+    from tests.test_host import prepared
+    monkeypatch.setattr(C, "F16IN", "1")
+    c = dict(key="ctr", kind="conv", name="up_blocks.0.resnets.2.conv_shortcut", cin=640, cout=1280, ksize=1,
+             stride=1, pad=0, bias=True, seed=381, split=0)
+    fm = make_float_module(c)
+    w = fm.weight.detach().float()
+    d = (w.reshape(1280, -1).abs().amax(dim=1) / 127).half()
+    ck = {c["name"] + ".weight_quantizer": {"delta_list": d[None].repeat(3, 1), "zero_point_list": torch.zeros(3, 1280).half()},
+          c["name"] + ".act_quantizer": {"delta_list": torch.tensor([0.05] * 3).half(),
+                                         "zero_point_list": torch.tensor([120.0] * 3).half()}}
+    qm = QuantizedConv2d.from_float(prepared(c, {}), split=0, ckpt=ck).to(DEV)
+    x = torch.from_numpy(dd.f16(382, (1, 640, 32, 32), -3, 3)).to(DEV).contiguous(memory_format=torch.channels_last)
+    refs = []
+    for _ in range(2):
+        ctx = C.PrefetchContext(DEV)
+        with ctx, torch.no_grad():
+            qm(x)
+        assert len(ctx.trace) == 1 and ctx.trace[0] is qm.weight_int
+        refs.append((weakref.ref(ctx.trace[0]), ctx.trace[0].data_ptr()))
+        del ctx
+    import gc
+    gc.collect()
+    assert all(r() is not None and r().data_ptr() == p for r, p in refs) and refs[0][1] == refs[1][1]

@@ -561,3 +561,10 @@ def test_qlinear_ln_range_and_graph_capture(C):
         torch.cuda.synchronize()
         assert torch.equal(got[0].view(torch.int16), ref[0].view(torch.int16))
         assert torch.equal(got[1][0], ref[1][0])
+    # every launch above found all its records: the workspace's sticky error word is clean (a workgroup that
+    # gives up waiting writes NaN rows AND leaves its launch tag there -- ADVICE r5); the epoch has grown
+    assert C.qlinear_ln_status(ws) == 0
+    assert int(ws[:4].view(torch.int32).item()) >= 4
+    ws[8:12].view(torch.int32).fill_(77)                        # (the word is the host's to read, not a launch's to clear)
+    C.qlinear_ln(a, w, sc, b0, None, r, g, b, 1e-5, qp, ws)
+    assert C.qlinear_ln_status(ws) == 77

@@ -33,8 +33,8 @@ def build_asm(out):
     sys.path.insert(0, ROOT)
     from mixdq_amd import build as B
     src = os.path.join(B.CSRC, "igemm_aq.hip")
-    cmd = [B._hipcc()] + B.FLAGS + B.EXTRA.get("igemm_aq.hip", []) + [
-        "--cuda-device-only", "-S", "-o", out, src]
+    extra = [f for f in B.EXTRA.get("igemm_aq.hip", []) if not f.startswith("-save-temps")]
+    cmd = [B._hipcc()] + B.FLAGS + extra + ["--cuda-device-only", "-S", "-o", out, src]
     subprocess.check_call(cmd, stderr=subprocess.DEVNULL)
     return out
 
