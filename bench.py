@@ -327,6 +327,30 @@ def csrc_sha16():
     return v.decode() if v else None
 
 
+def rocprof_kernel_avg(kname, B):
+    """The rocprofv3 --kernel-trace --stats average of the dominant kernel, from the COMMITTED summary of the same
+    command (profiles/r06_bench_kernel_stats_bs{B}.csv; a trace cannot run inside the timed command), beside the
+    live HIP-event clock: {rocprof_avg_launch_us, rocprof_calls, frac_rocprof, rocprof_source}, or None."""
+    import csv
+    path = os.path.join(ROOT, "profiles", f"r06_bench_kernel_stats_bs{B}.csv")
+    if not os.path.exists(path):
+        return None
+    pat = kernel_name_pattern(kname)
+    best = None
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            name = row.get("Name") or row.get("KernelName") or ""
+            if pat in name:
+                calls = int(float(row.get("Calls", 0) or 0))
+                tot = float(row.get("TotalDurationNs", 0) or 0)
+                if calls and (best is None or tot > best[1]):
+                    best = (calls, tot)
+    if not best:
+        return None
+    return {"rocprof_avg_launch_us": best[1] / best[0] / 1e3, "rocprof_calls": best[0],
+            "rocprof_source": os.path.relpath(path, ROOT) + " (committed summary of the same command; not measured by this run)"}
+
+
 def kernel_name_pattern(kname):
     """bench.py kernel name -> substring of the (demangled) device kernel name torch.profiler reports."""
     import re
@@ -761,10 +785,32 @@ def main():
         kd = max(5, args.steps // 2)
         dtd = time_steps(run_once, kd, 2, device)
         unet.forward = eager_forward
+        dropin = {"dropin_unfused_ms_per_step": 1e3 * dtd / kd, "dropin_unfused_kernels_per_step": n_unfused}
+        # ... and with quantize_unet(..., swap_glue=True) (mixdq_amd/nn/glue.py): the stock nn.GroupNorm (+ SiLU),
+        #     nn.LayerNorm and GEGLU modules swapped by type for this repo's FP16-output kernels, one launch per
+        #     module, same graph -- first with the attention core left to PyTorch's SDPA, then with it on
+        #     mixdq_attention_f16 as well (what swap_glue=True does by default)
+        from mixdq_amd.nn.glue import swap_glue_modules, unswap_glue_modules
+        for att, key in ((False, "dropin_glue_torch_sdpa"), (True, "dropin_glue")):
+            swapped = swap_glue_modules(unet, attention=att)
+            with torch.no_grad():
+                eager_forward(**inputs)
+            torch.cuda.synchronize(device)
+            n_k = count_kernels(lambda: eager_forward(**inputs), device)
+            hip_graph_opt(unet)
+            dtg = time_steps(run_once, kd, 2, device)
+            unet.forward = eager_forward
+            dropin[key + "_ms_per_step"] = 1e3 * dtg / kd
+            dropin[key + "_kernels_per_step"] = n_k
+            if att:
+                dropin["dropin_glue_swapped_modules"] = {k: v for k, v in swapped.items()} if any(swapped.values()) else None
+        dropin["dropin_glue_attention"] = ("dropin_unfused / dropin_glue_torch_sdpa: torch F.scaled_dot_product_attention "
+                                           "(its AOTriton kernel is also called attn_fwd); dropin_glue and the headline: "
+                                           "this repo's mixdq_attention_f16 (csrc/attention.hip)")
+        unswap_glue_modules(unet)
         unet.set_fused(True)
         n_fused = count_kernels(lambda: eager_forward(**inputs), device)
-        dropin = {"dropin_unfused_ms_per_step": 1e3 * dtd / kd, "dropin_unfused_kernels_per_step": n_unfused,
-                  "kernels_per_step": n_fused}
+        dropin["kernels_per_step"] = n_fused
     # ---- the same fused graph with every eligible LayerNorm riding in its producer GEMM's launch (DESIGN.md 3.13:
     #      off by default because it is time-neutral): its step time and kernel count beside the headline's
     ln_in_gemm = None
@@ -862,12 +908,34 @@ def main():
                 r["frac_in_step"] = ops_all / (us_all * 1e-6) / 1e12 / INT8_MFMA_PEAK_TOPS
             r["in_step_kernel_time_ms"] = sum(t for _, t in in_step.values()) / 1e3
             r["in_step_kernels"] = sum(n for n, _ in in_step.values())
+    if roof_stats:
+        # whole step against the dense INT8 peak: every INT8 GEMM / conv op of one forward / the step time (the FP16
+        # attention core's FLOPs are not INT8 work and are not counted)
+        ops_step = out["roofline"]["all_igemm"]["int8_ops_per_step"]
+        out["roofline"]["whole_step_int8_ops"] = ops_step
+        out["roofline"]["whole_step_frac"] = ops_step / (ms * 1e-3) / 1e12 / INT8_MFMA_PEAK_TOPS
+        rp = rocprof_kernel_avg(out["roofline"]["kernel"], B)
+        if rp:
+            out["roofline"].update(rp)
+            out["roofline"]["frac_rocprof"] = (out["roofline"]["ops_per_launch"] / (rp["rocprof_avg_launch_us"] * 1e-6)
+                                               / 1e12 / INT8_MFMA_PEAK_TOPS)
     if batch8:
+        if "roofline" in batch8:
+            ops8 = batch8["roofline"]["all_igemm"]["int8_ops_per_step"]
+            batch8["whole_step_int8_ops"] = ops8
+            batch8["whole_step_frac"] = ops8 / (batch8["ms_per_step"] * 1e-3) / 1e12 / INT8_MFMA_PEAK_TOPS
+            rp8 = rocprof_kernel_avg(batch8["roofline"]["kernel"], 8)
+            if rp8:
+                batch8["roofline"].update(rp8)
+                batch8["roofline"]["frac_rocprof"] = (batch8["roofline"]["achieved"] * batch8["roofline"]["avg_launch_us"]
+                                                      / rp8["rocprof_avg_launch_us"] / INT8_MFMA_PEAK_TOPS)
         out["batch8"] = batch8
     if dropin:
         out.update(dropin)
         if fp16:
             out["speedup_vs_fp16_dropin"] = fp16["ms_per_step"] / dropin["dropin_unfused_ms_per_step"]
+            out["speedup_vs_fp16_dropin_glue"] = fp16["ms_per_step"] / dropin["dropin_glue_ms_per_step"]
+            out["speedup_vs_fp16_dropin_glue_torch_sdpa"] = fp16["ms_per_step"] / dropin["dropin_glue_torch_sdpa_ms_per_step"]
     if ln_in_gemm:
         out["ln_in_gemm"] = ln_in_gemm
     if world == 1:

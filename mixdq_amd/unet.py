@@ -220,7 +220,8 @@ def _gn_feed(norm: nn.GroupNorm, x, consumer, silu: bool, x2=None, raw_for=None)
         return res + (out[2] if raw_qp is not None else None,)
     if x2 is not None:
         x = torch.cat([x, x2], dim=1)
-    h = norm(x)
+    # (the stock op by FUNCTION: a module swapped by swap_glue may fold the SiLU into its own launch)
+    h = F.group_norm(x, norm.num_groups, norm.weight, norm.bias, norm.eps)
     res = ((F.silu(h) if silu else h), False)
     return res if raw_for is None else res + (None,)
 
@@ -251,7 +252,7 @@ def _ln_feed(norm: nn.LayerNorm, x, consumers):
     from mixdq_amd import _C
     C = x.shape[-1]
     if not (_fusable_f16(x) and x.is_contiguous() and C % 16 == 0 and C <= 2048):
-        h = norm(x)
+        h = F.layer_norm(x, norm.normalized_shape, norm.weight, norm.bias, norm.eps)
         return [(h, False)] * len(consumers)
     groups, slot = _ln_plan(norm, consumers)
     want_f16 = any(s < 0 for s in slot)
@@ -407,6 +408,7 @@ class ResnetBlock2D(nn.Module):
         self.norm2 = nn.GroupNorm(groups, cout, eps=1e-5)
         self.conv2 = nn.Conv2d(cout, cout, 3, 1, 1)
         self.conv_shortcut = nn.Conv2d(cin, cout, 1, 1, 0) if cin != cout else None
+        self.nonlinearity = nn.SiLU()      # a MODULE, as in diffusers' ResnetBlock2D (swappable by type: nn/glue.py)
         if self.conv_shortcut is not None and split:
             # up-block: input = cat(hidden[:split], skip); the quantized shortcut uses separate
             # activation scales for the two halves (quant_block_forward_func.py:153-157)
@@ -423,9 +425,9 @@ class ResnetBlock2D(nn.Module):
             return self.forward_fused(x, temb, skip)
         if skip is not None:
             x = torch.cat([x, skip], dim=1)
-        h = self.conv1(F.silu(self.norm1(x)))
-        h = h + self.time_emb_proj(F.silu(temb))[:, :, None, None]
-        h = self.conv2(F.silu(self.norm2(h)))
+        h = self.conv1(self.nonlinearity(self.norm1(x)))
+        h = h + self.time_emb_proj(self.nonlinearity(temb))[:, :, None, None]
+        h = self.conv2(self.nonlinearity(self.norm2(h)))
         if self.conv_shortcut is not None:
             x = self.conv_shortcut(x)
         return x + h
@@ -993,6 +995,7 @@ class SDXLUNet(nn.Module):
                                           not last))
             prev = cout
         self.conv_norm_out = nn.GroupNorm(cfg["norm_num_groups"], boc[0], eps=1e-5)
+        self.conv_act = nn.SiLU()          # (diffusers' name)
         self.conv_out = nn.Conv2d(boc[0], cfg["out_channels"], 3, 1, 1)
         self.register_load_state_dict_post_hook(_refresh_after_load)
 
@@ -1305,7 +1308,7 @@ class SDXLUNet(nn.Module):
             feed, q = _gn_feed(self.conv_norm_out, x, self.conv_out, silu=True)
             x = self.conv_out.forward_quantized(feed) if q else self.conv_out(feed)
         else:
-            x = self.conv_out(F.silu(self.conv_norm_out(x)))
+            x = self.conv_out(self.conv_act(self.conv_norm_out(x)))
         return (x,)
 
 

@@ -675,3 +675,45 @@ def test_f16in_rows_view_accepts_exactly_the_operands_the_kernel_can_read_in_pla
     assert _rows_view(rows, 64) == (72, 96, [2, 6, 6])
     assert _rows_view(torch.zeros(0, 64, dtype=torch.float16), 64) is None
     assert _rows_view(torch.zeros(1, 64, dtype=torch.float16), 64) == (1, 64, [1])
+
+
+def test_swap_glue_modules_by_type_keeps_names_and_state_and_undoes():
+    """quantize_unet(..., swap_glue=True) / mixdq_amd.nn.glue (host logic; the kernels are checked on the GPU,
+    tests/test_glue_gpu.py): module CLASSES change to subclasses of the stock ones, names / state_dict keys /
+    isinstance do not; the SiLU behind a ResnetBlock2D's GroupNorms and behind conv_norm_out is folded, the one in
+    front of time_emb_proj keeps acting; idempotent; undone by unswap_glue_modules; on tensors the kernels do not take
+    (here: the CPU, FP32) every swapped module IS its stock op."""
+    import bench
+    import torch.nn as nn
+    from mixdq_amd.nn.glue import (HipGroupNorm, HipLayerNorm, HipSiLU, swap_glue_modules, unswap_glue_modules)
+    from mixdq_amd.quantize_sdxl import example_inputs
+    from mixdq_amd.unet import GEGLU, Attention, SDXLUNet, init_synthetic_weights
+    unet = init_synthetic_weights(SDXLUNet(bench.TINY_CFG)).eval()
+    inputs = example_inputs(1, 8, "cpu", seed=3)
+    inputs = {k: (v.float() if torch.is_tensor(v) else {a: b.float() for a, b in v.items()}) for k, v in inputs.items()}
+    with torch.no_grad():
+        want = unet(**inputs)[0]
+    keys, names = list(unet.state_dict()), [n for n, _ in unet.named_modules()]
+    n = swap_glue_modules(unet)
+    n_res = sum(1 for m in unet.modules() if type(m).__name__ == "ResnetBlock2D")
+    assert n["groupnorm"] == sum(isinstance(m, nn.GroupNorm) for m in unet.modules())
+    assert n["silu_folded"] == 2 * n_res + 1 and n["layernorm"] > 0 and n["geglu"] > 0 and n["attention"] > 0
+    assert list(unet.state_dict()) == keys and [m for m, _ in unet.named_modules()] == names
+    res = next(m for m in unet.modules() if type(m).__name__ == "ResnetBlock2D")
+    assert type(res.norm1) is HipGroupNorm and res.norm1.fuse_silu and type(res.nonlinearity) is HipSiLU
+    assert type(unet.conv_norm_out) is HipGroupNorm and unet.conv_norm_out.fuse_silu and type(unet.conv_act) is HipSiLU
+    tnorm = next(m for nme, m in unet.named_modules() if nme.endswith("attentions.0.norm"))
+    assert type(tnorm) is HipGroupNorm and not tnorm.fuse_silu
+    assert all(isinstance(m, (nn.LayerNorm, HipLayerNorm)) for m in unet.modules() if "LayerNorm" in type(m).__name__)
+    assert all(isinstance(m, GEGLU) for m in unet.modules() if "GEGLU" in type(m).__name__)
+    assert all(isinstance(m, Attention) for m in unet.modules() if "Attention" in type(m).__name__)
+    assert swap_glue_modules(unet) == dict(groupnorm=0, silu_folded=0, layernorm=0, geglu=0, attention=0)
+    with torch.no_grad():
+        assert torch.equal(unet(**inputs)[0], want)          # CPU / FP32: every swapped module runs its stock op
+    unswap_glue_modules(unet)
+    assert {type(m) for m in unet.modules() if isinstance(m, (nn.GroupNorm, nn.LayerNorm, nn.SiLU))} == \
+        {nn.GroupNorm, nn.LayerNorm, nn.SiLU}
+    assert not any("Hip" in type(m).__name__ for m in unet.modules())
+    n2 = swap_glue_modules(unet, attention=False)
+    assert n2["attention"] == 0 and n2["groupnorm"] == n["groupnorm"]
+    assert not any(type(m).__name__ == "HipAttention" for m in unet.modules())
