@@ -356,6 +356,8 @@ def kernel_name_pattern(kname):
     import re
     import mixdq_amd._C as C
     m = re.match(r"igemm_kernel<(\d+),(\d+),(\d+),(\d+),(\w+?)(,w4)?>#cfg(\d+)", kname)
+    if m and int(m.group(7)) == 71:      # the persistent four-phase kernel (csrc/igemm_pp.h)
+        return "igemm_pp_kernel<true>" if "geglu" in m.group(5) else "igemm_pp_kernel<false>"
     if m:
         wm, wn, ks, mt = C.IGEMM_WAVES[int(m.group(7))]
         return "igemm_kernel<%s, %s, %s, %s, %d, %d, " % (m.group(1), m.group(2), m.group(3), m.group(4), wm, wn)
@@ -791,8 +793,10 @@ def main():
         #     module, same graph -- first with the attention core left to PyTorch's SDPA, then with it on
         #     mixdq_attention_f16 as well (what swap_glue=True does by default)
         from mixdq_amd.nn.glue import swap_glue_modules, unswap_glue_modules
+        swapped = {}
         for att, key in ((False, "dropin_glue_torch_sdpa"), (True, "dropin_glue")):
-            swapped = swap_glue_modules(unet, attention=att)
+            for k_, v_ in swap_glue_modules(unet, attention=att).items():
+                swapped[k_] = swapped.get(k_, 0) + v_
             with torch.no_grad():
                 eager_forward(**inputs)
             torch.cuda.synchronize(device)
@@ -802,8 +806,7 @@ def main():
             unet.forward = eager_forward
             dropin[key + "_ms_per_step"] = 1e3 * dtg / kd
             dropin[key + "_kernels_per_step"] = n_k
-            if att:
-                dropin["dropin_glue_swapped_modules"] = {k: v for k, v in swapped.items()} if any(swapped.values()) else None
+        dropin["dropin_glue_swapped_modules"] = swapped
         dropin["dropin_glue_attention"] = ("dropin_unfused / dropin_glue_torch_sdpa: torch F.scaled_dot_product_attention "
                                            "(its AOTriton kernel is also called attn_fwd); dropin_glue and the headline: "
                                            "this repo's mixdq_attention_f16 (csrc/attention.hip)")

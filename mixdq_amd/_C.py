@@ -108,7 +108,10 @@ IGEMM_CONFIGS = {1: (64, 64, 64, 2), 3: (128, 128, 64, 2), 4: (64, 64, 128, 3),
                  42: (64, 80, 128, 3), 43: (64, 240, 128, 3), 44: (128, 80, 128, 3),
                  45: (64, 80, 128, 4), 46: (128, 320, 64, 4), 56: (64, 80, 128, 6),
                  # 256x256x128 on the four-phase loop (2 x 4 waves of 128x64, 16x16x64 MFMAs)
-                 70: (256, 256, 128, 2)}
+                 70: (256, 256, 128, 2),
+                 # ... and its persistent form: one workgroup per CU walking its tiles (csrc/igemm_pp.h); what the
+                 # automatic choice takes instead of 70 where a CU has more than one tile
+                 71: (256, 256, 128, 2)}
 
 # id -> (WM, WN, KSPLIT, MT): wave grid, k-split groups and MFMA shape of each configuration (the template
 # arguments that tell two configurations of one tile shape apart in a kernel trace)
@@ -116,7 +119,7 @@ IGEMM_WAVES = {1: (2, 2, 1, 32), 3: (2, 2, 1, 32), 4: (2, 2, 1, 32), 13: (4, 2, 
                15: (2, 4, 1, 32), 18: (4, 2, 1, 32), 20: (4, 2, 1, 32), 25: (4, 2, 1, 32), 27: (8, 2, 1, 16),
                28: (4, 4, 1, 16), 35: (4, 2, 1, 32), 37: (2, 2, 2, 32), 41: (2, 4, 1, 32), 42: (4, 1, 2, 16),
                43: (4, 1, 2, 16), 44: (4, 1, 2, 16), 45: (4, 1, 2, 16), 46: (4, 2, 1, 32), 47: (4, 2, 1, 32),
-               56: (4, 1, 2, 16), 70: (2, 4, 1, 16)}
+               56: (4, 1, 2, 16), 70: (2, 4, 1, 16), 71: (2, 4, 1, 16)}
 
 FLAG_W4 = 2   # MIXDQ_FLAG_W4: the weight tensor holds packed signed 4-bit values
 FLAG_UPSAMPLE2X = 4   # MIXDQ_FLAG_UPSAMPLE2X: the conv input is read through a nearest 2x upsampling

@@ -12,7 +12,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libmixdq_hip.so")
 SOURCES = ["quantize.hip", "igemm.hip", "igemm_aq.hip", "igemm_ln.hip", "iconv.hip", "fused_norm.hip", "attention.hip"]
-HEADERS = ["common.h", "attn_core.h", "iconv.h", "igemm_kernel.h", os.path.join("..", "..", "include", "mixdq_hip.h"),
+HEADERS = ["common.h", "attn_core.h", "iconv.h", "igemm_kernel.h", "igemm_pp.h", "f16in_table.h", os.path.join("..", "..", "include", "mixdq_hip.h"),
            os.path.join("..", "..", "include", "mixdq_math.h")]
 # -ffp-contract=off: every fused multiply-add in the arithmetic specification is written
 # explicitly (__builtin_fmaf); the compiler must not introduce others.

@@ -22,6 +22,7 @@
 //     materialising an [N,P,Q,K] f32 tensor per call as the reference does.
 //   * blockIdx -> tile map is XCD-aware (blocks that share a weight panel share an L2).
 #include "igemm_kernel.h"
+#include "igemm_pp.h"
 
 namespace mixdq {
 namespace {
@@ -172,7 +173,10 @@ __global__ __launch_bounds__(256) void gemm_f16_kernel(const __half* __restrict_
   X(46, 128, 320, 64, 4, 4, 2, 1, 32, false)     \
   X(47, 128, 320, 64, 5, 4, 2, 1, 32, false)     \
   X(56, 64, 80, 128, 6, 4, 1, 2, 16, false)  \
-  X(70, 256, 256, 128, 2, 2, 4, 1, 16, true)
+  X(70, 256, 256, 128, 2, 2, 4, 1, 16, true)    \
+  X(71, 256, 256, 128, 2, 2, 4, 1, 16, true)
+// (71: the persistent form of 70, csrc/igemm_pp.h -- one workgroup per CU walking its tiles; dispatch() runs it where
+//  the launch is in its range, and 70's kernel otherwise)
 
 struct TileCfg { int id, bm, bn, bk, stages, wm, wn, ksplit, mt; };
 constexpr TileCfg kTileCfgs[] = {
@@ -248,7 +252,7 @@ inline int select_cfg(int64_t M, int N, int Ktot, bool whole64 = false, bool pha
   // prologue and epilogue: three co-resident workgroups of 128x128 pipeline them; (32768, 640, 640):
   // 23.9 us against 28.8 on 256x256, 26.6 on 256x128, 26.3 on 128x320)
   if (!whole64 && Ktot <= 640 && N <= 640 && blocks(128, 128) >= 4 * kNumCU) return 35;
-  if (phased_ok && Ktot >= 640 && 2 * blocks(256, 256) >= 3 * kNumCU) return 70;
+  if (phased_ok && Ktot >= 640 && 2 * blocks(256, 256) >= 3 * kNumCU) return pp_auto(M, N) ? 71 : 70;
   if (blocks(256, 128) >= 2 * kNumCU)
     return (Ktot >= 4096 && blocks(256, 256) >= kNumCU) ? 20 : 13;
   // exact-fit 16x16x64-MFMA tiles (tools/bench_gemm.py, batch 1): 128x80 when that is exactly one
@@ -330,6 +334,12 @@ int dispatch(IgemmParams& p, hipStream_t stream, int forced_cfg) {
   const int cfg = forced_cfg > 0 ? forced_cfg
                                  : (W4 ? select_cfg_w4(p.M, p.N, p.Ktot, whole64)
                                        : select_cfg(p.M, p.N, p.Ktot, whole64, phased_ok));
+  // the four-phase 256 x 256 tile as ONE workgroup per CU walking its tiles (csrc/igemm_pp.h: the next tile's first
+  // K-tile lands under the current tile's epilogue; same arithmetic, same bits) wherever a CU has more than one tile
+  if constexpr (!CONV && !W4) {
+    if (cfg == 71 && phased_ok && pp_ok(p))
+      return whole64 ? launch_pp<true>(p, stream) : launch_pp<false>(p, stream);
+  }
   switch (cfg) {
 #define X(ID, BM, BN, BK, ST, WM, WN, KS, MT, PH) \
   case ID: return launch_tile<BM, BN, BK, ST, WM, WN, CONV, W4, KS, MT, false, PH>(p, stream);
@@ -408,7 +418,7 @@ inline int select_cfg_f16(int64_t M, int N, int k_bytes) {
     case 37: return 4;              // k-split 64x64 -> the plain 64x64 tile
     case 45: case 56: case 42: return 41;   // exact-fit 64x80 (16x16 MFMA, k-split) -> 64x128
     case 27: case 28: return 25;    // 16 waves of 16x16x64 MFMAs -> the same tile on 8 waves of 32x32
-    case 70: case 14: case 18: return 20;
+    case 70: case 71: case 14: case 18: return 20;
     default: return 35;
   }
 }

@@ -86,13 +86,15 @@ def test_tile_choice_is_a_host_function_of_the_shape():
     assert sel(1024, 10240, 1280, 1280) == 27 and sel(4096, 640, 2560, 2560) == 44
     assert sel(8192, 1280, 5120, 5120) == 28 and sel(8192, 1280, 1280, 1280) == 27      # 128x320: 4 x 4 waves for long K
     # batch 8: the four-phase 256x256 loop for plain Linear launches from 1.5 workgroups per CU on ...
-    assert sel(8192, 10240, 1280, 1280) == 70 and sel(8192, 3840, 1280, 1280) == 70
-    assert sel(32768, 1920, 640, 640) == 70
+    # (71 = that tile's persistent form, one workgroup per CU walking its tiles -- csrc/igemm_pp.h: what the rule
+    #  takes wherever a CU has more than one 256x256 tile; MIXDQ_IGEMM_PERSIST=0 gives 70 back)
+    assert sel(8192, 10240, 1280, 1280) == 71 and sel(8192, 3840, 1280, 1280) == 71
+    assert sel(32768, 1920, 640, 640) == 71
     # ... not for convolutions (k_align = C != k_total: the gather needs the general staging) ...
-    assert sel(32768, 640, 640, 5760) != 70 and sel(8192, 10240, 1280, 11520) != 70
+    assert sel(32768, 640, 640, 5760) not in (70, 71) and sel(8192, 10240, 1280, 11520) not in (70, 71)
     # ... nor a K that is not whole 128-byte tiles; GEMM + GEGLU does (its epilogue runs in registers)
-    assert sel(8192, 10240, 1296, 1296) != 70
-    assert lib.mixdq_igemm_select_id_geglu(8192, 10240, 1280, 0) == 70
+    assert sel(8192, 10240, 1296, 1296) not in (70, 71)
+    assert lib.mixdq_igemm_select_id_geglu(8192, 10240, 1280, 0) == 71
     assert lib.mixdq_igemm_select_id_geglu(1024, 10240, 1280, 0) == 27
     assert lib.mixdq_igemm_select_id_geglu(1024, 10240 + 16, 1280, 0) == -1      # N % 32 != 0
     # packed W4: 32x32x32 tiles (every wave unpacks what it multiplies)
@@ -116,3 +118,39 @@ def test_aq_kernels_never_touch_a_register_whose_load_is_in_flight():
                        text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert "20 AQ kernels checked, 0 failed" in r.stdout
+
+
+def test_f16in_auto_follows_the_measured_records():
+    """mixdq_qlinear_f16in_preferred decides the DEFAULT launch form of every drop-in Linear / 1x1 conv.  It is a
+    table of measurements (csrc/f16in_table.h <- tools/gen_f16in_table.py <- the committed records of
+    tools/bench_f16in.py), not a fitted model: on EVERY recorded row the form it picks is not slower
+    than the other by more than 3 % in any record of that shape; the generated header is what the generator makes
+    from the records today; unmeasured (N, K) pairs keep the reference's two launches."""
+    import json
+    import subprocess
+    import sys
+    from mixdq_amd.build import build
+    lib = ctypes.CDLL(build())
+    pref = lib.mixdq_qlinear_f16in_preferred
+    pref.argtypes, pref.restype = [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int], ctypes.c_int
+    n = 0
+    for rel in ("profiles/r05_f16in_per_layer.txt", "profiles/r06_f16in_per_layer.txt"):
+        path = os.path.join(ROOT, rel)
+        if not os.path.exists(path):
+            continue
+        for ln in open(path):
+            if not ln.startswith("{"):
+                continue
+            r = json.loads(ln)
+            fused = pref(r["M"], r["N"], r["K"], 0)
+            mine, other = (r["f16in_us"], r["pair_us"]) if fused else (r["pair_us"], r["f16in_us"])
+            assert mine <= 1.03 * other, (r, fused)
+            n += 1
+    assert n >= 18
+    assert pref(1024, 1280, 640, 0) == 1 and pref(4096, 5120, 640, 0) == 0        # the clearest rows of either sign
+    assert pref(1024, 1296, 640, 0) == 0 and pref(1024, 1280, 656, 0) == 0         # never measured: the reference's flow
+    assert pref(16384 * 3, 320, 640, 0) == 1 and pref(16384 * 40, 320, 640, 0) == 0    # M within / beyond a factor of two of a row
+    hdr = os.path.join(ROOT, "mixdq_amd", "csrc", "f16in_table.h")
+    before = open(hdr).read()
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_f16in_table.py")], stdout=subprocess.DEVNULL)
+    assert open(hdr).read() == before, "csrc/f16in_table.h is stale: run tools/gen_f16in_table.py"

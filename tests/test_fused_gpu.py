@@ -212,6 +212,8 @@ GEGLU_GEMM_CASES = [  # M, D, K, forced tile config (0 = automatic), bias
     (300, 320, 256, 25, True), (300, 320, 192, 46, True), (130, 160, 128, 46, False),
     # the four-phase 256x256 loop: M tail, several column tiles, a K tail (one-phase fallback)
     (300, 256, 256, 70, True), (513, 384, 384, 70, False), (257, 256, 192, 70, True),
+    # ... and its persistent form (one tile per workgroup at these sizes; the tile loop: test_persistent_... below)
+    (300, 256, 256, 71, True), (513, 384, 384, 71, False), (257, 256, 192, 71, True),
     # every remaining tile family: 64x64x64, the k-split 64x64, 128x128 8-wave, 128x256, 256x256,
     # the deeper 128x320 pipelines; D = 16 (one group)
     (96, 64, 64, 1, True), (130, 64, 256, 37, True), (200, 128, 128, 35, False), (300, 128, 128, 15, True),
@@ -246,7 +248,7 @@ def test_qlinear_geglu_equals_gemm_then_geglu_quantize(C, oracle, case):
     assert torch.equal(got, q2)
 
 
-@pytest.mark.parametrize("cfg", [70, 25, 13])
+@pytest.mark.parametrize("cfg", [70, 71, 25, 13])
 def test_qlinear_geglu_into_an_8_byte_aligned_output(C, oracle, cfg):
     """The entry point asks for 8-byte alignment of the INT8 output only; the register epilogue of the
     256x256 tile stores 16 bytes at a time when it can and 2 x 8 otherwise.  Same bits either way."""
@@ -268,7 +270,7 @@ def test_qlinear_geglu_into_an_8_byte_aligned_output(C, oracle, cfg):
     assert np.array_equal(want.cpu().numpy(), oracle.geglu_quantize(h, s_inv, zp, C.FLAGS & 1)[0])
 
 
-@pytest.mark.parametrize("cfg", [70, 25, 13, 0])
+@pytest.mark.parametrize("cfg", [70, 71, 25, 13, 0])
 def test_qlinear_geglu_with_overflowing_and_nan_columns(C, oracle, cfg):
     """Gates and values beyond the GELU table's range, +-inf (fp16 overflow of the GEMM output) and NaN
     (a NaN bias0): the table epilogues select g / -0 / NaN on the bits there -- same INT8 tensor as
@@ -568,3 +570,50 @@ def test_qlinear_ln_range_and_graph_capture(C):
     ws[8:12].view(torch.int32).fill_(77)                        # (the word is the host's to read, not a launch's to clear)
     C.qlinear_ln(a, w, sc, b0, None, r, g, b, 1e-5, qp, ws)
     assert C.qlinear_ln_status(ws) == 77
+
+
+PP_CASES = [  # M, N, K, workgroups the grid is capped at, GEGLU?, residual?, bias?
+    (1100, 768, 640, 8, True, False, True),      # 15 tiles on 8 workgroups, 5 K-tiles: the buffer parity flips per tile
+    (1100, 768, 512, 8, True, False, False),     # 4 K-tiles: the parity stays
+    (2100, 1024, 640, 16, True, False, True),    # 36 tiles on 16 workgroups: runs of 5 / 4 tiles per XCD, 2 - 3 per workgroup
+    (1100, 768, 640, 8, False, False, True),
+    (1100, 776, 512, 8, False, True, True),      # plain epilogue with a residual, N % 256 != 0 and N % 16 != 0
+    (2100, 1024, 384, 16, False, True, False),
+    (700, 512, 256, 8, False, False, False),     # two K-tiles: the shortest main loop the form takes
+]
+
+
+@pytest.mark.parametrize("M,N,K,wgs,geglu,res,bias", PP_CASES)
+def test_persistent_tile_loop_same_bits_with_several_tiles_per_workgroup(C, oracle, monkeypatch, M, N, K, wgs, geglu,
+                                                                         res, bias):
+    """The persistent four-phase kernel (configuration 71, csrc/igemm_pp.h) with its grid capped so that every
+    workgroup walks two or three tiles: the next tile's first K-tile staged during the current tile's last one and
+    landing under its epilogue, the epilogue's LDS region alternating between the two stage buffers when the
+    K-tile count is odd, the per-tile parameter block -- bit-identical to the oracle and to the
+    one-tile-per-workgroup kernel (70)."""
+    monkeypatch.setenv("MIXDQ_IGEMM_PERSIST_WGS", str(wgs))
+    a, w = dd.int8(811, (M, K)), dd.int8(812, (N, K))
+    scale, bias0 = dd.f32(813, (N,), 2e-4, 9e-4), dd.f32(814, (N,), -300, 300)
+    bs = dd.normal_f16(815, (N,), 0.5) if bias else None
+    if geglu:
+        D = N // 2
+        s_inv, zp = float(np.float32(1) / np.float32(0.02)), -60.0
+        perm = C.geglu_row_order(D, DEV)
+        args = (t(a), t(w)[perm].contiguous(), t(scale)[perm].contiguous(), t(bias0)[perm].contiguous(),
+                None if bs is None else t(bs)[perm].contiguous(), scal(s_inv), scal(zp))
+        got = C.qlinear_geglu(*args, _cfg=71)
+        h = oracle.qlinear(a, w, bias0, scale, bs, C.FLAGS & 1)
+        assert np.array_equal(got.cpu().numpy(), oracle.geglu_quantize(h, s_inv, zp, C.FLAGS & 1)[0])
+        assert torch.equal(got, C.qlinear_geglu(*args, _cfg=70))
+        return
+    r = dd.normal_f16(816, (M, N), 1.5) if res else None
+    kw = dict(_residual=t(r)) if res else {}
+    got = C.qlinear_w8_a8_ohalf(t(a), t(w), t(scale), scal(1), scal(0), t(bias0), t(scale), t(bias0),
+                                None if bs is None else t(bs), _cfg=71, **kw)
+    want = oracle.qlinear(a, w, bias0, scale, bs, C.FLAGS & 1)
+    if res:
+        want = oracle.add_f16(want, r)
+    assert np.array_equal(got.cpu().numpy().view(np.uint16), want.view(np.uint16))
+    ref70 = C.qlinear_w8_a8_ohalf(t(a), t(w), t(scale), scal(1), scal(0), t(bias0), t(scale), t(bias0),
+                                  None if bs is None else t(bs), _cfg=70, **kw)
+    assert torch.equal(got.view(torch.int16), ref70.view(torch.int16))

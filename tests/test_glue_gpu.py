@@ -143,13 +143,14 @@ def test_attention_core_swapped_and_diffusers_processor(C):
     from mixdq_amd.nn.glue import HipAttnProcessor, swap_glue_modules, unswap_glue_modules
     from mixdq_amd.unet import Attention
     torch.manual_seed(0)
-    a = Attention(640, 2048, 64).half().to(DEV)
+    a = Attention(640, 2048, 64).half().to(DEV)              # cross-attention (77 keys: the short-key kernel)
+    a_self = Attention(640, None, 64).half().to(DEV)         # self-attention (the pipelined kernel)
     x = t(dd.normal_f16(81, (2, 1024, 640), 1.0))
     ctx = t(dd.normal_f16(82, (2, 77, 2048), 1.0))
     with torch.no_grad():
-        stock_self, stock_cross = a(x), a(x, ctx)
-        assert swap_glue_modules(nn.ModuleList([a]))["attention"] == 1 and isinstance(a, Attention)
-        got_self, got_cross = a(x), a(x, ctx)
+        stock_self, stock_cross = a_self(x), a(x, ctx)
+        assert swap_glue_modules(nn.ModuleList([a, a_self]))["attention"] == 2 and isinstance(a, Attention)
+        got_self, got_cross = a_self(x), a(x, ctx)
         q, k, v = a.to_q(x), a.to_k(ctx), a.to_v(ctx)
         want = a.to_out[0](C.attention_f16(q, k, v, a.heads))
     assert torch.equal(got_cross.view(torch.int16), want.view(torch.int16))

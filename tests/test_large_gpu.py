@@ -66,7 +66,7 @@ def test_qlinear_full_batch_sampled_rows_vs_oracle(C, oracle, B, T, N, K, bias):
     want_res = oracle.add_f16(want, res.numpy()[rows])
     assert np.array_equal(bits(out_res.cpu().numpy()[rows]), bits(want_res))
     # which tile ran: at these sizes the automatic choice must be one of the large / 8-wave tiles
-    assert C.igemm_select_id(M, N, K) in (13, 20, 25, 27, 28, 35, 41, 44, 70), C.igemm_select_id(M, N, K)
+    assert C.igemm_select_id(M, N, K) in (13, 20, 25, 27, 28, 35, 41, 44, 70, 71), C.igemm_select_id(M, N, K)
 
 
 @pytest.mark.parametrize("B", [8, 16])
@@ -192,7 +192,7 @@ def test_shard_size_geglu_sampled_rows_vs_oracle(C, oracle, B):
     perm = C.geglu_row_order(D, DEV)
     got = C.qlinear_geglu(a, t(w)[perm].contiguous(), t(scale)[perm].contiguous(),
                           t(bias0)[perm].contiguous(), None, scal(s_inv), scal(zp))
-    assert C.igemm_select_id(M, 2 * D, K, geglu=True) == 70
+    assert C.igemm_select_id(M, 2 * D, K, geglu=True) == 71      # the persistent four-phase kernel
     rows = sample_rows(M, 96, 7 * B)
     idx = torch.from_numpy(rows).to(DEV)
     h = oracle.qlinear(a[idx].cpu().numpy(), w, bias0, scale, None, C.FLAGS & 1)

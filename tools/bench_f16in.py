@@ -22,6 +22,9 @@ SHAPES = [  # (name, M per image, N, K)
     ("ff.net.2 640", 4096, 640, 2560), ("ff.net.0.proj 640", 4096, 5120, 640),
     ("attn2.to_k/v", 76, 1280, 2048), ("shortcut 1x1 1280<-640", 1024, 1280, 640),
     ("shortcut 1x1 320<-640", 16384, 320, 640),
+    # (round 6: the other halves of the up-blocks' split shortcuts)
+    ("shortcut 1x1 640<-320", 4096, 640, 320), ("shortcut 1x1 640<-1280", 4096, 640, 1280),
+    ("shortcut 1x1 320<-320", 16384, 320, 320),
 ]
 
 

@@ -32,6 +32,10 @@ def main():
     ap.add_argument("--res", action="store_true")
     ap.add_argument("--ln", action="store_true", help="the GEMM + residual + LayerNorm + quantize launch (slots 6: tile "
                     "final | 10: records + output rows issued | 11: all records in | 14: row statistics done | 15: end)")
+    ap.add_argument("--pp", action="store_true", help="the persistent four-phase kernel (--cfg 71; csrc/igemm_pp.h): "
+                    "FIRST tile 1 prologue issued | 2 first K-tile ready | 3 main loop done | 5 accumulators -> fp16 | "
+                    "6 table landed (plain: first pass staged) | 7 epilogue done;  SECOND tile 10 past its first barrier "
+                    "(its first K-tile landed under the epilogue) | 11 main loop done | 14 epilogue done")
     ap.add_argument("--cfg", type=int, default=0)
     ap.add_argument("--cold", action="store_true", help="stream 512 MB between launches")
     ap.add_argument("--conv", type=int, default=0, metavar="HW",
@@ -97,8 +101,11 @@ def main():
         ok = dt_rt > 0
         ghz = float(np.median(dt_clk[ok] / dt_rt[ok])) * 0.1 if ok.any() else 2.0
         parts = []
-        end = 15 if a.ln else 7
-        for slot in (12, 13, 1, 2, 3, 4, 5, 7, 6, 10, 11, 14, 15) if a.ln else (12, 13, 1, 2, 3, 4, 5, 6, 10, 11, 7):
+        end = 15 if a.ln else 14 if a.pp else 7
+        order = (12, 13, 1, 2, 3, 4, 5, 7, 6, 10, 11, 14, 15) if a.ln else (12, 13, 1, 2, 3, 4, 5, 6, 10, 11, 7)
+        if a.pp:
+            order = (1, 2, 3, 5, 6, 7, 10, 11, 14)
+        for slot in order:
             v = s[:, :, slot]
             have = used & (v != 0)
             if not have.any():
