@@ -133,20 +133,21 @@ def test_f16in_auto_follows_the_measured_records():
     lib = ctypes.CDLL(build())
     pref = lib.mixdq_qlinear_f16in_preferred
     pref.argtypes, pref.restype = [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int], ctypes.c_int
-    n = 0
+    records = {}
     for rel in ("profiles/r05_f16in_per_layer.txt", "profiles/r06_f16in_per_layer.txt"):
         path = os.path.join(ROOT, rel)
         if not os.path.exists(path):
             continue
         for ln in open(path):
-            if not ln.startswith("{"):
-                continue
-            r = json.loads(ln)
-            fused = pref(r["M"], r["N"], r["K"], 0)
-            mine, other = (r["f16in_us"], r["pair_us"]) if fused else (r["pair_us"], r["f16in_us"])
-            assert mine <= 1.03 * other, (r, fused)
-            n += 1
-    assert n >= 18
+            if ln.startswith("{"):
+                r = json.loads(ln)
+                records.setdefault((r["M"], r["N"], r["K"]), []).append((r["pair_us"], r["f16in_us"]))
+    assert len(records) >= 18
+    for (M, N, K), recs in records.items():
+        if pref(M, N, K, 0):     # the one launch is only taken where it was not slower (3 %) in ANY record of the shape
+            assert all(f <= 1.03 * p_ for p_, f in recs), (M, N, K, recs)
+        else:                    # the reference's two launches: kept unless the one launch won EVERY record
+            assert any(p_ <= f for p_, f in recs), (M, N, K, recs)
     assert pref(1024, 1280, 640, 0) == 1 and pref(4096, 5120, 640, 0) == 0        # the clearest rows of either sign
     assert pref(1024, 1296, 640, 0) == 0 and pref(1024, 1280, 656, 0) == 0         # never measured: the reference's flow
     assert pref(16384 * 3, 320, 640, 0) == 1 and pref(16384 * 40, 320, 640, 0) == 0    # M within / beyond a factor of two of a row
