@@ -65,6 +65,9 @@ def parse_args():
     ap.add_argument("--no-graph", action="store_true", help="eager launches (host-bound)")
     ap.add_argument("--no-fuse", action="store_true",
                     help="run the unfused drop-in graph (torch GroupNorm/LayerNorm/GELU + quantize)")
+    ap.add_argument("--swap-glue", action="store_true",
+                    help="with --no-fuse: quantize_unet(..., swap_glue=True) -- the stock GroupNorm (+ SiLU) / LayerNorm / "
+                         "GEGLU modules and the attention core swapped by type for this repo's FP16-output kernels")
     ap.add_argument("--no-fp16", action="store_true", help="skip the FP16 comparison")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -708,7 +711,7 @@ def main():
     else:
         w_cfg, a_cfg = cfgs.load(args.w_config), cfgs.load(args.a_config)
     quantize_unet(unet, Cfg(w_cfg, a_cfg), ckpt, bos=not args.no_bos, bos_dict=bos_dict,
-                  w4_kernel=args.w4_kernel)
+                  w4_kernel=args.w4_kernel, swap_glue=bool(args.swap_glue and args.no_fuse))
     del ckpt
     unet.set_fused(not args.no_fuse)
     bcast_bytes = shard.broadcast_module_state(unet, src=0)
@@ -867,6 +870,7 @@ def main():
             "w_config": args.w_config, "a_config": args.a_config, "bos": not args.no_bos,
             "parallelism": f"dp{world} (batch-sharded replicas, no step-loop collective)",
             "hip_graph": not args.no_graph, "producer_fusions": not args.no_fuse,
+            "swap_glue": bool(args.swap_glue and args.no_fuse),
             "accelerated_layers": n_accel, "w4_kernel_layers": n_w4,
             "quantizable_layers": len(qmods),
             "epilogue_variant": "B" if C.FLAGS & 1 else "A",

@@ -46,7 +46,7 @@ for line in open(out + "/shapes.txt"):
             continue
         agg = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(f[0])):
-            if not any(t in r["Kernel_Name"] for t in ("igemm_kernel", "conv3x3_halo", "attn_fwd_kernel", "attn_short_kernel")):
+            if not any(t in r["Kernel_Name"] for t in ("igemm_kernel", "igemm_pp_kernel", "conv3x3_halo", "attn_fwd_kernel", "attn_short_kernel")):
                 continue
             k = re.sub(r"\(.*$", "", r["Kernel_Name"].replace("mixdq::(anonymous namespace)::", "").replace("void ", ""))
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))

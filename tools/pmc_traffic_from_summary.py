@@ -8,11 +8,12 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r05_pmc_summary.json")
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "profiles", "r06_pmc_summary.json")
 lease = sys.argv[2] if len(sys.argv) > 2 else "unknown"
+lib_sha = sys.argv[3] if len(sys.argv) > 3 else None      # the hash embedded in the library the counters were taken on
 tag = os.path.basename(src)
 out = {"_comment": "HBM-side bytes per launch and MFMA-busy fraction from the rocprofv3 --pmc passes of "
-                   "tools/pmc_r05.sh (profiles/r05_pmc_*): FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, "
+                   "tools/pmc_r06.sh (profiles/r06_pmc_*): FETCH_SIZE x2 (gfx950 correction) + WRITE_SIZE, "
                    "KiB -> bytes, separate passes; mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (4 x "
                    "SQ_BUSY_CU_CYCLES).  Sections = batch size of the benchmarked graph, keys = bench.py "
                    "kernel names; each entry was measured on that very instantiation and launch kind."}
@@ -23,8 +24,9 @@ for name in sorted(os.listdir(d)):          # = bench.py csrc_sha16(): the kerne
     if name.endswith((".hip", ".h")):
         with open(os.path.join(d, name), "rb") as f:
             h.update(name.encode() + b"\0" + f.read())
-out["_provenance"] = {"summary": f"profiles/{tag}", "script": "tools/pmc_r05.sh", "lease": lease,
-                      "csrc_sha16": h.hexdigest()[:16],
+out["_provenance"] = {"summary": f"profiles/{tag}", "script": "tools/pmc_r06.sh", "lease": lease,
+                      "csrc_sha16": lib_sha or h.hexdigest()[:16],
+                      "csrc_sha16_from": "the probed library (mixdq_build_csrc_sha16)" if lib_sha else "the source tree at table-generation time",
                       "note": "collected by the builder's rocprofv3 --pmc passes; bench.py re-prints these columns and "
                               "drops them when csrc_sha16 differs from the running tree's"}
 for key, e in json.load(open(src)).items():
@@ -36,6 +38,12 @@ for key, e in json.load(open(src)).items():
     elif kern.startswith("conv3x3_halo"):
         name = f"conv3x3_halo_kernel<{args[0]},{args[1]},{args[2]}>"
         bs = int(re.search(r"conv3x3 (\d+)x", shape).group(1))
+    elif kern.startswith("igemm_pp_kernel"):       # the persistent four-phase kernel: configuration 71
+        kind = "linear_geglu" if shape.split()[0] == "geglu" else "linear"
+        name = f"igemm_kernel<256,256,128,2,{kind}>#cfg71"
+        rows = int(re.search(r"M(\d+)", shape).group(1))
+        ncols = int(re.search(r"N(\d+)", shape).group(1))
+        bs = max(1, rows // (4096 if ncols in (640, 5120) and rows % 4096 == 0 else 1024))
     else:
         kind = {"geglu": "linear_geglu", "linattn": "linear_attn", "ln": "linear_ln", "f16in": "linear_f16in"}.get(
             shape.split()[0], "linear")
@@ -54,7 +62,7 @@ for key, e in json.load(open(src)).items():
         "traffic_over_algorithmic": round(e["traffic_over_algorithmic"], 3),
         "mfma_util": round(e.get("mfma_util", 0.0), 4),
         "us_under_pmc": round(e.get("SQ:_dur_ns", 0) / 1e3, 1),
-        "source": f"profiles/{tag} (tools/pmc_r05.sh)"}
+        "source": f"profiles/{tag} (tools/pmc_r06.sh)"}
     if "valu_util" in e:
         out[f"bs{bs}"][name]["valu_util"] = round(e["valu_util"], 4)
 dst = os.path.join(ROOT, "profiles", "pmc_traffic.json")
