@@ -14,6 +14,13 @@
 // resident tile, or the 64 packed-fp16 registers of a pending one, do not fit, and the GELU table (76 KB) cannot
 // sit in LDS beside two 64 KB stage buffers.
 //
+// (Measured and dropped, round 6: the next tile's SECOND K-tile requested from the GEGLU epilogue as well -- all table
+//  lookups first, the table laid over stage L and the staging tile in the extra block, so that stage L is free ~2 us
+//  before the main loop; bit-identical, and SLOWER: (8192, 10240, 1280) 107.7 -> 110.5 us, (32768, 5120, 640) 138 -> 145.5
+//  (profiles/r06_persistent_early_k1_ab.txt): with the lookups in front the store passes no longer run beside lookup
+//  arithmetic, and the early DMA shares the CU's memory pipe with the stores.  hipcc also put `s_waitcnt vmcnt(0)` in
+//  front of every compiler-generated LDS read behind that DMA; those reads had to become inline asm.)
+//
 // LDS (all 160 KiB): [params 3 K][stage 0 64 K][extra 29 K][stage 1 64 K].  The epilogue of a tile whose LAST K-tile
 // sat in stage L works in the 93 KB that contain stage L and the extra block -- [3 K, 96 K) or [67 K, 160 K):
 // contiguous either way -- while stage L ^ 1 receives the next tile's first K-tile.  93 KB = the GELU table (76 KB)
@@ -307,10 +314,12 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(MIXDQ_IGEMM_HEAD_PARAM
         else to_regs(std::integral_constant<int, 2>{}, tm);
       }
       if (first) MIXDQ_STAMP_AT(5);
+      else MIXDQ_STAMP_AT(12);
       // the table has landed -- and with it everything older: the next tile's first K-tile, whole
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (first) MIXDQ_STAMP_AT(6);
+      else MIXDQ_STAMP_AT(13);
       const int Dh = p.N >> 1;
       const bool al16 = ((uintptr_t)p.Dq & 15) == 0;
 #pragma unroll
@@ -360,6 +369,7 @@ __global__ __launch_bounds__(512, 2) void igemm_pp_kernel(MIXDQ_IGEMM_HEAD_PARAM
           }
         }
         if (pass == 0) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // (pass 1: the next tile's first barrier, or the exit)
+        if (pass == 0 && !first) MIXDQ_STAMP_AT(15);
       }
     } else {
       // ---- plain epilogue: accumulators -> fp16 tile (igemm_kernel's to_tile arithmetic) -> whole-row stores,

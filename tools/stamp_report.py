@@ -35,7 +35,8 @@ def main():
     ap.add_argument("--pp", action="store_true", help="the persistent four-phase kernel (--cfg 71; csrc/igemm_pp.h): "
                     "FIRST tile 1 prologue issued | 2 first K-tile ready | 3 main loop done | 5 accumulators -> fp16 | "
                     "6 table landed (plain: first pass staged) | 7 epilogue done;  SECOND tile 10 past its first barrier "
-                    "(its first K-tile landed under the epilogue) | 11 main loop done | 14 epilogue done")
+                    "(its first K-tile landed under the epilogue) | 11 main loop done | 12 accumulators -> fp16 | 13 table landed | "
+                    "15 first store pass done | 14 epilogue done")
     ap.add_argument("--cfg", type=int, default=0)
     ap.add_argument("--cold", action="store_true", help="stream 512 MB between launches")
     ap.add_argument("--conv", type=int, default=0, metavar="HW",
@@ -104,7 +105,7 @@ def main():
         end = 15 if a.ln else 14 if a.pp else 7
         order = (12, 13, 1, 2, 3, 4, 5, 7, 6, 10, 11, 14, 15) if a.ln else (12, 13, 1, 2, 3, 4, 5, 6, 10, 11, 7)
         if a.pp:
-            order = (1, 2, 3, 5, 6, 7, 10, 11, 14)
+            order = (1, 2, 3, 5, 6, 7, 10, 11, 12, 13, 15, 14)
         for slot in order:
             v = s[:, :, slot]
             have = used & (v != 0)
