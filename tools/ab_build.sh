@@ -26,6 +26,16 @@ for src in b.SOURCES:
     flags = [f for f in b.FLAGS if f != "-Wall"] + list(getattr(b, "EXTRA", {}).get(src, []))
     procs.append(subprocess.Popen(["/opt/rocm/bin/hipcc"] + flags + ["-c", "-o", obj, os.path.join(csrc, src)]))
 assert all(p.wait() == 0 for p in procs), "compile failed"
+# the AQ kernels park in-flight loads in registers the compiler believes written: the static check of the build
+# (mixdq_amd/build.py _check_aq_isa) on THIS library's assembly too, same flags, -S instead of -c
+if "igemm_aq.hip" in b.SOURCES and os.path.exists("tools/check_aq_isa.py"):
+    flags = [f for f in b.FLAGS if f != "-Wall"] + [f for f in getattr(b, "EXTRA", {}).get("igemm_aq.hip", []) if not f.startswith("-save-temps")]
+    asm = os.path.join(d, "igemm_aq.s")
+    subprocess.check_call(["/opt/rocm/bin/hipcc"] + flags + ["--cuda-device-only", "-S", "-o", asm, os.path.join(csrc, "igemm_aq.hip")],
+                          stderr=subprocess.DEVNULL)
+    r = subprocess.run([sys.executable, "tools/check_aq_isa.py", asm], capture_output=True, text=True)
+    assert r.returncode == 0, "AQ ISA check failed for this library:\n" + r.stdout[-2000:]
+    os.remove(asm)
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o",
                        os.path.join(d, "libmixdq_hip.so")] + objs)
 for o in objs:

@@ -2,6 +2,7 @@
 # Diagnostic build with in-kernel phase stamps (csrc/igemm.hip MIXDQ_STAMP): build/stamp/libmixdq_stamp.so.
 # Use with  MIXDQ_HIP_LIB=$PWD/build/stamp/libmixdq_stamp.so python tools/stamp_report.py ...
 set -e
+# (igemm_aq.o is taken from mixdq_amd/_obj: the object mixdq_amd/build.py compiled AND ran tools/check_aq_isa.py on)
 cd "$(dirname "$0")/.."
 mkdir -p build/stamp
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-function"
