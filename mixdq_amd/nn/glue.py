@@ -153,14 +153,25 @@ def _is_geglu(mod) -> bool:
     return type(mod).__name__ == "GEGLU" and isinstance(getattr(mod, "proj", None), nn.Module)
 
 
-def swap_glue_modules(unet: nn.Module, attention: bool = True) -> dict:
+# Parent classes (by name) whose forward is KNOWN to apply the nn.SiLU module `act` to the output of each GroupNorm in
+# `norms`, and to nothing else of it: diffusers' and this repo's ResnetBlock2D (norm1 / norm2 -> nonlinearity) and the
+# UNet itself (conv_norm_out -> conv_act).  Only there is the SiLU folded into the GroupNorm's launch: a parent that
+# applied F.silu itself, or used the GroupNorm's output twice, would get the activation twice or in the wrong place.
+SILU_PAIRS = {"ResnetBlock2D": (("norm1", "norm2"), "nonlinearity"),
+              "UNet2DConditionModel": (("conv_norm_out",), "conv_act"),
+              "SDXLUNet": (("conv_norm_out",), "conv_act")}
+
+
+def swap_glue_modules(unet: nn.Module, attention: bool = True, silu_pairs=None) -> dict:
     """Swap the stock glue modules of `unet` in place (see the top of this file); returns how many of each kind
-    were swapped.  Idempotent.  `attention=False` leaves the attention core to PyTorch's SDPA."""
+    were swapped.  Idempotent.  `attention=False` leaves the attention core to PyTorch's SDPA.  `silu_pairs`:
+    {parent class name: ((GroupNorm attribute names), SiLU attribute name)} in place of SILU_PAIRS."""
     n = dict(groupnorm=0, silu_folded=0, layernorm=0, geglu=0, attention=0)
+    pairs = SILU_PAIRS if silu_pairs is None else silu_pairs
     for parent in unet.modules():
         kids = parent._modules
-        # GroupNorm -> SiLU pairs: a ResnetBlock2D's (norm1, norm2, nonlinearity), the UNet's (conv_norm_out, conv_act)
-        for norms, act in ((("norm1", "norm2"), "nonlinearity"), (("conv_norm_out",), "conv_act")):
+        spec = pairs.get(type(parent).__name__)
+        for norms, act in ((spec,) if spec else ()):
             a = kids.get(act)
             if a is None or type(a) not in (nn.SiLU, HipSiLU):
                 continue

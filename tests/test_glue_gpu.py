@@ -54,7 +54,10 @@ def test_groupnorm_silu_pair_swapped(C, N, H, W, Cc, G):
     x = t(dd.normal_f16(53, (N, H, W, Cc), 1.5)).permute(0, 3, 1, 2)       # NCHW view of NHWC memory
     temb = t(dd.normal_f16(54, (N, 1280), 1.0))
     keys = list(m.state_dict())
-    n = swap_glue_modules(m)
+    # (folding is limited to parents KNOWN to apply the SiLU module to the norm's output: here the stand-in is named)
+    pairs = {"_Res": (("norm1", "norm2"), "nonlinearity")}
+    assert swap_glue_modules(_Res(Cc, G))["silu_folded"] == 0          # an unknown parent class: nothing folded
+    n = swap_glue_modules(m, silu_pairs=pairs)
     assert n["groupnorm"] == 2 and n["silu_folded"] == 2 and list(m.state_dict()) == keys
     assert type(m.norm1) is HipGroupNorm and type(m.nonlinearity) is HipSiLU and isinstance(m.norm1, nn.GroupNorm)
     with torch.no_grad():
@@ -74,7 +77,7 @@ def test_groupnorm_silu_pair_swapped(C, N, H, W, Cc, G):
     # an input the kernel does not take (FP32; NCHW memory) goes to the stock op, activation applied once
     with torch.no_grad():
         m32 = _Res(Cc, G).to(DEV)
-        swap_glue_modules(m32)
+        swap_glue_modules(m32, silu_pairs=pairs)
         y32 = m32(x.float(), temb.float())[0]
         assert torch.allclose(y32, F.silu(F.group_norm(x.float(), G, m32.norm1.weight, m32.norm1.bias, 1e-5)), atol=1e-6)
         if N * H * W > 1:
