@@ -227,3 +227,38 @@ def test_attention_argument_checks(C):
         C.attention_f16(odd, odd, odd, 2)                # row stride not a multiple of 8
     empty = C.attention_f16(q[:, :0], q, q, 2)
     assert empty.shape == (1, 0, 128)
+
+
+def test_attention_xcd_map_changes_where_a_block_runs_not_what_it_computes(C):
+    """The XCD-aware workgroup map (csrc/attention.hip attn_block_of, round 6) is a permutation of the workgroup ->
+    (batch, head, query block) assignment: with MIXDQ_ATTN_XCD=0 (read once per process: a child process) the pipelined
+    kernel (both launch geometries, ragged query / key counts, INT8 output) and the short-key kernel return the bits
+    they return with the map on."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    shapes = [(2, 1024, 1024, 1280), (3, 320, 704, 128), (1, 4096, 4096, 640), (2, 1024, 77, 1280), (1, 1, 300, 128)]
+    code = r'''
+import sys, hashlib, torch
+sys.path.insert(0, %r)
+import mixdq_amd._C as C
+from tests import detdata as dd
+import numpy as np
+out = []
+for B, tq, tkv, Cc in %r:
+    q = torch.from_numpy(dd.normal_f16(901, (B, tq, Cc), 1.0)).cuda()
+    kv = torch.from_numpy(dd.normal_f16(902, (B, tkv, 2 * Cc), 1.0)).cuda()
+    s, z = torch.tensor(30.0, device="cuda"), torch.tensor(2.0, device="cuda")
+    for quant in (False, True):
+        o = C.attention_f16(q, kv[..., :Cc], kv[..., Cc:], Cc // 64, *((s, z) if quant else ()))
+        out.append(hashlib.sha256(o.cpu().numpy().tobytes()).hexdigest())
+print("HASHES " + " ".join(out))
+''' % (root, shapes)
+    got = {}
+    for flag in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, MIXDQ_ATTN_XCD=flag),
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-3000:]
+        got[flag] = [ln for ln in r.stdout.splitlines() if ln.startswith("HASHES ")][-1]
+    assert got["1"] == got["0"] and len(got["1"].split()) == 1 + 2 * len(shapes)

@@ -155,3 +155,21 @@ def test_f16in_auto_follows_the_measured_records():
     before = open(hdr).read()
     subprocess.check_call([sys.executable, os.path.join(ROOT, "tools", "gen_f16in_table.py")], stdout=subprocess.DEVNULL)
     assert open(hdr).read() == before, "csrc/f16in_table.h is stale: run tools/gen_f16in_table.py"
+
+
+def test_persistent_form_is_a_switchable_choice_of_the_rule():
+    """MIXDQ_IGEMM_PERSIST=0 (read once per process) gives the one-workgroup-per-tile four-phase kernel (70) back where
+    the rule otherwise takes its persistent form (71); launches with at most one 256x256 tile per CU never take 71."""
+    import subprocess
+    import sys
+    code = ("import ctypes; from mixdq_amd.build import build; lib = ctypes.CDLL(build()); "
+            "f = lib.mixdq_igemm_select_id; f.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int]; "
+            "print('IDS', f(8192, 10240, 1280, 1280), f(8192, 3840, 1280, 1280), f(2048, 10240, 1280, 1280))")
+    ids = {}
+    for flag in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=dict(os.environ, MIXDQ_IGEMM_PERSIST=flag),
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:]
+        ids[flag] = [int(v) for v in [ln for ln in r.stdout.splitlines() if ln.startswith("IDS ")][-1].split()[1:]]
+    assert ids["1"][:2] == [71, 71] and ids["0"][:2] == [70, 70]
+    assert ids["1"][2] == ids["0"][2] and ids["1"][2] not in (70, 71)       # (2048, 10240, 1280): 320 tiles of 256x256 < 1.5 per CU
