@@ -462,6 +462,11 @@ int mixdq_conv_halo_select(int N, int H, int W, int C, int K, int R, int S, int 
  * 2 x 0x4c00 uint16: f16 bits of gelu(g) for the FP16 gate g with bits (sign << 15) | magnitude,
  * magnitude < 0x4c00 (|g| < 16), positive half first -- copied to `out_device` (77 824 bytes). */
 int mixdq_gelu_table(uint16_t* out_device, mixdq_stream_t stream);
+/* The FP16 -> FP16 SiLU table the GroupNorm apply pass of LARGE launches looks SiLU up in (round 6; built on first use
+ * by the specification itself, include/mixdq_math.h: same bits as the arithmetic): n_pos entries for y = +bits, then
+ * n_neg for y = -bits; values outside take the arithmetic.  Builds the table if needed; copies it to out_device
+ * (2 * (n_pos + n_neg) bytes) unless null.  No reference counterpart (stock nn.SiLU). */
+int mixdq_silu_table(uint16_t* out_device_or_null, int* n_pos, int* n_neg, mixdq_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -604,6 +604,19 @@ _lib.mixdq_qlinear_w8a8_geglu.restype = _i32
 GELU_TABLE_MAG = 0x4c00   # csrc/igemm.hip kGeluTabMag: the table covers |gate| < 16
 
 
+def silu_table(device="cuda"):
+    """(table [n_pos + n_neg] uint16 as int16 tensor, n_pos, n_neg): the FP16 -> FP16 SiLU table of the GroupNorm apply
+    pass's large-launch variant (mixdq_silu_table); building it eagerly keeps the init kernel out of captured graphs."""
+    _lib.mixdq_silu_table.argtypes = [_vp, _vp, _vp, _vp]
+    _lib.mixdq_silu_table.restype = _i32
+    n_pos, n_neg = ctypes.c_int(0), ctypes.c_int(0)
+    with torch.cuda.device(device):
+        _status(_lib.mixdq_silu_table(None, ctypes.byref(n_pos), ctypes.byref(n_neg), _stream()), "silu_table")
+        out = torch.empty(n_pos.value + n_neg.value, dtype=torch.int16, device=device)
+        _status(_lib.mixdq_silu_table(out.data_ptr(), None, None, _stream()), "silu_table")
+    return out, n_pos.value, n_neg.value
+
+
 def gelu_table(device="cuda") -> torch.Tensor:
     """The table the GEMM + GEGLU epilogue of the large tiles looks GELU up in (mixdq_gelu_table):
     int16 [2, 0x4c00] -- row 0: gates +0 .. +16, row 1: -0 .. -16 -- of f16 bit patterns."""

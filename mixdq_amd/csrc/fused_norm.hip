@@ -190,9 +190,57 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float2* __restric
                     threadIdx.x);
 }
 
+// ---- SiLU by table (round 6) -----------------------------------------------------------------------------------
+// The apply pass rounds the normalised value to FP16, applies SiLU and rounds to FP16 again: SiLU there is a function
+// of 16 bits.  Its arithmetic (include/mixdq_math.h: an exp and a correctly rounded division, ~32 of the pass's ~45
+// vector operations per element) makes the pass VALU-bound at batch >= 8 ((8, 128 x 128, 320): 75 us with SiLU, 45
+// without).  TAB instantiations look f16(silu(y)) up in LDS instead: the table covers the non-trivial range of the
+// specification -- y in [0, 8.06) (beyond: silu(y) rounds to y) and (-20.5, 0] (beyond: -0) -- 75 KB, built ONCE per
+// device BY the specification (silu_table_init_kernel), copied into LDS by LDS-DMA at block entry by blocks that then
+// walk several chunks of their image; a value outside the table (or NaN / inf) takes the arithmetic itself, decided
+// per wave.  Bit-identical by construction; used where a launch is large enough to pay for the table (below).
+constexpr int kSiluPos = 0x4810, kSiluNeg = 0x4d20;          // magnitudes (FP16 bit patterns) covered per sign
+constexpr int kSiluTabBytes = (2 * (kSiluPos + kSiluNeg) + 1023) / 1024 * 1024;
+__device__ uint16_t g_silu_tab[kSiluTabBytes / 2];
+
+__global__ __launch_bounds__(256) void silu_table_init_kernel() {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= kSiluTabBytes / 2) return;
+  unsigned short bits = 0;
+  if (i < kSiluPos) bits = (unsigned short)i;
+  else if (i < kSiluPos + kSiluNeg) bits = (unsigned short)(0x8000 | (i - kSiluPos));
+  __half_raw r;
+  r.x = bits;
+  g_silu_tab[i] = __half_as_ushort(f32_to_f16_rn(mixdq_siluf(__half2float(__half(r)))));
+}
+
+// Built once per device by the first launch that needs it; inside a stream capture the (idempotent) init kernel is
+// recorded in front of the first consumer of that capture only (the logic of igemm.hip's ensure_gelu_table).
+inline int ensure_silu_table(hipStream_t stream) {
+  static bool done[64] = {};
+  static unsigned long long in_capture[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MIXDQ_ERR_LAUNCH;
+  if (done[dev]) return MIXDQ_OK;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  unsigned long long cap_id = 0;
+  if (hipStreamGetCaptureInfo(stream, &cap, &cap_id) != hipSuccess) return MIXDQ_ERR_LAUNCH;
+  if (cap != hipStreamCaptureStatusNone && cap_id != 0 && in_capture[dev] == cap_id) return MIXDQ_OK;
+  silu_table_init_kernel<<<(kSiluTabBytes / 2 + 255) / 256, 256, 0, stream>>>();
+  if (hipGetLastError() != hipSuccess) return MIXDQ_ERR_LAUNCH;
+  if (cap == hipStreamCaptureStatusNone) {
+    if (hipStreamSynchronize(stream) != hipSuccess) return MIXDQ_ERR_LAUNCH;
+    done[dev] = true;
+  } else {
+    in_capture[dev] = cap_id;
+  }
+  return MIXDQ_OK;
+}
+
 // SELF: the blocks reduce their groups' partials themselves (stats == nullptr); a template parameter because as a
 // run-time branch the two forms shared registers and the compiler drained every load where they met.
-template <bool SILU, bool UNFUSED, bool SELF>
+// TAB: SiLU by the LDS table above; the block walks the chunks blockIdx.x, blockIdx.x + gridDim.x, ... of its image.
+template <bool SILU, bool UNFUSED, bool SELF, bool TAB = false>
 __global__ void gn_apply_kernel(const __half* __restrict__ x, const __half* __restrict__ x2,
                                 const float2* __restrict__ partial,
                                 const float2* __restrict__ stats, float eps,
@@ -204,7 +252,19 @@ __global__ void gn_apply_kernel(const __half* __restrict__ x, const __half* __re
   MIXDQ_ARGS_NOW(x, x2, partial, stats, eps, gamma, beta, s_inv_p, zp_p, out_q, out_h);
   MIXDQ_ARGS_NOW(g.C, g.G, g.cg, g.OCs, g.PPa, g.GS, g.HW, g.ppb_apply, g.nchunk, g.C1, raw.s_inv[0],
                  raw.s_inv[1], raw.zp[0], raw.zp[1], raw.q[0], raw.q[1]);
-  __shared__ float2 s_stats[1024];   // G <= OC * PP <= 1024
+  static_assert(!TAB || (SILU && !SELF), "the table variant: SiLU, statistics from the finalize launch");
+  __shared__ float2 s_stats[SELF ? 1024 : 1];   // G <= OC * PP <= 1024
+  extern __shared__ __attribute__((aligned(16))) char gn_dyn[];   // TAB: the SiLU table
+  if constexpr (TAB) {     // requested first of all, by the block's complete waves, 1 KiB per wave-instruction
+    const int nfull = (int)blockDim.x >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    if (wave < nfull)
+      for (int q = wave; q < kSiluTabBytes / 1024; q += nfull)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(g_silu_tab) + q * 1024 +
+                                                            ((int)threadIdx.x & 63) * 16),
+            (__attribute__((address_space(3))) void*)(gn_dyn + q * 1024), 16, 0, 0);
+  }
   // the quantizers' scalars as scalar loads at kernel entry (kernel-uniform addresses; as plain loads they were
   // vector loads issued after the statistics, the raw pair behind a pointer fetched from the argument block)
   using cf32 = const __attribute__((address_space(4))) float;
@@ -216,15 +276,16 @@ __global__ void gn_apply_kernel(const __half* __restrict__ x, const __half* __re
   // channel slice blockIdx.z: octets [z * OCs, (z + 1) * OCs) = groups [z * GS, (z + 1) * GS) -- a slice ends
   // on a group boundary; one slice (OCs = OC, PPa = PP, GS = G) unless the launch sliced the pass
   const int o = (int)blockIdx.z * g.OCs + t % g.OCs, pp = t / g.OCs;
-  const int n = blockIdx.y, chunk = blockIdx.x;
+  const int n = blockIdx.y;
+  int chunk = blockIdx.x;
   const int g0 = (8 * o) / g.cg;
   const int jb = min(8, (g0 + 1) * g.cg - 8 * o);
   const Half8 gm = *reinterpret_cast<const Half8*>(gamma + 8 * o);
   const Half8 bt = *reinterpret_cast<const Half8*>(beta + 8 * o);
   // the block's first pixel is requested here, beside gamma / beta / the statistics, not behind them: at batch 1
   // a thread has one or two pixels, and the pass was two memory round trips in a row (statistics, then pixels)
-  const int64_t p_begin = (int64_t)chunk * g.ppb_apply;
-  const int64_t p_end = min(g.HW, p_begin + g.ppb_apply);
+  int64_t p_begin = (int64_t)chunk * g.ppb_apply;
+  int64_t p_end = min(g.HW, p_begin + g.ppb_apply);
   int xs;
   const __half* src = gn_src(x, x2, g, n, o, xs);
   Half8 h_next;
@@ -270,12 +331,50 @@ __global__ void gn_apply_kernel(const __half* __restrict__ x, const __half* __re
   int8_t* raw_q = which ? raw.q[1] : raw.q[0];
   const float raw_si = which ? raw_si1 : raw_si0, raw_zp = which ? raw_zp1 : raw_zp0;
   if (raw_q) raw_q += ((int64_t)n * g.HW) * xs + (8 * o - (which ? g.C1 : 0));
+  if constexpr (TAB) {     // the table has landed, for every wave (the first pixel with it)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  const uint16_t* tab = reinterpret_cast<const uint16_t*>(gn_dyn);
+  for (;;) {               // (one chunk per block unless TAB)
   for (int64_t p = p_begin + pp; p < p_end; p += g.PPa) {
     const Half8 h = h_next;
     if (p + g.PPa < p_end) h_next = *reinterpret_cast<const Half8*>(src + (p + g.PPa) * xs);
     Half8 oh;
     oh.w[0] = oh.w[1] = oh.w[2] = oh.w[3] = 0;
     float y8[8], h8[8];
+    if constexpr (TAB) {
+      float pre[8];
+      uint32_t tb[8];
+      bool far = false;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        h8[j] = half_at(h, j);
+        const __half yh = f32_to_f16_rn(__builtin_fmaf(h8[j], a[j], b[j]));     // GroupNorm -> fp16
+        pre[j] = __half2float(yh);
+        const uint32_t yb = __half_as_ushort(yh), mag = yb & 0x7fffu;
+        const bool neg = (yb >> 15) != 0;
+        const bool in = mag < (uint32_t)(neg ? kSiluNeg : kSiluPos);
+        far |= !in;
+        tb[j] = tab[in ? (neg ? kSiluPos + mag : mag) : 0u];                      // f16(silu(y)), from the table
+      }
+      if (__builtin_amdgcn_ballot_w64(far) != 0) {      // wave-uniform, rare: a value the table does not cover
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const uint32_t yb = __half_as_ushort(__float2half_rn(pre[j])), mag = yb & 0x7fffu;
+          if (mag >= (uint32_t)((yb >> 15) ? kSiluNeg : kSiluPos))
+            tb[j] = __half_as_ushort(f32_to_f16_rn(mixdq_siluf(pre[j])));       // the specification itself
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        __half_raw r;
+        r.x = (unsigned short)tb[j];
+        y8[j] = __half2float(__half(r));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) oh.w[j] = tb[2 * j] | (tb[2 * j + 1] << 16);
+    } else {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       h8[j] = half_at(h, j);
@@ -284,11 +383,19 @@ __global__ void gn_apply_kernel(const __half* __restrict__ x, const __half* __re
       y8[j] = y;
       put_half(oh, j, y);
     }
+    }
     // (the quantizers only where their output exists -- kernel-uniform branches -- and with the packed helper:
     //  the pass is VALU-bound, and the raw-input quantizer ran for every element whether or not it was wanted)
     if (want_q) *reinterpret_cast<uint2*>(out_q + img + p * g.C) = quantize_pack8<UNFUSED>(y8, s_inv, zp);
     if (out_h) *reinterpret_cast<Half8*>(out_h + img + p * g.C) = oh;
     if (raw_q) *reinterpret_cast<uint2*>(raw_q + p * xs) = quantize_pack8<UNFUSED>(h8, raw_si, raw_zp);
+  }
+    if constexpr (!TAB) break;
+    chunk += (int)gridDim.x;                       // TAB: the block's next chunk of this image
+    if (chunk >= g.nchunk_apply) break;
+    p_begin = (int64_t)chunk * g.ppb_apply;
+    p_end = min(g.HW, p_begin + g.ppb_apply);
+    if (p_begin + pp < p_end) h_next = *reinterpret_cast<const Half8*>(src + (p_begin + pp) * xs);
   }
 }
 
@@ -636,8 +743,45 @@ extern "C" int mixdq_groupnorm_silu_quantize3(const void* x_nhwc, int C1, const 
     g.nchunk_apply = (int)((HW + g.ppb_apply - 1) / g.ppb_apply);
     threads_apply = g.OCs * g.PPa;
   }
-  const dim3 grid(g.nchunk_apply, N, nslice);
   const bool unfused = flags & MIXDQ_FLAG_UNFUSED;
+  // SiLU by table (see gn_apply_kernel): where the launch is large enough to pay for 75 KB of table per block -- from
+  // MIXDQ_GN_SILU_TAB_MIN elements on (default 2 Mi) -- statistics from the finalize launch, no channel slices.
+  // Measured (tools/bench_norms.py, profiles/r06_gn_silu_table_ab.txt; us for the three launches, arithmetic -> table):
+  // (8, 128 x 128, 320) 76.2 -> 57.2, (8, 64 x 64, 640) 46.8 -> 37.0, (8, 32 x 32, 1280) 32.7 -> 26.6; one image:
+  // (1, 128 x 128, 960) 40.0 -> 30.4, (1, 64 x 64, 1920) 26.2 -> 20.2, (1, 128 x 128, 320) 21.6 -> 18.3, (1, 64 x 64, 640)
+  // 15.9 -> 14.9 -- and (1, 32 x 32, 1280), 1.3 Mi elements, 12.8 -> 13.3: the threshold.
+  // MIXDQ_GN_SILU_TAB=0 never / 1 wherever possible (tests).
+  static const int tab_mode = [] { const char* e = getenv("MIXDQ_GN_SILU_TAB"); return e ? atoi(e) : -1; }();
+  static const int64_t tab_min = [] { const char* e = getenv("MIXDQ_GN_SILU_TAB_MIN"); return e ? atoll(e) : (int64_t)2 << 20; }();
+  const bool use_tab = apply_silu && stats != nullptr && nslice == 1 && tab_mode != 0 &&
+                       (tab_mode == 1 || (int64_t)N * HW * C >= tab_min);
+  if (use_tab) {
+    if (const int st = ensure_silu_table(stream)) return st;
+    // ~512 threads per block, two blocks per CU (75 KB of LDS each), every block walking several chunks of its image;
+    // the same number of pixels per THREAD and chunk as the plain pass would take (the pass is elementwise: any split
+    // gives the same bits)
+    const int iters = g.ppb_apply / g.PP;
+    g.PPa = g.OC >= 512 ? 1 : 512 / g.OC;
+    g.ppb_apply = iters * g.PPa;
+    g.nchunk_apply = (int)((HW + g.ppb_apply - 1) / g.ppb_apply);
+    const int threads_tab = g.OC * g.PPa;
+    int gx = (2 * kNumCU + N - 1) / N;
+    if (gx > g.nchunk_apply) gx = g.nchunk_apply;
+    if (gx < 1) gx = 1;
+    static bool seen_t[2][64] = {};
+#define GN_APPLY_TAB(U)                                                                                         \
+    do {                                                                                                        \
+      if (const int st = lds_opt_in(reinterpret_cast<const void*>(&gn_apply_kernel<true, U, false, true>),       \
+                                    kSiluTabBytes, seen_t[U ? 1 : 0])) return st;                                \
+      gn_apply_kernel<true, U, false, true><<<dim3(gx, N, 1), threads_tab, kSiluTabBytes, stream>>>(            \
+          (const __half*)x_nhwc, (const __half*)x2_nhwc, partial, stats, eps, (const __half*)gamma,             \
+          (const __half*)beta, scale_inv, zero_point, out_q_or_null, (__half*)out_f16_or_null, g, raw);         \
+    } while (0)
+    if (unfused) GN_APPLY_TAB(true); else GN_APPLY_TAB(false);
+#undef GN_APPLY_TAB
+    return launch_status();
+  }
+  const dim3 grid(g.nchunk_apply, N, nslice);
 #define GN_APPLY(S, U)                                                                          \
   (stats ? gn_apply_kernel<S, U, false> : gn_apply_kernel<S, U, true>)<<<grid, threads_apply, 0, stream>>>( \
       (const __half*)x_nhwc, (const __half*)x2_nhwc, partial, stats, eps, (const __half*)gamma, \
@@ -647,6 +791,19 @@ extern "C" int mixdq_groupnorm_silu_quantize3(const void* x_nhwc, int C1, const 
   else            { if (unfused) GN_APPLY(false, true); else GN_APPLY(false, false); }
 #undef GN_APPLY
   return launch_status();
+}
+
+// The FP16 -> FP16 SiLU table of the apply pass's TAB variant (built on first use; this call builds it eagerly --
+// mixdq_amd does so before it captures a graph -- and copies it out for the test that holds every entry to the
+// scalar specification): [kSiluPos] entries for y = +bits, then [kSiluNeg] for y = -bits.
+extern "C" int mixdq_silu_table(uint16_t* out_device_or_null, int* n_pos, int* n_neg, mixdq_stream_t stream) {
+  if (n_pos) *n_pos = kSiluPos;
+  if (n_neg) *n_neg = kSiluNeg;
+  if (const int st = ensure_silu_table((hipStream_t)stream)) return st;
+  if (!out_device_or_null) return MIXDQ_OK;
+  return hipMemcpyFromSymbolAsync(out_device_or_null, HIP_SYMBOL(g_silu_tab), 2 * (kSiluPos + kSiluNeg), 0,
+                                  hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess
+             ? MIXDQ_OK : MIXDQ_ERR_LAUNCH;
 }
 
 extern "C" int mixdq_layernorm_quantize(const void* x, const void* gamma, const void* beta,

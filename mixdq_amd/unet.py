@@ -1225,6 +1225,7 @@ class SDXLUNet(nn.Module):
         if dev is not None:
             from mixdq_amd import _C
             _C.gelu_table(dev)
+            _C.silu_table(dev)              # ... and the SiLU table of the large GroupNorm apply launches (fused_norm.hip)
         return self
 
     def set_fused(self, enabled: bool = True):

@@ -617,3 +617,65 @@ def test_persistent_tile_loop_same_bits_with_several_tiles_per_workgroup(C, orac
     ref70 = C.qlinear_w8_a8_ohalf(t(a), t(w), t(scale), scal(1), scal(0), t(bias0), t(scale), t(bias0),
                                   None if bs is None else t(bs), _cfg=70, **kw)
     assert torch.equal(got.view(torch.int16), ref70.view(torch.int16))
+
+
+def test_silu_table_is_the_specification(C, oracle):
+    """The GroupNorm apply pass of large launches looks f16(silu(y)) up in an LDS table (csrc/fused_norm.hip, round 6):
+    every entry against the host evaluation of include/mixdq_math.h; and the ranges it leaves to the arithmetic are the
+    trivial ones of the specification (silu(y) == y above, -0 below) -- not relied on by the kernel (values outside the
+    table take the arithmetic itself), but it is why the table ends where it ends."""
+    import ctypes
+    L = oracle.lib()
+    L.mixdq_oracle_siluf.restype, L.mixdq_oracle_siluf.argtypes = ctypes.c_float, [ctypes.c_float]
+    tab, n_pos, n_neg = C.silu_table(DEV)
+    tab = tab.cpu().numpy().view(np.uint16)
+    assert tab.size == n_pos + n_neg and n_pos == 0x4810 and n_neg == 0x4d20
+    bits = np.concatenate([np.arange(n_pos, dtype=np.uint16), (0x8000 | np.arange(n_neg, dtype=np.uint32)).astype(np.uint16)])
+    with np.errstate(all="ignore"):
+        want = np.array([np.float32(L.mixdq_oracle_siluf(float(a))) for a in bits.view(np.float16).astype(np.float32)],
+                        np.float32).astype(np.float16)
+    assert np.array_equal(tab, want.view(np.uint16))
+    rest_pos = np.arange(n_pos, 0x7c01, dtype=np.uint16)                       # up to +inf
+    rest_neg = (0x8000 | np.arange(n_neg, 0x7c00, dtype=np.uint32)).astype(np.uint16)
+    with np.errstate(all="ignore"):
+        sp = np.array([np.float32(L.mixdq_oracle_siluf(float(a))) for a in rest_pos.view(np.float16).astype(np.float32)],
+                      np.float32).astype(np.float16)
+        sn = np.array([np.float32(L.mixdq_oracle_siluf(float(a))) for a in rest_neg.view(np.float16).astype(np.float32)],
+                      np.float32).astype(np.float16)
+    assert np.array_equal(sp.view(np.uint16), rest_pos) and (sn.view(np.uint16) == 0x8000).all()
+
+
+def test_groupnorm_silu_table_variant_same_bits():
+    """MIXDQ_GN_SILU_TAB=1 (read once per process) sends every GroupNorm + SiLU launch with a finalize launch through
+    the table variant of the apply pass -- persistent blocks, SiLU by LDS lookup, values beyond the table by the
+    arithmetic -- instead of only the large ones: the GroupNorm parity cases (oracle, two sources, raw outputs, and the
+    case below with values far beyond the table) again in a child process with the switch on."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MIXDQ_GN_SILU_TAB="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_fused_gpu.py", "-m", "gpu", "-q", "-x",
+                        "-p", "no:cacheprovider", "-k",
+                        "test_groupnorm_silu_quantize or two_sources or raw_outputs or beyond_the_silu_table"],
+                       cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-3000:]
+
+
+@pytest.mark.parametrize("N,H,W,Cc", [(1, 32, 32, 640), (2, 64, 64, 320)])
+def test_groupnorm_silu_values_beyond_the_silu_table(C, oracle, N, H, W, Cc):
+    """gamma = +-12: normalised values reach +-40 -- above 8.06 SiLU rounds to the value itself, below -20.5 to -0, and
+    the table variant of the apply pass (the child-process test above; here whichever variant the launch takes) computes
+    those by the arithmetic: bit-exact vs the oracle, INT8 and FP16 outputs."""
+    x = dd.normal_f16(911, (N, H, W, Cc), 1.5)
+    gamma = (np.where(np.arange(Cc) % 2 == 0, 12.0, -12.0)).astype(np.float16)
+    beta = dd.normal_f16(912, (Cc,), 0.5)
+    s_inv, zp = float(np.float32(1) / np.float32(0.3)), -20.0
+    xd = t(x).permute(0, 3, 1, 2)
+    q, h = C.groupnorm_silu_quantize(xd, 32, t(gamma), t(beta), 1e-5, scal(s_inv), scal(zp), silu=True, want_f16=True)
+    q_ref, h_ref = oracle.groupnorm_silu_quantize(x, gamma, beta, 1e-5, 32, True, s_inv, zp, C.FLAGS & 1)
+    got_h = h.permute(0, 2, 3, 1).contiguous().cpu().numpy()
+    assert np.abs(h_ref.astype(np.float32)).max() > 25 and (h_ref.view(np.uint16) == 0x8000).any()
+    assert np.array_equal(got_h.view(np.uint16), h_ref.view(np.uint16))
+    assert np.array_equal(q.permute(0, 2, 3, 1).contiguous().cpu().numpy(), q_ref)
