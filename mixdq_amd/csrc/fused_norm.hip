@@ -618,6 +618,106 @@ __global__ __launch_bounds__(256) void geglu_quant_kernel(
   }
 }
 
+// The same pass with GELU by table (round 6; the stand-alone GEGLU launch of the module-swap path and of the layers
+// the fused graph does not fuse): f16(gelu(g)) for an FP16 gate is a function of 16 bits -- igemm's GEMM + GEGLU
+// epilogue has looked it up since round 3 (csrc/igemm_kernel.h: |g| < 16, both signs, 76 KB, built by the scalar
+// specification); this translation unit keeps its own copy of that table, built the same way, and 1024-thread blocks
+// (two per CU: 37 registers) copy it into LDS by LDS-DMA at entry and then stride over the tensor.  A gate outside the table, NaN or
+// +-inf takes the arithmetic (mixdq_geluf), decided per wave.  Bit-identical by construction.
+constexpr int kGeluMagFn = 0x4c00;                        // |g| < 16.0, as kGeluTabMag of csrc/igemm_kernel.h
+constexpr int kGeluTabBytesFn = 2 * kGeluMagFn * 2;
+__device__ uint16_t g_gelu_tab_fn[2 * kGeluMagFn];
+
+__global__ __launch_bounds__(256) void gelu_table_fn_init_kernel() {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 2 * kGeluMagFn) return;
+  __half_raw r;
+  r.x = (unsigned short)((i >= kGeluMagFn ? 0x8000 : 0) | (i % kGeluMagFn));
+  g_gelu_tab_fn[i] = __half_as_ushort(f32_to_f16_rn(mixdq_geluf(__half2float(__half(r)))));
+}
+
+inline int ensure_gelu_table_fn(hipStream_t stream) {      // (the logic of ensure_silu_table)
+  static bool done[64] = {};
+  static unsigned long long in_capture[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return MIXDQ_ERR_LAUNCH;
+  if (done[dev]) return MIXDQ_OK;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  unsigned long long cap_id = 0;
+  if (hipStreamGetCaptureInfo(stream, &cap, &cap_id) != hipSuccess) return MIXDQ_ERR_LAUNCH;
+  if (cap != hipStreamCaptureStatusNone && cap_id != 0 && in_capture[dev] == cap_id) return MIXDQ_OK;
+  gelu_table_fn_init_kernel<<<(2 * kGeluMagFn + 255) / 256, 256, 0, stream>>>();
+  if (hipGetLastError() != hipSuccess) return MIXDQ_ERR_LAUNCH;
+  if (cap == hipStreamCaptureStatusNone) {
+    if (hipStreamSynchronize(stream) != hipSuccess) return MIXDQ_ERR_LAUNCH;
+    done[dev] = true;
+  } else {
+    in_capture[dev] = cap_id;
+  }
+  return MIXDQ_OK;
+}
+
+template <bool UNFUSED>
+__global__ __launch_bounds__(1024) void geglu_quant_tab_kernel(
+    const __half* __restrict__ h, int64_t M, int D, const float* __restrict__ s_inv_p,
+    const float* __restrict__ zp_p, int8_t* __restrict__ out_q, __half* __restrict__ out_h) {
+  extern __shared__ __attribute__((aligned(16))) char gg_dyn[];
+  {
+    const int wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    for (int q = wave; q < kGeluTabBytesFn / 1024; q += 16)
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(g_gelu_tab_fn) + q * 1024 +
+                                                          ((int)threadIdx.x & 63) * 16),
+          (__attribute__((address_space(3))) void*)(gg_dyn + q * 1024), 16, 0, 0);
+  }
+  const int dch = D / 8;
+  const int64_t total = M * dch;
+  const bool want_q = out_q != nullptr;
+  using cf32 = const __attribute__((address_space(4))) float;
+  const float s_inv = want_q ? *(cf32*)s_inv_p : 0.f, zp = want_q ? *(cf32*)zp_p : 0.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const uint16_t* tab = reinterpret_cast<const uint16_t*>(gg_dyn);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / dch;
+    const int c = (int)(i - m * dch);
+    const Half8 xv = *reinterpret_cast<const Half8*>(h + m * 2 * D + 8 * c);
+    const Half8 gv = *reinterpret_cast<const Half8*>(h + m * 2 * D + D + 8 * c);
+    uint32_t ge[8];
+    bool far = false;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const uint32_t gb = (j & 1) ? (gv.w[j >> 1] >> 16) : (gv.w[j >> 1] & 0xffffu);
+      const uint32_t mag = gb & 0x7fffu;
+      const bool in = mag < (uint32_t)kGeluMagFn;
+      far |= !in;
+      ge[j] = tab[in ? (gb >> 15) * kGeluMagFn + mag : 0u];            // f16(gelu(g)), from the table
+    }
+    if (__builtin_amdgcn_ballot_w64(far) != 0) {                       // wave-uniform, rare: beyond the table
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t gb = (j & 1) ? (gv.w[j >> 1] >> 16) : (gv.w[j >> 1] & 0xffffu);
+        if ((gb & 0x7fffu) >= (uint32_t)kGeluMagFn)
+          ge[j] = __half_as_ushort(f32_to_f16_rn(mixdq_geluf(half_at(gv, j))));   // the specification itself
+      }
+    }
+    Half8 oh;
+    oh.w[0] = oh.w[1] = oh.w[2] = oh.w[3] = 0;
+    float y8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      __half_raw r;
+      r.x = (unsigned short)ge[j];
+      const float y = round_f16(__fmul_rn(half_at(xv, j), __half2float(__half(r))));
+      put_half(oh, j, y);
+      y8[j] = y;
+    }
+    if (want_q) *reinterpret_cast<uint2*>(out_q + m * D + 8 * c) = quantize_pack8<UNFUSED>(y8, s_inv, zp);
+    if (out_h) *reinterpret_cast<Half8*>(out_h + m * D + 8 * c) = oh;
+  }
+}
+
 }  // namespace
 }  // namespace mixdq
 
@@ -873,6 +973,26 @@ extern "C" int mixdq_geglu_quantize(const void* h, int64_t M, int D, const float
   int64_t blocks = (M * (D / 8) + 255) / 256;
   if (blocks > kNumCU * 8) blocks = kNumCU * 8;
   hipStream_t stream = (hipStream_t)stream_;
+  // GELU by table from 2 Mi outputs on (MIXDQ_GEGLU_TAB=0 never / 1 always: tests and A/B runs): (1024, 5120), the
+  // batch-1 ff layer of the module-swap path, is 5 Mi
+  static const int tab_mode = [] { const char* e = getenv("MIXDQ_GEGLU_TAB"); return e ? atoi(e) : -1; }();
+  if (tab_mode != 0 && (tab_mode == 1 || M * (int64_t)D >= ((int64_t)2 << 20))) {
+    if (const int st = ensure_gelu_table_fn(stream)) return st;
+    static bool seen_g[2][64] = {};
+    const bool unf = flags & MIXDQ_FLAG_UNFUSED;
+    const void* kern = unf ? reinterpret_cast<const void*>(&geglu_quant_tab_kernel<true>)
+                           : reinterpret_cast<const void*>(&geglu_quant_tab_kernel<false>);
+    if (const int st = lds_opt_in(kern, kGeluTabBytesFn, seen_g[unf ? 1 : 0])) return st;
+    int64_t tb = (M * (D / 8) + 1023) / 1024;
+    if (tb > 2 * kNumCU) tb = 2 * kNumCU;
+    if (unf)
+      geglu_quant_tab_kernel<true><<<(int)tb, 1024, kGeluTabBytesFn, stream>>>(
+          (const __half*)h, M, D, scale_inv, zero_point, out_q_or_null, (__half*)out_f16_or_null);
+    else
+      geglu_quant_tab_kernel<false><<<(int)tb, 1024, kGeluTabBytesFn, stream>>>(
+          (const __half*)h, M, D, scale_inv, zero_point, out_q_or_null, (__half*)out_f16_or_null);
+    return launch_status();
+  }
   if (flags & MIXDQ_FLAG_UNFUSED)
     geglu_quant_kernel<true><<<(int)blocks, 256, 0, stream>>>(
         (const __half*)h, M, D, scale_inv, zero_point, out_q_or_null, (__half*)out_f16_or_null);

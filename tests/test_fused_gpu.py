@@ -679,3 +679,23 @@ def test_groupnorm_silu_values_beyond_the_silu_table(C, oracle, N, H, W, Cc):
     assert np.abs(h_ref.astype(np.float32)).max() > 25 and (h_ref.view(np.uint16) == 0x8000).any()
     assert np.array_equal(got_h.view(np.uint16), h_ref.view(np.uint16))
     assert np.array_equal(q.permute(0, 2, 3, 1).contiguous().cpu().numpy(), q_ref)
+
+
+def test_geglu_table_variant_same_bits():
+    """MIXDQ_GEGLU_TAB=1 (read once per process) sends every stand-alone GEGLU + quantize launch through the table
+    variant (csrc/fused_norm.hip geglu_quant_tab_kernel: GELU looked up in LDS, gates beyond +-16 / NaN / inf by the
+    arithmetic) instead of only the launches of 2 Mi outputs and more: the GEGLU parity cases -- the oracle, the
+    specification on 4 000 gates, ALL 65 536 FP16 gates -- again in a child process with the switch on, and once more
+    with it off (the large cases then take the arithmetic kernel the small ones always take)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for flag in ("1", "0"):
+        r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_fused_gpu.py", "-m", "gpu", "-q", "-x",
+                            "-p", "no:cacheprovider", "-k",
+                            "test_geglu_quantize or shared_math_spec or every_fp16_gate"],
+                           cwd=root, env=dict(os.environ, MIXDQ_GEGLU_TAB=flag), stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-3000:]
+        assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-3000:]
