@@ -561,6 +561,7 @@ CROSS_FUSE_MAX_ROWS = int(__import__("os").environ.get("MIXDQ_CROSS_FUSE_MAX_ROW
 LN_CHAIN = __import__("os").environ.get("MIXDQ_LN_CHAIN", "0") == "1"
 # weight prefetch from the self-attention launch: on for launches of up to this many rows
 PREFETCH = __import__("os").environ.get("MIXDQ_PREFETCH", "1") != "0"
+WEIGHT_ARENA = __import__("os").environ.get("MIXDQ_WEIGHT_ARENA", "0") == "1"      # arena.py (prepare_fused_)
 PREFETCH_MAX_ROWS = int(__import__("os").environ.get("MIXDQ_PREFETCH_MAX_ROWS", "0"))      # 0: no limit (see _build_prefetch_plan)
 PREFETCH_MB_PER_LAUNCH = float(__import__("os").environ.get("MIXDQ_PREFETCH_MB", "48"))   # per 1024 x 1024 scores
 PREFETCH_MAX_LEAD = int(__import__("os").environ.get("MIXDQ_PREFETCH_LEAD", "4"))         # launches a weight may be read ahead
@@ -1226,6 +1227,11 @@ class SDXLUNet(nn.Module):
             from mixdq_amd import _C
             _C.gelu_table(dev)
             _C.silu_table(dev)              # ... and the SiLU table of the large GroupNorm apply launches (fused_norm.hip)
+            if WEIGHT_ARENA:
+                # every static tensor of the converted network in ONE allocation, in module order (arena.py)
+                from mixdq_amd.arena import pack_static_
+                self.__dict__["_arena"] = pack_static_(self, dev)
+                self.__dict__.pop("_pf_plans", None)
         return self
 
     def set_fused(self, enabled: bool = True):

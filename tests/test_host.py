@@ -717,3 +717,39 @@ def test_swap_glue_modules_by_type_keeps_names_and_state_and_undoes():
     n2 = swap_glue_modules(unet, attention=False)
     assert n2["attention"] == 0 and n2["groupnorm"] == n["groupnorm"]
     assert not any(type(m).__name__ == "HipAttention" for m in unet.modules())
+
+
+def test_pack_static_moves_every_tensor_into_one_allocation_and_keeps_the_network():
+    """mixdq_amd/arena.py: same tensor objects, names, values, aliasing (row packs) -- one storage."""
+    import bench
+    from mixdq_amd.arena import ALIGN, pack_static_
+    from mixdq_amd.quantize_sdxl import example_inputs
+    from mixdq_amd.unet import SDXLUNet, init_synthetic_weights
+    unet = init_synthetic_weights(SDXLUNet(bench.TINY_CFG)).eval()
+    inputs = example_inputs(1, 8, "cpu", seed=5)
+    inputs = {k: (v.float() if torch.is_tensor(v) else {a: b.float() for a, b in v.items()}) for k, v in inputs.items()}
+    lin = next(m for m in unet.modules() if isinstance(m, nn.Linear))
+    cat = torch.arange(24, dtype=torch.float32)
+    lin.register_buffer("lo", cat[:8])                       # two buffers and a row pack on one storage
+    lin.register_buffer("hi", cat[8:].view(2, 8).t())
+    lin.__dict__["_qkv"] = dict(layers=(), names=(), w=cat)
+    with torch.no_grad():
+        want = unet(**inputs)[0]
+    state = {k: v.clone() for k, v in unet.state_dict().items()}
+    ids = {k: id(v) for k, v in list(unet.named_parameters()) + list(unet.named_buffers())}
+    r = pack_static_(unet)
+    tensors = list(unet.parameters()) + list(unet.buffers()) + [cat]
+    assert r["tensors"] == len(tensors) and r["storages"] == len(tensors) - 2
+    assert len({t.untyped_storage().data_ptr() for t in tensors}) == 1                # one allocation
+    assert r["bytes"] == tensors[0].untyped_storage().nbytes() and r["bytes"] % ALIGN == 0
+    assert lin.lo.data_ptr() == cat.data_ptr() and lin.hi.data_ptr() == cat.data_ptr() + 32
+    assert lin.hi.stride() == (1, 8) and torch.equal(cat, torch.arange(24, dtype=torch.float32))
+    assert {k: id(v) for k, v in list(unet.named_parameters()) + list(unet.named_buffers())} == ids
+    assert all(isinstance(p, nn.Parameter) for p in unet.parameters())
+    for k, v in unet.state_dict().items():
+        assert torch.equal(v, state[k]), k
+    spans = sorted((t.data_ptr(), t.untyped_storage().data_ptr()) for t in tensors)
+    assert all((a - base) % 4 == 0 for a, base in spans)
+    with torch.no_grad():
+        assert torch.equal(unet(**inputs)[0], want)
+    assert pack_static_(nn.Identity()) == dict(bytes=0, storages=0, tensors=0)
