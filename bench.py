@@ -797,8 +797,12 @@ def main():
         #     mixdq_attention_f16 as well (what swap_glue=True does by default)
         from mixdq_amd.nn.glue import swap_glue_modules, unswap_glue_modules
         swapped = {}
-        for att, key in ((False, "dropin_glue_torch_sdpa"), (True, "dropin_glue")):
-            for k_, v_ in swap_glue_modules(unet, attention=att).items():
+        #     -- both with every layer still running its own quantize launch (operands=False) -- and last as
+        #     swap_glue=True does it by default: the producers' launches also write the INT8 operand of the quantized
+        #     layers behind them (nn/glue.py OPERAND_PAIRS), whose quantize launches disappear
+        for att, ops, key in ((False, False, "dropin_glue_torch_sdpa"), (True, False, "dropin_glue_own_quantize"),
+                              (True, True, "dropin_glue")):
+            for k_, v_ in swap_glue_modules(unet, attention=att, operands=ops).items():
                 swapped[k_] = swapped.get(k_, 0) + v_
             with torch.no_grad():
                 eager_forward(**inputs)
@@ -811,7 +815,7 @@ def main():
             dropin[key + "_kernels_per_step"] = n_k
         dropin["dropin_glue_swapped_modules"] = swapped
         dropin["dropin_glue_attention"] = ("dropin_unfused / dropin_glue_torch_sdpa: torch F.scaled_dot_product_attention "
-                                           "(its AOTriton kernel is also called attn_fwd); dropin_glue and the headline: "
+                                           "(its AOTriton kernel is also called attn_fwd); dropin_glue_own_quantize, dropin_glue and the headline: "
                                            "this repo's mixdq_attention_f16 (csrc/attention.hip)")
         unswap_glue_modules(unet)
         unet.set_fused(True)
@@ -943,6 +947,7 @@ def main():
             out["speedup_vs_fp16_dropin"] = fp16["ms_per_step"] / dropin["dropin_unfused_ms_per_step"]
             out["speedup_vs_fp16_dropin_glue"] = fp16["ms_per_step"] / dropin["dropin_glue_ms_per_step"]
             out["speedup_vs_fp16_dropin_glue_torch_sdpa"] = fp16["ms_per_step"] / dropin["dropin_glue_torch_sdpa_ms_per_step"]
+            out["speedup_vs_fp16_dropin_glue_own_quantize"] = fp16["ms_per_step"] / dropin["dropin_glue_own_quantize_ms_per_step"]
     if ln_in_gemm:
         out["ln_in_gemm"] = ln_in_gemm
     if world == 1:

@@ -21,6 +21,7 @@ import torch.nn.functional as F
 from torch.ao.quantization import QConfig
 
 from mixdq_amd import _C
+from mixdq_amd.nn.glue import tagged_operand
 from mixdq_amd.nn.utils import create_qparams_from_dtype, pack_w4, unpack_w4
 from mixdq_amd.op.quant import quantize_per_tensor_vectorized
 
@@ -324,6 +325,9 @@ class QuantizedConv2d(nn.Module):
         if x.dtype != torch.float16:
             return self.forward_fallback(x)
         if self.split == 0:
+            x_int = tagged_operand(x, self)       # (swap_glue: written by the producer of x -- nn/glue.py)
+            if x_int is not None:
+                return self._conv(x_int, "", self.bias)
             return self._quant_conv(x, "", self.bias)
         # bias is applied once, in the first half (nn/Conv2d.py:341-343); the reference's half add of
         # the two fp16 outputs rides in the second launch's epilogue (same arithmetic: each output

@@ -20,6 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 from torch.ao.quantization import QConfig
 
+from mixdq_amd.nn.glue import tagged_operand
 from mixdq_amd.nn.utils import create_qparams_from_dtype, pack_w4, unpack_w4
 from mixdq_amd.op.quant import quantize_per_tensor_vectorized
 from mixdq_amd.op.qlinear import qlinear
@@ -227,6 +228,10 @@ class QuantizedLinear(nn.Module):
         from mixdq_amd._C import qlinear_f16in_wanted
         N, K = self.out_features, self.in_features
         if not getattr(self, "bos", False):
+            # (swap_glue: the producer of x already wrote quantize(x) for THIS layer's quantizer -- nn/glue.py)
+            x_int = tagged_operand(x, self)
+            if x_int is not None:
+                return self._gemm(x_int)
             # the reference's two launches (nn/Linear.py:162-176) as one wherever the quantizing GEMM
             # takes the shape; otherwise literally: quantize, then GEMM
             if qlinear_f16in_wanted(x, N, K, w4=self.w_packed4):

@@ -15,6 +15,15 @@ state_dict keys and the call sites are those of the stock network:
     the FP16 attention core           -> mixdq_attention_f16  (this repo's Attention.attend, or a diffusers
                                          attention processor: HipAttnProcessor)          csrc/attention.hip
 
+Operand hand-off (`operands=True`, the default): a swapped producer whose parent class is known to pass its output
+straight to quantized layers (OPERAND_PAIRS: LayerNorm -> to_q / to_k / to_v / the GEGLU projection, GroupNorm + SiLU ->
+the ResNet conv, GEGLU -> ff.net.2; the attention core -> to_out.0 directly) also writes, in the SAME launch, the INT8
+operand those layers' own quantize launch would compute from its FP16 output -- quantize() of the FP16 value, the same
+bits -- and attaches it to the FP16 tensor it returns.  QuantizedLinear / QuantizedConv2d look for an attachment made
+with THEIR quantizer tensors on THEIR input tensor object (`tagged_operand`: identity of the tensor, of the two
+quantizer buffers, and the tensor's in-place version) and skip the quantize launch; anything else -- another tensor, a
+modified one, a re-quantized layer -- finds nothing and quantizes as before.  The FP16 tensor is always written too.
+
 The swap changes `module.__class__` to a subclass of the module's own class: parameters, buffers, hooks, names and
 `isinstance` checks are untouched, `unswap_glue_modules` restores the stock classes.  A swapped module falls back to
 its stock forward (PyTorch's op: still the GPU, never a CPU path) for inputs the kernel does not take (FP32, NCHW
@@ -28,10 +37,46 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 _ACT_TAG = "_mixdq_silu_applied"
+_OPS_TAG = "_mixdq_operands"        # on an FP16 tensor: (its _version, [(scale_inv, zero_point, int8 tensor), ...])
+_CONSUMERS = "_mixdq_consumers"     # in a swapped producer's __dict__: the layers its parent hands its output to
 
 
 def _f16_cuda(x) -> bool:
     return torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float16
+
+
+def _takes_operand(m) -> bool:
+    """A W8A8 / W4A8 layer that quantizes its whole input with ONE per-tensor quantizer (no BOS carve-out, no
+    split input)."""
+    return bool(getattr(m, "valid_for_acceleration", False) and not getattr(m, "bos", False)
+                and not getattr(m, "split", 0) and hasattr(m, "act_scales_inv"))
+
+
+def _consumers(mod, width=None):
+    out = [c for c in mod.__dict__.get(_CONSUMERS, ()) if _takes_operand(c)]
+    if width is not None:
+        out = [c for c in out if getattr(c, "in_features", getattr(c, "in_channels", None)) == width]
+    return out
+
+
+def _attach(y, consumers, ints):
+    """`ints[i]`: quantize(y) with consumers[i]'s quantizer (or None)."""
+    ops = [(c.act_scales_inv, c.act_zero_points, q) for c, q in zip(consumers, ints) if q is not None]
+    if ops:
+        setattr(y, _OPS_TAG, (y._version, ops))
+    return y
+
+
+def tagged_operand(x, layer):
+    """The INT8 operand a swapped producer attached to `x` for `layer`'s activation quantizer, or None."""
+    tag = getattr(x, _OPS_TAG, None)
+    if tag is None or tag[0] != x._version:
+        return None
+    s, z = layer.act_scales_inv, layer.act_zero_points
+    for ts, tz, q in tag[1]:
+        if ts is s and tz is z and q.shape == x.shape and q.device == x.device:
+            return q
+    return None
 
 
 class HipGroupNorm(nn.GroupNorm):
@@ -45,11 +90,14 @@ class HipGroupNorm(nn.GroupNorm):
         if (_f16_cuda(x) and x.dim() == 4 and self.affine and self.weight.dtype == torch.float16
                 and x.is_contiguous(memory_format=torch.channels_last)
                 and _C.groupnorm_supported(x.shape[0], x.shape[2] * x.shape[3], x.shape[1], self.num_groups)):
-            y = _C.groupnorm_silu_quantize(x, self.num_groups, self.weight, self.bias, self.eps,
-                                           silu=self.fuse_silu, want_f16=True)[1]
+            # (the consumer reads silu(norm(x)): its operand can ride along only where the SiLU does)
+            cons = _consumers(self, x.shape[1])[:1] if self.fuse_silu else []
+            qp = (cons[0].act_scales_inv, cons[0].act_zero_points) if cons else (None, None)
+            q, y = _C.groupnorm_silu_quantize(x, self.num_groups, self.weight, self.bias, self.eps, *qp,
+                                              silu=self.fuse_silu, want_f16=True)[:2]
             if self.fuse_silu:
                 setattr(y, _ACT_TAG, True)
-            return y
+            return _attach(y, cons, [q])
         return super().forward(x)
 
 
@@ -69,7 +117,21 @@ class HipLayerNorm(nn.LayerNorm):
         if (_f16_cuda(x) and x.is_contiguous() and len(self.normalized_shape) == 1 and self.elementwise_affine
                 and self.bias is not None and self.weight.dtype == torch.float16
                 and C == self.normalized_shape[0] and C % 16 == 0 and 0 < C <= 2048):
-            return _C.layernorm_quantize(x, self.weight, self.bias, self.eps, [], want_f16=True)[1]
+            cons = _consumers(self, C)
+            if not cons:
+                return _C.layernorm_quantize(x, self.weight, self.bias, self.eps, [], want_f16=True)[1]
+            # one INT8 tensor per DISTINCT quantizer among the consumers (to_q / to_k / to_v are calibrated on the
+            # same tensor: usually one); at most three ride in the launch
+            from mixdq_amd.unet import _quantizer_groups
+            ids = _quantizer_groups(self.__dict__.setdefault("_mixdq_memo", {}), "glue", cons)
+            first = {}
+            for c, i in zip(cons, ids):
+                first.setdefault(i, c)
+            order = sorted(first)[:3]
+            outs, y = _C.layernorm_quantize(x, self.weight, self.bias, self.eps,
+                                            [(first[i].act_scales_inv, first[i].act_zero_points) for i in order],
+                                            want_f16=True)
+            return _attach(y, cons, [outs[order.index(i)] if i in order else None for i in ids])
         return super().forward(x)
 
 
@@ -82,13 +144,18 @@ class _HipGEGLU:
         from mixdq_amd import _C
         h = self.proj(x)
         if _f16_cuda(h) and h.is_contiguous() and h.shape[-1] % 16 == 0:
-            return _C.geglu_quantize(h, want_f16=True)[1]
+            cons = _consumers(self, h.shape[-1] // 2)[:1]
+            qp = (cons[0].act_scales_inv, cons[0].act_zero_points) if cons else (None, None)
+            q, y = _C.geglu_quantize(h, *qp, want_f16=True)
+            return _attach(y, cons, [q])
         v, g = h.chunk(2, dim=-1)
         return v * F.gelu(g)
 
 
-def _attention_core(q, k, v, heads):
-    """FP16 attention on [B, T, C] tensors (heads of 64 columns), or None where the kernel does not take them."""
+def _attention_core(q, k, v, heads, out_layer=None):
+    """FP16 attention on [B, T, C] tensors (heads of 64 columns), or None where the kernel does not take them.
+    `out_layer` (to_out.0): where it is a quantized layer that takes an operand, the launch writes that layer's
+    INT8 operand instead of the FP16 tensor and the return value is the layer's OUTPUT."""
     from mixdq_amd import _C
     C = q.shape[-1]
     if C != heads * 64:
@@ -97,15 +164,29 @@ def _attention_core(q, k, v, heads):
         if not (_f16_cuda(t) and t.dim() == 3 and t.stride(-1) == 1 and t.stride(0) % 8 == 0
                 and t.stride(1) % 8 == 0 and t.data_ptr() % 16 == 0):
             return None
+    if out_layer is not None:
+        if _takes_operand(out_layer) and out_layer.in_features == C:
+            return out_layer._gemm(_C.attention_f16(q, k, v, heads, out_layer.act_scales_inv,
+                                                    out_layer.act_zero_points))
+        return out_layer(_C.attention_f16(q, k, v, heads))
     return _C.attention_f16(q, k, v, heads)
 
 
 class _HipAttend:
     """Mix-in for mixdq_amd.unet.Attention: `attend` (the FP16 core between the projections) on the HIP kernel."""
+    hand_off = False            # (swap_glue_modules(operands=True): to_out.0's operand from the attention launch)
 
     def attend(self, q, k, v):
         o = _attention_core(q, k, v, self.heads)
         return o if o is not None else super().attend(q, k, v)
+
+    def forward(self, x, context=None):
+        if not self.hand_off:
+            return super().forward(x, context)
+        context = x if context is None else context
+        q, k, v = self.to_q(x), self.to_k(context), self.to_v(context)
+        y = _attention_core(q, k, v, self.heads, out_layer=self.to_out[0])
+        return y if y is not None else self.to_out[0](super().attend(q, k, v))
 
 
 class HipAttnProcessor:
@@ -115,8 +196,9 @@ class HipAttnProcessor:
     Covers what the SDXL UNet uses: no attention mask, no group / spatial norm inside the attention, no added
     key / value projections, residual_connection False -- anything else goes to the processor it replaced."""
 
-    def __init__(self, fallback=None):
+    def __init__(self, fallback=None, hand_off=False):
         self.fallback = fallback
+        self.hand_off = hand_off    # to_out.0's INT8 operand written by the attention launch
 
     def __call__(self, attn, hidden_states, encoder_hidden_states=None, attention_mask=None, temb=None,
                  *args, **kwargs):
@@ -130,9 +212,10 @@ class HipAttnProcessor:
             if encoder_hidden_states is not None and getattr(attn, "norm_cross", False):
                 ctx = attn.norm_encoder_hidden_states(ctx)
             q, k, v = attn.to_q(hidden_states), attn.to_k(ctx), attn.to_v(ctx)
-            o = _attention_core(q, k, v, attn.heads)
+            o = _attention_core(q, k, v, attn.heads, out_layer=attn.to_out[0] if self.hand_off else None)
             if o is not None:
-                o = attn.to_out[0](o)
+                if not self.hand_off:
+                    o = attn.to_out[0](o)
                 return attn.to_out[1](o) if len(attn.to_out) > 1 else o
         if self.fallback is None:
             raise RuntimeError("HipAttnProcessor: unsupported attention call and no fallback processor")
@@ -162,11 +245,36 @@ SILU_PAIRS = {"ResnetBlock2D": (("norm1", "norm2"), "nonlinearity"),
               "SDXLUNet": (("conv_norm_out",), "conv_act")}
 
 
-def swap_glue_modules(unet: nn.Module, attention: bool = True, silu_pairs=None) -> dict:
+# Parent classes (by name) whose forward is KNOWN to hand the output of the producer at the first path to the layers
+# at the other paths, as the same tensor object (through at most nn.SiLU / nn.Dropout / nn.Identity modules, which
+# pass an eval-mode tensor through): diffusers' and this repo's BasicTransformerBlock, ResnetBlock2D and FeedForward.
+# A wrong entry costs time, never bits: a consumer only ever uses an operand attached to ITS input tensor for ITS
+# quantizer (`tagged_operand`).
+OPERAND_PAIRS = {
+    "BasicTransformerBlock": (("norm1", ("attn1.to_q", "attn1.to_k", "attn1.to_v")),
+                              ("norm2", ("attn2.to_q",)),
+                              ("norm3", ("ff.net.0.proj",))),
+    "ResnetBlock2D": (("norm1", ("conv1",)), ("norm2", ("conv2",))),
+    "FeedForward": (("net.0", ("net.2",)),),
+}
+
+
+def _submodule(root, path):
+    for part in path.split("."):
+        root = getattr(root, "_modules", {}).get(part)
+        if root is None:
+            return None
+    return root
+
+
+def swap_glue_modules(unet: nn.Module, attention: bool = True, silu_pairs=None, operands: bool = True,
+                      operand_pairs=None) -> dict:
     """Swap the stock glue modules of `unet` in place (see the top of this file); returns how many of each kind
     were swapped.  Idempotent.  `attention=False` leaves the attention core to PyTorch's SDPA.  `silu_pairs`:
-    {parent class name: ((GroupNorm attribute names), SiLU attribute name)} in place of SILU_PAIRS."""
-    n = dict(groupnorm=0, silu_folded=0, layernorm=0, geglu=0, attention=0)
+    {parent class name: ((GroupNorm attribute names), SiLU attribute name)} in place of SILU_PAIRS.
+    `operands=False`: no INT8 operand hand-off between swapped producers and the quantized layers behind them
+    (every layer runs its own quantize launch, as in the reference); `operand_pairs` in place of OPERAND_PAIRS."""
+    n = dict(groupnorm=0, silu_folded=0, layernorm=0, geglu=0, attention=0, operand_links=0, attention_handoff=0)
     pairs = SILU_PAIRS if silu_pairs is None else silu_pairs
     for parent in unet.modules():
         kids = parent._modules
@@ -200,12 +308,33 @@ def swap_glue_modules(unet: nn.Module, attention: bool = True, silu_pairs=None) 
                 and not isinstance(getattr(mod, "processor", None), HipAttnProcessor):
             mod.set_processor(HipAttnProcessor(fallback=getattr(mod, "processor", None)))
             n["attention"] += 1
+    if not operands:
+        return n
+    opairs = OPERAND_PAIRS if operand_pairs is None else operand_pairs
+    for parent in unet.modules():
+        for prod_path, cons_paths in opairs.get(type(parent).__name__, ()):
+            prod = _submodule(parent, prod_path)
+            if not isinstance(prod, (HipGroupNorm, HipLayerNorm, _HipGEGLU)) or _CONSUMERS in prod.__dict__:
+                continue
+            cons = tuple(c for c in (_submodule(parent, p) for p in cons_paths) if c is not None)
+            if cons:
+                prod.__dict__[_CONSUMERS] = cons       # (not registered as sub-modules: plain references)
+                n["operand_links"] += len(cons)
+    for mod in unet.modules():
+        if isinstance(mod, _HipAttend) and not mod.__dict__.get("hand_off"):
+            mod.__dict__["hand_off"] = True
+            n["attention_handoff"] += 1
+        elif isinstance(getattr(mod, "processor", None), HipAttnProcessor) and not mod.processor.hand_off:
+            mod.processor.hand_off = True
+            n["attention_handoff"] += 1
     return n
 
 
 def unswap_glue_modules(unet: nn.Module) -> None:
     """Restore the stock classes (and attention processors) swap_glue_modules replaced."""
     for mod in unet.modules():
+        mod.__dict__.pop(_CONSUMERS, None)
+        mod.__dict__.pop("hand_off", None)
         if type(mod) is HipGroupNorm:
             mod.__dict__.pop("fuse_silu", None)
             mod.__class__ = nn.GroupNorm

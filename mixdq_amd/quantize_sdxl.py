@@ -97,14 +97,17 @@ def convert_to_quantized(unet, ckpt):
             inplace=True, ckpt=ckpt)
 
 
-def quantize_unet(unet, args, ckpt, bos, bos_dict, w4_kernel=False, swap_glue=False, swap_attention=None):
+def quantize_unet(unet, args, ckpt, bos, bos_dict, w4_kernel=False, swap_glue=False, swap_attention=None,
+                  swap_operands=True):
     """The reference's call (quantize_sdxl.py:154-156) plus three options it does not have:
     `w4_kernel=True`: 4-/2-bit weight layers run the packed-W4 INT8 kernels instead of falling back to FP16
     (mixdq_amd.nn.QuantizedLinear.w4_kernel);
     `swap_glue=True`: the stock glue modules BETWEEN the quantized layers -- nn.GroupNorm (+ the nn.SiLU behind
     it), nn.LayerNorm, GEGLU -- are swapped by type for this repo's FP16-output kernels, and (`swap_attention`,
     default: as `swap_glue`) the FP16 attention core for mixdq_attention_f16: same graph, same names, same
-    state_dict, one launch per module (mixdq_amd/nn/glue.py; `unswap_glue_modules` undoes it)."""
+    state_dict, one launch per module (mixdq_amd/nn/glue.py; `unswap_glue_modules` undoes it).  `swap_operands`
+    (with swap_glue): a swapped producer's launch also writes the INT8 operand of the quantized layers its parent
+    hands its output to, and those layers skip their quantize launch -- the same bits, ~600 launches fewer."""
     register_qconfig_from_input_files(unet, args, bos=bos, bos_dict=bos_dict)
     if w4_kernel:
         for mod in unet.modules():
@@ -114,7 +117,8 @@ def quantize_unet(unet, args, ckpt, bos, bos_dict, w4_kernel=False, swap_glue=Fa
     if swap_glue or swap_attention:
         from mixdq_amd.nn.glue import swap_glue_modules
         if swap_glue:
-            swap_glue_modules(unet, attention=swap_glue if swap_attention is None else bool(swap_attention))
+            swap_glue_modules(unet, attention=swap_glue if swap_attention is None else bool(swap_attention),
+                              operands=bool(swap_operands))
         else:
             raise ValueError("swap_attention=True needs swap_glue=True")
 

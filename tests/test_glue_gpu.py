@@ -96,7 +96,7 @@ def test_groupnorm_without_a_silu_behind_it_is_not_folded(C):
             super().__init__()
             self.norm = nn.GroupNorm(32, 640, eps=1e-6)
     m = P().half().to(DEV)
-    assert swap_glue_modules(m) == dict(groupnorm=1, silu_folded=0, layernorm=0, geglu=0, attention=0)
+    assert swap_glue_modules(m) == dict(groupnorm=1, silu_folded=0, layernorm=0, geglu=0, attention=0, operand_links=0, attention_handoff=0)
     x = t(dd.normal_f16(55, (2, 8, 8, 640), 1.5)).permute(0, 3, 1, 2)
     with torch.no_grad():
         y = m.norm(x)
@@ -212,11 +212,22 @@ def test_swapped_unet_is_the_chain_of_its_kernels(C):
     with torch.no_grad():
         dropin = unet(**inputs)[0].clone()
     from mixdq_amd.nn.glue import swap_glue_modules
-    n = swap_glue_modules(unet)
+    n = swap_glue_modules(unet, operands=False)        # every layer still runs its own quantize launch
     assert n["groupnorm"] == 46 and n["silu_folded"] == 35 and n["layernorm"] > 0 and n["geglu"] > 0 and n["attention"] > 0
+    assert n["operand_links"] == 0 and n["attention_handoff"] == 0
+    with torch.no_grad():
+        no_handoff = unet(**inputs)[0].clone()
+        k_no = bench.count_kernels(lambda: unet(**inputs), torch.device(DEV))
+    n = swap_glue_modules(unet)                        # ... and with the producers' INT8 operands handed on
+    assert n["operand_links"] > 0 and n["attention_handoff"] > 0 and n["groupnorm"] == 0
     assert list(unet.state_dict()) == keys
     with torch.no_grad():
         glue = unet(**inputs)[0].clone()
+        k_yes = bench.count_kernels(lambda: unet(**inputs), torch.device(DEV))
+    assert torch.equal(glue.view(torch.int16), no_handoff.view(torch.int16))     # the same bits, fewer launches:
+    n_tb = sum(1 for m in unet.modules() if type(m).__name__ == "BasicTransformerBlock")
+    assert k_no - k_yes >= 6 * n_tb, (k_no, k_yes)     # per block at least q|k|v + to_q + proj + net.2 quantize launches
+    with torch.no_grad():
         unet.set_fused(True)
         with defused():
             ref = unet(**inputs)[0].clone()
@@ -234,3 +245,66 @@ def test_swapped_unet_is_the_chain_of_its_kernels(C):
     unswap_glue_modules(unet)
     with torch.no_grad():
         assert torch.equal(unet(**inputs)[0].view(torch.int16), dropin.view(torch.int16))
+
+
+
+class _Lin(nn.Module):
+    """What an operand hand-off looks at in a consumer: its two quantizer buffers, its width, that it is accelerated."""
+    valid_for_acceleration = True
+
+    def __init__(self, k, scale, zp):
+        super().__init__()
+        self.in_features = k
+        self.register_buffer("act_scales_inv", torch.tensor(1.0 / scale))
+        self.register_buffer("act_zero_points", torch.tensor(float(zp)))
+
+
+class BasicTransformerBlock(nn.Module):          # (the class NAME is what OPERAND_PAIRS keys on)
+    def __init__(self, c):
+        super().__init__()
+        self.norm1, self.norm2, self.norm3 = nn.LayerNorm(c), nn.LayerNorm(c), nn.LayerNorm(c)
+        self.attn1 = nn.Module()
+        self.attn1.to_q, self.attn1.to_k, self.attn1.to_v = _Lin(c, 0.05, 3), _Lin(c, 0.05, 3), _Lin(c, 0.031, -7)
+        self.attn2 = nn.Module()
+        self.attn2.to_q = _Lin(c, 0.04, 0)
+
+
+def test_operand_hand_off_is_quantize_of_the_fp16_output_and_only_for_that_tensor(C):
+    """A swapped LayerNorm with known consumers: one INT8 tensor per distinct quantizer, each == the quantize launch
+    applied to the FP16 tensor it returns; found only on THAT tensor object, unmodified, for a linked quantizer."""
+    from mixdq_amd.nn.glue import swap_glue_modules, tagged_operand, unswap_glue_modules
+    c = 640
+    blk = BasicTransformerBlock(c).half().to(DEV)
+    for m in blk.modules():
+        if isinstance(m, _Lin):
+            m.float()
+    with torch.no_grad():
+        blk.norm1.weight.copy_(t((dd.normal_f16(71, (c,), 0.3).astype(np.float32) + 1).astype(np.float16)))
+        blk.norm1.bias.copy_(t(dd.normal_f16(72, (c,), 0.2)))
+    x = t(dd.normal_f16(73, (2, 77, c), 1.5))
+    n = swap_glue_modules(blk)
+    assert n["layernorm"] == 3 and n["operand_links"] == 4           # (norm3 -> ff.net.0.proj: no such module here)
+    y = blk.norm1(x)
+    a = blk.attn1
+    qq, qk, qv = (tagged_operand(y, m) for m in (a.to_q, a.to_k, a.to_v))
+    assert qq is not None and qq is qk and qv is not None and qv is not qq       # equal quantizers share one tensor
+    for m, q in ((a.to_q, qq), (a.to_v, qv)):
+        want = C.quantize_per_tensor_to_int8(y, m.act_scales_inv, m.act_zero_points)
+        assert q.dtype == torch.int8 and torch.equal(q, want)
+    assert torch.equal(y, C.layernorm_quantize(x, blk.norm1.weight, blk.norm1.bias, blk.norm1.eps, [], want_f16=True)[1])
+    assert tagged_operand(y, blk.attn2.to_q) is None                  # another producer's consumer
+    assert tagged_operand(y.clone(), a.to_q) is None and tagged_operand(y[:1], a.to_q) is None
+    assert tagged_operand(y.view(-1, c), a.to_q) is None              # a view is another tensor object
+    other = _Lin(c, 0.05, 3).to(DEV)
+    assert tagged_operand(y, other) is None                           # equal values, another layer's buffers
+    y.add_(0)                                                         # modified in place since: stale
+    assert tagged_operand(y, a.to_q) is None
+    with torch.no_grad():
+        a.to_k.act_scales_inv.fill_(1 / 0.02)                         # a re-calibrated consumer: regrouped
+    y = blk.norm1(x)
+    qq, qk = tagged_operand(y, a.to_q), tagged_operand(y, a.to_k)
+    assert qk is not qq and torch.equal(qk, C.quantize_per_tensor_to_int8(y, a.to_k.act_scales_inv, a.to_k.act_zero_points))
+    a.to_v.valid_for_acceleration = False                             # an FP16 fallback layer: takes the FP16 tensor
+    assert tagged_operand(blk.norm1(x), a.to_v) is None
+    unswap_glue_modules(blk)
+    assert tagged_operand(blk.norm1(x), a.to_q) is None

@@ -707,15 +707,28 @@ def test_swap_glue_modules_by_type_keeps_names_and_state_and_undoes():
     assert all(isinstance(m, (nn.LayerNorm, HipLayerNorm)) for m in unet.modules() if "LayerNorm" in type(m).__name__)
     assert all(isinstance(m, GEGLU) for m in unet.modules() if "GEGLU" in type(m).__name__)
     assert all(isinstance(m, Attention) for m in unet.modules() if "Attention" in type(m).__name__)
-    assert swap_glue_modules(unet) == dict(groupnorm=0, silu_folded=0, layernorm=0, geglu=0, attention=0)
+    # operand hand-off links (OPERAND_PAIRS): per transformer block norm1 -> q / k / v, norm2 -> to_q, norm3 -> the GEGLU
+    # projection, GEGLU -> net.2; per ResNet block norm1 -> conv1, norm2 -> conv2; plain references, not sub-modules
+    n_tb = sum(1 for m in unet.modules() if type(m).__name__ == "BasicTransformerBlock")
+    assert n["operand_links"] == 6 * n_tb + 2 * n_res and n["attention_handoff"] == n["attention"] == 2 * n_tb
+    tb = next(m for m in unet.modules() if type(m).__name__ == "BasicTransformerBlock")
+    assert tb.norm1.__dict__["_mixdq_consumers"] == (tb.attn1.to_q, tb.attn1.to_k, tb.attn1.to_v)
+    assert tb.ff.net[0].__dict__["_mixdq_consumers"] == (tb.ff.net[2],) and tb.attn1.hand_off
+    assert res.norm2.__dict__["_mixdq_consumers"] == (res.conv2,) and "_mixdq_consumers" not in tnorm.__dict__
+    assert swap_glue_modules(unet) == dict(groupnorm=0, silu_folded=0, layernorm=0, geglu=0, attention=0,
+                                           operand_links=0, attention_handoff=0)
     with torch.no_grad():
         assert torch.equal(unet(**inputs)[0], want)          # CPU / FP32: every swapped module runs its stock op
     unswap_glue_modules(unet)
     assert {type(m) for m in unet.modules() if isinstance(m, (nn.GroupNorm, nn.LayerNorm, nn.SiLU))} == \
         {nn.GroupNorm, nn.LayerNorm, nn.SiLU}
     assert not any("Hip" in type(m).__name__ for m in unet.modules())
-    n2 = swap_glue_modules(unet, attention=False)
-    assert n2["attention"] == 0 and n2["groupnorm"] == n["groupnorm"]
+    assert not any("_mixdq_consumers" in m.__dict__ or "hand_off" in m.__dict__ for m in unet.modules())
+    n2 = swap_glue_modules(unet, attention=False, operands=False)
+    assert n2["attention"] == 0 and n2["groupnorm"] == n["groupnorm"] and n2["operand_links"] == 0
+    assert not any("_mixdq_consumers" in m.__dict__ for m in unet.modules())
+    n3 = swap_glue_modules(unet, attention=False)               # the links can be added to an earlier swap
+    assert n3["operand_links"] == n["operand_links"] and n3["groupnorm"] == 0 and n3["attention_handoff"] == 0
     assert not any(type(m).__name__ == "HipAttention" for m in unet.modules())
 
 
@@ -753,3 +766,27 @@ def test_pack_static_moves_every_tensor_into_one_allocation_and_keeps_the_networ
     with torch.no_grad():
         assert torch.equal(unet(**inputs)[0], want)
     assert pack_static_(nn.Identity()) == dict(bytes=0, storages=0, tensors=0)
+
+
+def test_tagged_operand_matches_tensor_object_quantizer_buffers_and_version():
+    """nn/glue.py tagged_operand / _attach on the CPU: the hand-off is found only on the tensor it was attached to,
+    unmodified since, for the layer whose own quantizer buffers it was made with."""
+    from mixdq_amd.nn.glue import _attach, tagged_operand
+
+    class L:
+        def __init__(self):
+            self.act_scales_inv, self.act_zero_points = torch.tensor(20.0), torch.tensor(3.0)
+    a, b = L(), L()
+    y, q = torch.zeros(2, 4, dtype=torch.float16), torch.zeros(2, 4, dtype=torch.int8)
+    assert _attach(y, [a, b], [q, None]) is y
+    assert tagged_operand(y, a) is q and tagged_operand(y, b) is None
+    assert tagged_operand(y.clone(), a) is None and tagged_operand(torch.zeros(2, 4), a) is None
+    a2 = L()
+    a2.act_scales_inv = a.act_scales_inv                      # one of the two buffers only
+    assert tagged_operand(y, a2) is None
+    y.mul_(1)
+    assert tagged_operand(y, a) is None
+    z = torch.zeros(2, 4, dtype=torch.float16)
+    assert not hasattr(_attach(z, [a], [None]), "_mixdq_operands")
+    _attach(z, [a], [torch.zeros(8, dtype=torch.int8)])       # a shape that is not the tensor's: never used
+    assert tagged_operand(z, a) is None
