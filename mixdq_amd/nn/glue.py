@@ -52,11 +52,11 @@ def _takes_operand(m) -> bool:
                 and not getattr(m, "split", 0) and hasattr(m, "act_scales_inv"))
 
 
-def _consumers(mod, width=None):
-    out = [c for c in mod.__dict__.get(_CONSUMERS, ()) if _takes_operand(c)]
-    if width is not None:
-        out = [c for c in out if getattr(c, "in_features", getattr(c, "in_channels", None)) == width]
-    return out
+def _consumers(mod, width, device):
+    """The linked layers that would quantize a [.., width] tensor on `device` with a quantizer that lives there."""
+    return [c for c in mod.__dict__.get(_CONSUMERS, ())
+            if _takes_operand(c) and getattr(c, "in_features", getattr(c, "in_channels", None)) == width
+            and c.act_scales_inv.device == device and c.act_zero_points.device == device]
 
 
 def _attach(y, consumers, ints):
@@ -91,7 +91,7 @@ class HipGroupNorm(nn.GroupNorm):
                 and x.is_contiguous(memory_format=torch.channels_last)
                 and _C.groupnorm_supported(x.shape[0], x.shape[2] * x.shape[3], x.shape[1], self.num_groups)):
             # (the consumer reads silu(norm(x)): its operand can ride along only where the SiLU does)
-            cons = _consumers(self, x.shape[1])[:1] if self.fuse_silu else []
+            cons = _consumers(self, x.shape[1], x.device)[:1] if self.fuse_silu else []
             qp = (cons[0].act_scales_inv, cons[0].act_zero_points) if cons else (None, None)
             q, y = _C.groupnorm_silu_quantize(x, self.num_groups, self.weight, self.bias, self.eps, *qp,
                                               silu=self.fuse_silu, want_f16=True)[:2]
@@ -117,7 +117,7 @@ class HipLayerNorm(nn.LayerNorm):
         if (_f16_cuda(x) and x.is_contiguous() and len(self.normalized_shape) == 1 and self.elementwise_affine
                 and self.bias is not None and self.weight.dtype == torch.float16
                 and C == self.normalized_shape[0] and C % 16 == 0 and 0 < C <= 2048):
-            cons = _consumers(self, C)
+            cons = _consumers(self, C, x.device)
             if not cons:
                 return _C.layernorm_quantize(x, self.weight, self.bias, self.eps, [], want_f16=True)[1]
             # one INT8 tensor per DISTINCT quantizer among the consumers (to_q / to_k / to_v are calibrated on the
@@ -144,7 +144,7 @@ class _HipGEGLU:
         from mixdq_amd import _C
         h = self.proj(x)
         if _f16_cuda(h) and h.is_contiguous() and h.shape[-1] % 16 == 0:
-            cons = _consumers(self, h.shape[-1] // 2)[:1]
+            cons = _consumers(self, h.shape[-1] // 2, h.device)[:1]
             qp = (cons[0].act_scales_inv, cons[0].act_zero_points) if cons else (None, None)
             q, y = _C.geglu_quantize(h, *qp, want_f16=True)
             return _attach(y, cons, [q])
@@ -165,7 +165,8 @@ def _attention_core(q, k, v, heads, out_layer=None):
                 and t.stride(1) % 8 == 0 and t.data_ptr() % 16 == 0):
             return None
     if out_layer is not None:
-        if _takes_operand(out_layer) and out_layer.in_features == C:
+        if (_takes_operand(out_layer) and getattr(out_layer, "in_features", None) == C
+                and out_layer.act_scales_inv.device == q.device):
             return out_layer._gemm(_C.attention_f16(q, k, v, heads, out_layer.act_scales_inv,
                                                     out_layer.act_zero_points))
         return out_layer(_C.attention_f16(q, k, v, heads))
