@@ -220,7 +220,10 @@ class QuantizedLinear(nn.Module):
         return qlinear_f16in(x, self.act_scales_inv, self.act_zero_points, w, self.scale, self.bias0,
                              self.bias, _out=out, _bos=bos, _residual=residual, _w4=self.w_packed4)
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, _bos_out: torch.Tensor = None) -> torch.Tensor:
+        """`_bos_out` (BOS layers): a caller-owned [B, T, N] FP16 buffer whose row 0 already holds
+        bos_pre_computed -- the output is written there (rows 1..) and no row-0 copy is launched; for a caller
+        that consumes the result before its next call (nn/glue.py: the swapped cross-attention)."""
         if not self.valid_for_acceleration:
             return self.forward_fp(x)
         if x.dtype != torch.float16:
@@ -238,9 +241,14 @@ class QuantizedLinear(nn.Module):
                 return self._gemm_f16in(x)
             return self._gemm(quant_op(x, self.act_scales_inv, self.act_zero_points))
         # BOS carve-out: token 0 is a precomputed FP16 row, tokens 1.. go through the kernels
+        out = _bos_out
+        if out is not None and not (out.shape == (x.shape[0], x.shape[1], N) and out.dtype == torch.float16
+                                    and out.device == x.device and out.is_contiguous()):
+            out = None
         if qlinear_f16in_wanted(x, N, K, w4=self.w_packed4, bos=True):
-            out = torch.empty((x.shape[0], x.shape[1], N), dtype=torch.float16, device=x.device)
-            out[:, :1, :] = self.bos_pre_computed
+            if out is None:
+                out = torch.empty((x.shape[0], x.shape[1], N), dtype=torch.float16, device=x.device)
+                out[:, :1, :] = self.bos_pre_computed
             return self._gemm_f16in(x, out=out, bos=True)
         x_int = quant_op(x[:, 1:, :], self.act_scales_inv, self.act_zero_points)
-        return self.forward_bos_quantized(x_int, x.shape[0], x.shape[1])
+        return self.forward_bos_quantized(x_int, x.shape[0], x.shape[1], out=out)

@@ -152,6 +152,63 @@ class _HipGEGLU:
         return v * F.gelu(g)
 
 
+_BOS_BUFS = "_mixdq_bos_out"          # in a BOS layer's __dict__: {(B, T, device): [buffer, bos row tensor, its version]}
+
+
+def _project_context(layer, ctx):
+    """`layer(ctx)` for the key / value projection of a swapped attention.  A BOS layer (token 0 of the text context
+    is a precomputed FP16 row, nn/Linear.py) writes into a buffer the layer keeps per (batch, tokens, device), whose
+    row 0 was filled once -- the reference's `out[:, :1] = bos_pre_computed` copy per call (140 launches per step)
+    disappears.  Safe HERE because the swapped attention consumes k / v before it returns; every buffer ever handed
+    out stays alive with the layer (a captured hipGraph holds its address), and row 0 is re-filled in place when
+    the BOS row changes (load_state_dict: the buffer's in-place version)."""
+    if not _is_bos_layer(layer, ctx):
+        return layer(ctx)
+    return layer(ctx, _bos_out=_bos_buffer(layer, ctx))
+
+
+def _bos_buffer(layer, ctx):
+    """The kept [B, T, N] output buffer of a BOS layer for this (batch, tokens, device), row 0 filled."""
+    bufs = layer.__dict__.setdefault(_BOS_BUFS, {})
+    key = (ctx.shape[0], ctx.shape[1], ctx.device)
+    row = layer.bos_pre_computed
+    e = bufs.get(key)
+    if e is None:
+        e = bufs[key] = [torch.empty((ctx.shape[0], ctx.shape[1], layer.out_features), dtype=torch.float16,
+                                     device=ctx.device), None, -1]
+    if e[1] is not row or e[2] != row._version:
+        with torch.no_grad():
+            e[0][:, :1, :] = row
+        e[1], e[2] = row, row._version
+    return e[0]
+
+
+def _is_bos_layer(layer, ctx) -> bool:
+    return bool(getattr(layer, "valid_for_acceleration", False) and getattr(layer, "bos", False)
+                and _f16_cuda(ctx) and ctx.dim() == 3 and ctx.shape[1] > 1
+                and torch.is_tensor(getattr(layer, "bos_pre_computed", None))
+                and layer.bos_pre_computed.device == ctx.device and layer.act_scales_inv.device == ctx.device)
+
+
+def _project_kv(to_k, to_v, ctx):
+    """(to_k(ctx), to_v(ctx)) for a swapped attention.  Two BOS layers with EQUAL activation quantizers (they are
+    calibrated on the same tensor) share one quantize launch of the context's tokens 1.. -- the reference runs it
+    once per layer -- unless the measured table prefers the quantizing GEMM for the shape."""
+    if _is_bos_layer(to_k, ctx) and _is_bos_layer(to_v, ctx) and to_k.in_features == to_v.in_features:
+        from mixdq_amd import _C
+        from mixdq_amd.unet import _quantizer_groups
+        ids = _quantizer_groups(to_k.__dict__.setdefault("_mixdq_memo", {}), "glue_kv", [to_k, to_v])
+        if ids[0] == ids[1] and not any(
+                _C.qlinear_f16in_wanted(ctx, m.out_features, m.in_features, w4=m.w_packed4, bos=True)
+                for m in (to_k, to_v)):
+            B, T = ctx.shape[0], ctx.shape[1]
+            from mixdq_amd.op.quant import quantize_per_tensor_vectorized as quant_op
+            x_int = quant_op(ctx[:, 1:, :], to_k.act_scales_inv, to_k.act_zero_points)
+            return (to_k.forward_bos_quantized(x_int, B, T, out=_bos_buffer(to_k, ctx)),
+                    to_v.forward_bos_quantized(x_int, B, T, out=_bos_buffer(to_v, ctx)))
+    return _project_context(to_k, ctx), _project_context(to_v, ctx)
+
+
 def _attention_core(q, k, v, heads, out_layer=None):
     """FP16 attention on [B, T, C] tensors (heads of 64 columns), or None where the kernel does not take them.
     `out_layer` (to_out.0): where it is a quantized layer that takes an operand, the launch writes that layer's
@@ -185,7 +242,7 @@ class _HipAttend:
         if not self.hand_off:
             return super().forward(x, context)
         context = x if context is None else context
-        q, k, v = self.to_q(x), self.to_k(context), self.to_v(context)
+        q, (k, v) = self.to_q(x), _project_kv(self.to_k, self.to_v, context)
         y = _attention_core(q, k, v, self.heads, out_layer=self.to_out[0])
         return y if y is not None else self.to_out[0](super().attend(q, k, v))
 
@@ -212,7 +269,10 @@ class HipAttnProcessor:
             ctx = hidden_states if encoder_hidden_states is None else encoder_hidden_states
             if encoder_hidden_states is not None and getattr(attn, "norm_cross", False):
                 ctx = attn.norm_encoder_hidden_states(ctx)
-            q, k, v = attn.to_q(hidden_states), attn.to_k(ctx), attn.to_v(ctx)
+            if self.hand_off:
+                q, (k, v) = attn.to_q(hidden_states), _project_kv(attn.to_k, attn.to_v, ctx)
+            else:
+                q, k, v = attn.to_q(hidden_states), attn.to_k(ctx), attn.to_v(ctx)
             o = _attention_core(q, k, v, attn.heads, out_layer=attn.to_out[0] if self.hand_off else None)
             if o is not None:
                 if not self.hand_off:
@@ -336,6 +396,7 @@ def unswap_glue_modules(unet: nn.Module) -> None:
     for mod in unet.modules():
         mod.__dict__.pop(_CONSUMERS, None)
         mod.__dict__.pop("hand_off", None)
+        mod.__dict__.pop(_BOS_BUFS, None)
         if type(mod) is HipGroupNorm:
             mod.__dict__.pop("fuse_silu", None)
             mod.__class__ = nn.GroupNorm

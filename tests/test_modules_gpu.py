@@ -110,6 +110,51 @@ def test_bos_batch2(C, modules_golden):
     assert torch.equal(y2[:, 0], qm.bos_pre_computed.expand(2, -1, -1)[:, 0])
 
 
+def test_bos_layer_writes_into_a_callers_buffer_whose_row_0_is_prefilled(C, modules_golden):
+    """forward(x, _bos_out=buf) (nn/glue.py _project_context: the swapped cross-attention keeps the buffer): same
+    bits as forward(x), written into buf, row 0 left as the caller filled it; a buffer of another shape is ignored."""
+    from mixdq_amd.nn.glue import _project_context
+    c = next(c for c in MODULE_CASES if c["key"] == "lin_bos")
+    qm = build(c, modules_golden)
+    x = module_input(c).to(DEV)
+    with torch.no_grad():
+        want = qm(x)
+        buf = torch.full_like(want, 7.0)
+        buf[:, :1, :] = qm.bos_pre_computed
+        got = qm(x, _bos_out=buf)
+        assert got.data_ptr() == buf.data_ptr() and torch.equal(got, want)
+        wrong = torch.empty((3,) + tuple(want.shape[1:]), dtype=want.dtype, device=DEV)
+        y = qm(x, _bos_out=wrong)
+        assert y.data_ptr() != wrong.data_ptr() and torch.equal(y, want)
+        a, b = _project_context(qm, x), _project_context(qm, x.flip(1))        # one kept buffer per (B, T, device)
+        assert a.data_ptr() == b.data_ptr() and torch.equal(b, qm(x.flip(1)))
+        x2 = torch.cat([x, x.flip(1)], dim=0)
+        assert _project_context(qm, x2).data_ptr() != a.data_ptr() and torch.equal(_project_context(qm, x2), qm(x2))
+        assert len(qm.__dict__["_mixdq_bos_out"]) == 2
+        qm.bos_pre_computed.mul_(2)                                            # the BOS row replaced in place: re-filled
+        assert torch.equal(_project_context(qm, x), qm(x)) and _project_context(qm, x).data_ptr() == a.data_ptr()
+        assert torch.equal(_project_context(qm, x.float()), qm(x.float()))     # not the kernel's input: the plain call
+        # to_k / to_v of one cross-attention: equal quantizers share ONE quantize launch of the context
+        from mixdq_amd.nn.glue import _project_kv
+        qv = build(c, modules_golden)
+        qv.weight_int.copy_(qv.weight_int.flip(0))
+        k, v = _project_kv(qm, qv, x)
+        assert torch.equal(k, qm(x)) and torch.equal(v, qv(x)) and k.data_ptr() == a.data_ptr() != v.data_ptr()
+        n_shared = bench_count(lambda: _project_kv(qm, qv, x))
+        qv.act_scales_inv.mul_(1.5)                                            # unequal quantizers: each its own
+        qv.act_scales.div_(1.5)
+        k, v = _project_kv(qm, qv, x)
+        assert torch.equal(k, qm(x)) and torch.equal(v, qv(x))
+        # (where the quantize-in-GEMM launch is preferred -- MIXDQ_F16IN=1 -- neither form has a quantize launch)
+        fused = C.qlinear_f16in_wanted(x, qm.out_features, qm.in_features, bos=True)
+        assert bench_count(lambda: _project_kv(qm, qv, x)) == n_shared + (0 if fused else 1)
+
+
+def bench_count(fn):
+    import bench
+    return bench.count_kernels(fn, torch.device(DEV))
+
+
 def test_split_shortcut_batch2_channels_last_and_nchw(C, modules_golden):
     c = next(c for c in MODULE_CASES if c["key"] == "conv_split")
     qm = build(c, modules_golden)
