@@ -23,6 +23,11 @@ bits -- and attaches it to the FP16 tensor it returns.  QuantizedLinear / Quanti
 with THEIR quantizer tensors on THEIR input tensor object (`tagged_operand`: identity of the tensor, of the two
 quantizer buffers, and the tensor's in-place version) and skip the quantize launch; anything else -- another tensor, a
 modified one, a re-quantized layer -- finds nothing and quantizes as before.  The FP16 tensor is always written too.
+Inside a swapped attention module, where nothing escapes between its input and to_out.0's output
+(`_attention_hand_off`): to_q / to_k / to_v of a self-attention are ONE GEMM against their row-concatenated weights,
+the attention launch writes to_out.0's INT8 operand, a cross-attention's k / v go into kept BOS buffers from one shared
+quantize launch, and to_q + attention + to_out.0's quantizer are one launch -- the launch forms of the fused graph,
+each bit-identical to the chain it replaces (tests/test_fused_gpu.py).
 
 The swap changes `module.__class__` to a subclass of the module's own class: parameters, buffers, hooks, names and
 `isinstance` checks are untouched, `unswap_glue_modules` restores the stock classes.  A swapped module falls back to
@@ -230,21 +235,102 @@ def _attention_core(q, k, v, heads, out_layer=None):
     return _C.attention_f16(q, k, v, heads)
 
 
+def _operand(x, layer):
+    """quantize(x) with `layer`'s quantizer: the one its producer attached, else the layer's own quantize launch."""
+    q = tagged_operand(x, layer)
+    if q is None:
+        from mixdq_amd.op.quant import quantize_per_tensor_vectorized as quant_op
+        q = quant_op(x, layer.act_scales_inv, layer.act_zero_points)
+    return q
+
+
+def _self_qkv(attn, x):
+    """(q, k, v) of a self-attention from ONE GEMM against the row-concatenated weights of to_q / to_k / to_v --
+    three W8A8 (or three packed 4-bit) layers without bias whose activation quantizers are equal (they read the same
+    tensor): per-channel scale / bias0 concatenate, so every output element is computed exactly as by the three
+    launches (mixdq_amd.unet._pack_rows: the pack is the storage, the layers' buffers become views of it -- names,
+    shapes and values of the state_dict are unchanged).  None where the layers do not qualify."""
+    layers = [attn.to_q, attn.to_k, attn.to_v]
+    C = x.shape[-1]
+    if not (x.is_contiguous() and all(_takes_operand(m) and m.bias is None and m.in_features == C
+                                      and m.act_scales_inv.device == x.device for m in layers)):
+        return None
+    from mixdq_amd.op.qlinear import qlinear
+    from mixdq_amd.unet import _pack_rows, _pack_valid, _quantizer_groups, _uniform_storage
+    if not _uniform_storage(layers) or len(set(_quantizer_groups(
+            attn.__dict__.setdefault("_mixdq_memo", {}), "glue_qkv", layers))) != 1:
+        return None
+    pack = attn.__dict__.get("_qkv")
+    if not _pack_valid(pack, layers):
+        pack = attn.__dict__["_qkv"] = _pack_rows(layers)
+    q0 = layers[0]
+    x_int = next((t for t in (tagged_operand(x, m) for m in layers) if t is not None), None)
+    if x_int is None:
+        x_int = _operand(x, q0)
+    qkv = qlinear(x_int, pack["w"], pack["wscale"], q0.act_scales, q0.act_zero_points, pack["wsum"], pack["scale"],
+                  pack["bias0"], None, _w4=pack["w4"])
+    n = pack["C"]
+    return qkv[..., :n], qkv[..., n:2 * n], qkv[..., 2 * n:]
+
+
+def _cross_one_launch(attn, x, k, v):
+    """to_out.0(attention(to_q(x), k, v)) of a cross-attention with to_q's GEMM, the attention core and to_out.0's
+    quantizer in ONE launch (mixdq_qlinear_w8a8_attn: the 77 keys / values fit a workgroup's LDS; bit-identical to
+    the three steps, tests/test_fused_gpu.py).  None where the launch does not take the problem."""
+    from mixdq_amd import _C
+    from mixdq_amd.unet import CROSS_FUSE_MAX_ROWS
+    q, out = attn.to_q, attn.to_out[0]
+    if not (_takes_operand(q) and q.bias is None and _takes_operand(out) and x.is_contiguous()
+            and q.in_features == x.shape[-1] and attn.heads * 64 == q.out_features == out.in_features
+            and q.act_scales_inv.device == x.device and out.act_scales_inv.device == x.device
+            and all(_f16_cuda(z) and z.dim() == 3 and z.stride(-1) == 1 and z.stride(0) % 8 == 0
+                    and z.stride(1) % 8 == 0 and z.data_ptr() % 16 == 0 for z in (k, v))
+            and k.shape == v.shape and k.shape[0] == x.shape[0]
+            and x.shape[0] * x.shape[1] <= CROSS_FUSE_MAX_ROWS
+            and _C.qlinear_attention_supported(x.shape, q.out_features, q.in_features, k)):
+        return None
+    o_int = _C.qlinear_attention(_operand(x, q), q.weight_int4 if q.w_packed4 else q.weight_int, q.scale, q.bias0,
+                                 k, v, out.act_scales_inv, out.act_zero_points, _w4=q.w_packed4)
+    return out._gemm(o_int)
+
+
+def _attention_hand_off(attn, x, context):
+    """to_out.0(attention(...)) of a swapped attention module with everything between its input and to_out.0's
+    output inside this function (nothing escapes: kept buffers and INT8 intermediates are safe): self-attention =
+    one q | k | v GEMM + the attention launch writing to_out.0's operand; cross-attention = k / v into kept BOS
+    buffers from one shared quantize launch + (to_q, attention, to_out.0's quantizer) in one launch.  Each step
+    falls back to the module-by-module form where its conditions do not hold; None: not an input of the kernels."""
+    if not (_f16_cuda(x) and x.dim() == 3 and getattr(attn.to_q, "out_features", None) == attn.heads * 64):
+        return None                                     # (decided before anything is launched)
+    if context is None:
+        qkv = _self_qkv(attn, x)
+        q, k, v = qkv if qkv is not None else (attn.to_q(x), attn.to_k(x), attn.to_v(x))
+    else:
+        k, v = _project_kv(attn.to_k, attn.to_v, context)
+        y = _cross_one_launch(attn, x, k, v)
+        if y is not None:
+            return y
+        q = attn.to_q(x)
+    y = _attention_core(q, k, v, attn.heads, out_layer=attn.to_out[0])
+    if y is None:         # (operands the kernel does not take after all: PyTorch's core on the projections made)
+        B, T, C = q.shape
+        h = attn.heads
+        o = F.scaled_dot_product_attention(*(t.unflatten(-1, (h, C // h)).transpose(1, 2) for t in (q, k, v)))
+        y = attn.to_out[0](o.transpose(1, 2).reshape(B, T, C))
+    return y
+
+
 class _HipAttend:
     """Mix-in for mixdq_amd.unet.Attention: `attend` (the FP16 core between the projections) on the HIP kernel."""
-    hand_off = False            # (swap_glue_modules(operands=True): to_out.0's operand from the attention launch)
+    hand_off = False            # (swap_glue_modules(operands=True): see _attention_hand_off)
 
     def attend(self, q, k, v):
         o = _attention_core(q, k, v, self.heads)
         return o if o is not None else super().attend(q, k, v)
 
     def forward(self, x, context=None):
-        if not self.hand_off:
-            return super().forward(x, context)
-        context = x if context is None else context
-        q, (k, v) = self.to_q(x), _project_kv(self.to_k, self.to_v, context)
-        y = _attention_core(q, k, v, self.heads, out_layer=self.to_out[0])
-        return y if y is not None else self.to_out[0](super().attend(q, k, v))
+        y = _attention_hand_off(self, x, context) if self.hand_off else None
+        return y if y is not None else super().forward(x, context)
 
 
 class HipAttnProcessor:
@@ -269,14 +355,14 @@ class HipAttnProcessor:
             ctx = hidden_states if encoder_hidden_states is None else encoder_hidden_states
             if encoder_hidden_states is not None and getattr(attn, "norm_cross", False):
                 ctx = attn.norm_encoder_hidden_states(ctx)
+            o = None
             if self.hand_off:
-                q, (k, v) = attn.to_q(hidden_states), _project_kv(attn.to_k, attn.to_v, ctx)
-            else:
-                q, k, v = attn.to_q(hidden_states), attn.to_k(ctx), attn.to_v(ctx)
-            o = _attention_core(q, k, v, attn.heads, out_layer=attn.to_out[0] if self.hand_off else None)
-            if o is not None:
-                if not self.hand_off:
+                o = _attention_hand_off(attn, hidden_states, None if encoder_hidden_states is None else ctx)
+            if o is None:
+                o = _attention_core(attn.to_q(hidden_states), attn.to_k(ctx), attn.to_v(ctx), attn.heads)
+                if o is not None:
                     o = attn.to_out[0](o)
+            if o is not None:
                 return attn.to_out[1](o) if len(attn.to_out) > 1 else o
         if self.fallback is None:
             raise RuntimeError("HipAttnProcessor: unsupported attention call and no fallback processor")
@@ -397,6 +483,8 @@ def unswap_glue_modules(unet: nn.Module) -> None:
         mod.__dict__.pop(_CONSUMERS, None)
         mod.__dict__.pop("hand_off", None)
         mod.__dict__.pop(_BOS_BUFS, None)
+        if isinstance(mod, _HipAttend) or isinstance(getattr(mod, "processor", None), HipAttnProcessor):
+            mod.__dict__.pop("_qkv", None)      # (_self_qkv's pack record; the layers' buffers stay views of the pack)
         if type(mod) is HipGroupNorm:
             mod.__dict__.pop("fuse_silu", None)
             mod.__class__ = nn.GroupNorm

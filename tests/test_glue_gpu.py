@@ -188,7 +188,8 @@ def test_attention_core_swapped_and_diffusers_processor(C):
     assert fake.processor is stock_proc
 
 
-def test_swapped_unet_is_the_chain_of_its_kernels(C):
+@pytest.mark.parametrize("heads64", [False, True], ids=["heads16", "heads64"])
+def test_swapped_unet_is_the_chain_of_its_kernels(C, heads64):
     """The tiny UNet, Linear / Conv2d swapped (the reference's surface) and then swap_glue=True: same names and
     state_dict keys, output == the de-fused reference of the fused graph (every fused launch replaced by the chain of
     this repo's FP16-output kernels + the layer's own quantize launch: the same arithmetic at every rounding point
@@ -199,8 +200,12 @@ def test_swapped_unet_is_the_chain_of_its_kernels(C):
     from mixdq_amd.nn.glue import unswap_glue_modules
     from mixdq_amd.quantize_sdxl import example_inputs, hip_graph_opt, quantize_unet
     from mixdq_amd.unet import build_unet, defused, quantizable_layers
-    unet = build_unet(DEV, cfg=bench.TINY_CFG)
-    inputs = example_inputs(2, 16, DEV, seed=7)
+    # heads64: 64-wide heads and 256 / 64 tokens per level -- the attention modules then run this repo's kernels and
+    # the launch forms of _attention_hand_off (one q | k | v GEMM, to_q + cross-attention + quantize in one launch);
+    # heads16: PyTorch's SDPA stays (mixdq_attention_f16 is head_dim 64 only), everything else is swapped
+    cfg = dict(bench.TINY_CFG, block_out_channels=(64, 128, 256), head_dim=64) if heads64 else bench.TINY_CFG
+    unet = build_unet(DEV, cfg=cfg)
+    inputs = example_inputs(2, 32 if heads64 else 16, DEV, seed=7)
     ckpt = calibrate(unet, [inputs])
     bos_dict = precompute_bos(unet, inputs["encoder_hidden_states"])
     names = list(quantizable_layers(unet))
@@ -228,7 +233,12 @@ def test_swapped_unet_is_the_chain_of_its_kernels(C):
     n_tb = sum(1 for m in unet.modules() if type(m).__name__ == "BasicTransformerBlock")
     # per block: the quantize launches of q | k | v, to_q, the GEGLU projection, net.2, two to_out.0 and one of the two
     # of attn2.to_k / to_v (equal quantizers: the context is quantized once); per ResNet block those of conv1 / conv2
-    assert k_no - k_yes >= 9 * n_tb, (k_no, k_yes)
+    # (heads64) ... and two launches of the self-attention's three projections, one of to_q / cross-attention
+    assert k_no - k_yes >= (12 if heads64 else 6) * n_tb, (k_no, k_yes)
+    if heads64:
+        from mixdq_amd.nn.glue import _HipAttend
+        assert all("_qkv" in m.__dict__ for m in unet.modules()
+                   if isinstance(m, _HipAttend) and m.to_k.in_features == m.to_q.in_features)
     with torch.no_grad():
         unet.set_fused(True)
         with defused():
