@@ -78,6 +78,7 @@ struct GnRaw {
   int8_t* q[2];
 };
 
+template <int U>
 __global__ void gn_stats_kernel(const __half* __restrict__ x, const __half* __restrict__ x2,
                                 float2* __restrict__ partial, GnGeom g) {
   MIXDQ_ARGS_NOW(x, x2, partial, g.C, g.G, g.cg, g.OC, g.PP, g.HW, g.ppb, g.nchunk, g.C1);
@@ -92,14 +93,26 @@ __global__ void gn_stats_kernel(const __half* __restrict__ x, const __half* __re
   int xs;
   const __half* base = gn_src(x, x2, g, n, o, xs);
   float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
-  for (int64_t p = p_begin + pp; p < p_end; p += g.PP) {
-    const Half8 h = *reinterpret_cast<const Half8*>(base + p * xs);
+  // U pixels of this thread in flight at a time (4; 2 where a thread has no more than two; 1 = the plain loop, for A/B
+  // runs): as `load; use` per pixel the compiler waits for each load before it issues the next, and a thread's 2 .. 16
+  // pixels become as many trips to the memory side (the tensor was written by the producing conv on other XCDs) with
+  // two waves per SIMD to hide them.  Unconditional, clamped addresses (no branch between the loads); the additions
+  // are the same, in the same order (pixels ascending, j ascending).
+  for (int64_t p = p_begin + pp; p < p_end; p += (int64_t)U * g.PP) {
+    Half8 h[U];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float v = half_at(h, j);
-      if (j < jb) { s0 = __fadd_rn(s0, v); q0 = __builtin_fmaf(v, v, q0); }
-      else        { s1 = __fadd_rn(s1, v); q1 = __builtin_fmaf(v, v, q1); }
-    }
+    for (int u = 0; u < U; ++u)
+      h[u] = *reinterpret_cast<const Half8*>(base + min(p + (int64_t)u * g.PP, p_end - 1) * xs);
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+      if (p + (int64_t)u * g.PP < p_end) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float v = half_at(h[u], j);
+          if (j < jb) { s0 = __fadd_rn(s0, v); q0 = __builtin_fmaf(v, v, q0); }
+          else        { s1 = __fadd_rn(s1, v); q1 = __builtin_fmaf(v, v, q1); }
+        }
+      }
   }
   lds[4 * t + 0] = s0; lds[4 * t + 1] = q0; lds[4 * t + 2] = s1; lds[4 * t + 3] = q1;
   __syncthreads();
@@ -824,8 +837,11 @@ extern "C" int mixdq_groupnorm_silu_quantize3(const void* x_nhwc, int C1, const 
   hipStream_t stream = (hipStream_t)stream_;
   float2* partial = (float2*)workspace;
   const int threads = g.OC * g.PP;
-  gn_stats_kernel<<<dim3(g.nchunk, N), threads, threads * 4 * sizeof(float), stream>>>(
-      (const __half*)x_nhwc, (const __half*)x2_nhwc, partial, g);
+  static const int stats_unroll = [] { const char* e = getenv("MIXDQ_GN_STATS_UNROLL"); return e ? atoi(e) : 0; }();
+  const int su = stats_unroll == 1 || stats_unroll == 2 || stats_unroll == 4 ? stats_unroll : (g.ppb / g.PP <= 2 ? 2 : 4);
+  (su == 1 ? gn_stats_kernel<1> : su == 2 ? gn_stats_kernel<2> : gn_stats_kernel<4>)
+      <<<dim3(g.nchunk, N), threads, threads * 4 * sizeof(float), stream>>>(
+          (const __half*)x_nhwc, (const __half*)x2_nhwc, partial, g);
   // MIXDQ_GN_SLICED=1 (measured, off): with more than 64 partials per group the apply pass is cut into channel
   // slices (blockIdx.z) of whole groups, at most 8 groups each, so that a block needs -- and reduces in its
   // prologue -- only its slice's statistics (4 x 342 x 8 B at C = 640) and the finalize launch disappears (46 per

@@ -102,6 +102,24 @@ def test_groupnorm_sliced_apply_pass_same_bits():
     assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-3000:]
 
 
+@pytest.mark.parametrize("unroll", ["1", "4"])
+def test_groupnorm_statistics_pixels_in_flight_same_bits(unroll):
+    """The statistics pass keeps 4 pixels of a thread in flight (2 where a thread has no more than two;
+    MIXDQ_GN_STATS_UNROLL=1: the plain loop, =4: four everywhere): the same additions in the same order -- the
+    GroupNorm parity cases against the oracle again in a child process with the switch set (read once per process)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MIXDQ_GN_STATS_UNROLL=unroll)
+    r = subprocess.run([sys.executable, "-m", "pytest", "tests/test_fused_gpu.py", "-m", "gpu", "-q", "-x",
+                        "-p", "no:cacheprovider", "-k",
+                        "test_groupnorm_silu_quantize or two_sources or raw_outputs"],
+                       cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-3000:]
+
+
 def test_groupnorm_unsupported_shapes_raise(C):
     x = torch.zeros(1, 36, 4, 4, dtype=torch.float16, device=DEV).contiguous(
         memory_format=torch.channels_last)

@@ -38,4 +38,12 @@ for f in sorted(glob.glob("$out/bench_*.json")):
     except Exception as e:
         print(f, 'ERR', e)
 PY
+# (appended late in round 6) what the statistics pass's pixels-in-flight are worth: one library, the switch, alternating
+for rep in 1 2; do for u in 1 0; do
+  MIXDQ_GN_STATS_UNROLL=$u timeout 300 python bench.py --no-fp16 --no-cpu-baseline --no-roofline --no-dropin --no-lnchain --no-batch8 --steps 40 > $out/ab_gnstats_${u}_$rep.json 2>/dev/null
+  python3 -c "
+import json,sys
+try: print('MIXDQ_GN_STATS_UNROLL=$u rep $rep ms %.3f' % json.loads(open('$out/ab_gnstats_${u}_$rep.json').read().strip().splitlines()[-1])['ms_per_step'])
+except Exception as e: print('ERR', e)" | tee -a $out/ab_gnstats.txt
+done; done
 cat $out/pytest_gpu.txt; tail -24 $out/pmc.txt; head -14 $out/step_breakdown_bs1.txt
