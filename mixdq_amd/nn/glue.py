@@ -338,7 +338,8 @@ class HipAttnProcessor:
     AttnProcessor2_0) whose softmax(q k^T) v runs on mixdq_attention_f16; the projections stay the (quantized)
     modules of `attn`.  Installed by `attn.set_processor(HipAttnProcessor())` for every module that has one.
     Covers what the SDXL UNet uses: no attention mask, no group / spatial norm inside the attention, no added
-    key / value projections, residual_connection False -- anything else goes to the processor it replaced."""
+    key / value projections, residual_connection False, softmax scale 1 / 8 -- anything else goes to the processor
+    it replaced."""
 
     def __init__(self, fallback=None, hand_off=False):
         self.fallback = fallback
@@ -350,7 +351,8 @@ class HipAttnProcessor:
                  and getattr(attn, "group_norm", None) is None and getattr(attn, "spatial_norm", None) is None
                  and getattr(attn, "norm_q", None) is None and getattr(attn, "norm_k", None) is None
                  and not getattr(attn, "residual_connection", False)
-                 and getattr(attn, "rescale_output_factor", 1.0) == 1.0)
+                 and getattr(attn, "rescale_output_factor", 1.0) == 1.0
+                 and getattr(attn, "scale", 0.125) == 0.125)       # (the kernel's softmax scale: 64 ** -0.5)
         if plain:
             ctx = hidden_states if encoder_hidden_states is None else encoder_hidden_states
             if encoder_hidden_states is not None and getattr(attn, "norm_cross", False):
