@@ -158,6 +158,11 @@ class _HipGEGLU:
 
 
 _BOS_BUFS = "_mixdq_bos_out"          # in a BOS layer's __dict__: {(B, T, device): [buffer, bos row tensor, its version]}
+# A kept buffer is never freed while its layer lives (a captured graph may hold its address), so their NUMBER is
+# bounded instead: a layer that has handed out this many (batch, tokens, device) shapes serves further shapes the
+# reference's way (allocate + copy row 0 per call).  197 KB per image at 77 x 1280: 16 shapes of <= 64 images stay
+# under 0.2 GB per layer pair even in the worst case; a service with a few fixed batch sizes never gets near it.
+BOS_BUFFERS_MAX = int(__import__("os").environ.get("MIXDQ_BOS_BUFFERS_MAX", "16"))
 
 
 def _project_context(layer, ctx):
@@ -169,16 +174,19 @@ def _project_context(layer, ctx):
     the BOS row changes (load_state_dict: the buffer's in-place version)."""
     if not _is_bos_layer(layer, ctx):
         return layer(ctx)
-    return layer(ctx, _bos_out=_bos_buffer(layer, ctx))
+    return layer(ctx, _bos_out=_bos_buffer(layer, ctx))        # (None past BOS_BUFFERS_MAX shapes: the plain call)
 
 
 def _bos_buffer(layer, ctx):
-    """The kept [B, T, N] output buffer of a BOS layer for this (batch, tokens, device), row 0 filled."""
+    """The kept [B, T, N] output buffer of a BOS layer for this (batch, tokens, device), row 0 filled; None when the
+    layer already keeps BOS_BUFFERS_MAX of them.  One forward at a time per module, as with a captured graph."""
     bufs = layer.__dict__.setdefault(_BOS_BUFS, {})
     key = (ctx.shape[0], ctx.shape[1], ctx.device)
     row = layer.bos_pre_computed
     e = bufs.get(key)
     if e is None:
+        if len(bufs) >= BOS_BUFFERS_MAX:
+            return None
         e = bufs[key] = [torch.empty((ctx.shape[0], ctx.shape[1], layer.out_features), dtype=torch.float16,
                                      device=ctx.device), None, -1]
     if e[1] is not row or e[2] != row._version:
@@ -209,6 +217,7 @@ def _project_kv(to_k, to_v, ctx):
             B, T = ctx.shape[0], ctx.shape[1]
             from mixdq_amd.op.quant import quantize_per_tensor_vectorized as quant_op
             x_int = quant_op(ctx[:, 1:, :], to_k.act_scales_inv, to_k.act_zero_points)
+            # (out=None: forward_bos_quantized allocates and fills row 0 itself, as the reference does)
             return (to_k.forward_bos_quantized(x_int, B, T, out=_bos_buffer(to_k, ctx)),
                     to_v.forward_bos_quantized(x_int, B, T, out=_bos_buffer(to_v, ctx)))
     return _project_context(to_k, ctx), _project_context(to_v, ctx)

@@ -790,3 +790,33 @@ def test_tagged_operand_matches_tensor_object_quantizer_buffers_and_version():
     assert not hasattr(_attach(z, [a], [None]), "_mixdq_operands")
     _attach(z, [a], [torch.zeros(8, dtype=torch.int8)])       # a shape that is not the tensor's: never used
     assert tagged_operand(z, a) is None
+
+
+def test_kept_bos_buffers_are_bounded_in_number_and_refilled_when_the_row_changes(monkeypatch):
+    """nn/glue.py _bos_buffer (host logic; the GPU side: tests/test_modules_gpu.py): one buffer per (batch, tokens,
+    device), never replaced; past BOS_BUFFERS_MAX shapes None (the caller then runs the reference's allocate + copy);
+    row 0 re-filled in place when the BOS row was replaced or modified."""
+    import mixdq_amd.nn.glue as G
+
+    class L(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.out_features = 8
+            self.register_buffer("bos_pre_computed", torch.arange(8, dtype=torch.float16).view(1, 1, 8))
+    m = L()
+    monkeypatch.setattr(G, "BOS_BUFFERS_MAX", 2)
+    a = G._bos_buffer(m, torch.zeros(2, 5, 4, dtype=torch.float16))
+    assert a.shape == (2, 5, 8) and torch.equal(a[:, 0], m.bos_pre_computed.expand(2, 1, 8)[:, 0])
+    assert G._bos_buffer(m, torch.zeros(2, 5, 4, dtype=torch.float16)) is a
+    b = G._bos_buffer(m, torch.zeros(3, 5, 4, dtype=torch.float16))
+    assert b is not a and b.shape == (3, 5, 8)
+    assert G._bos_buffer(m, torch.zeros(4, 5, 4, dtype=torch.float16)) is None       # the third shape: not kept
+    assert G._bos_buffer(m, torch.zeros(2, 5, 4, dtype=torch.float16)) is a           # the kept ones still served
+    a[:, 1:] = 7
+    m.bos_pre_computed.mul_(2)                                                          # modified in place
+    a2 = G._bos_buffer(m, torch.zeros(2, 5, 4, dtype=torch.float16))
+    assert a2 is a and torch.equal(a[:, 0], m.bos_pre_computed.expand(2, 1, 8)[:, 0]) and (a[:, 1:] == 7).all()
+    m.bos_pre_computed = torch.ones(1, 1, 8, dtype=torch.float16)                      # replaced
+    assert torch.equal(G._bos_buffer(m, torch.zeros(2, 5, 4, dtype=torch.float16))[:, 0], torch.ones(2, 8, dtype=torch.float16))
+    G.unswap_glue_modules(m)
+    assert "_mixdq_bos_out" not in m.__dict__
